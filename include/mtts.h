@@ -1,0 +1,308 @@
+/* libmtts_hip -- C ABI of the MI355X-native multilingual Tacotron-2 text->mel hot path.
+ *
+ * The reference (Tomiinek/Multilingual_Text_to_Speech) has no FFI: its hot path is a chain of ATen ops
+ * behind torch.nn.Module.  Each entry point below names the reference call sites it replaces.
+ * Conventions: raw device pointers, explicit sizes/strides in ELEMENTS, `stream` is a hipStream_t;
+ * return 0 on success, non-zero on error (text via mtts_last_error(), thread-local); functions never
+ * allocate, never synchronise the stream and are re-entrant per (device, stream).  fp32 throughout.
+ * Activations are channel-last: a conv input [N, C, L] of the reference is stored [N*L, C].
+ * Dropout masks are inputs (uint8 keep flags + a scale) so that tests can inject the reference's draws.
+ *
+ * This header is also parsed by multilingual_text_to_speech_amd/_C.py to build the ctypes mirrors of
+ * the structs: keep every field declaration of the form `<type> <name>;` with the types used below.
+ */
+#ifndef MTTS_H
+#define MTTS_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { MTTS_ACT_NONE = 0, MTTS_ACT_RELU = 1, MTTS_ACT_TANH = 2, MTTS_ACT_SIGMOID = 3 };
+
+/* ---- general fp32 MFMA GEMM:  C[M,N] = epilogue(alpha * sum_k A(m,k) B(n,k)) ------------------------------
+ * Replaces torch.nn.Linear / F.conv1d / their autograd GEMMs at: modules/tacotron2.py:34,111-112 (prenet,
+ * frame/stop projection), modules/attention.py:18-20,63 (memory/location projections), modules/layers.py:75
+ * (Conv1d inside ConvBlock), modules/generated.py:42 (F.conv1d with generated kernels), modules/encoder.py:33
+ * (LSTM input projection), modules/classifier.py:53-54.
+ * transX = 0: operand stored [rows][K] (K contiguous); 1: stored [K][rows].
+ * Convolution = implicit GEMM over channel-last rows r = n*seq_len + l: K = taps*Kc, tap t reads row
+ * r + shift0 + t*dshift and contributes zero outside [0, seq_len) ('same' zero padding, layers.py:72-74). */
+typedef struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    const uint8_t* mask;
+    int M;
+    int N;
+    int K;
+    int lda;
+    int ldb;
+    int ldc;
+    int ldmask;
+    int transA;
+    int transB;
+    int taps;
+    int Kc;
+    int seq_len;
+    int shift_mode;   /* 0 none; 1: A rows shifted per tap (conv fwd / bwd-data); 2: B k-rows shifted by the z tap (wgrad) */
+    int shift0;
+    int dshift;
+    long b_tap;       /* B element offset per tap (transB conv bwd-data) */
+    int batch;        /* grid.z = batch * zt */
+    int zt;           /* >1: z % zt selects the tap (shift, C offset c_ztap) for weight gradients */
+    long a_z;
+    long b_z;
+    long c_z;
+    long bias_z;
+    long c_ztap;
+    float alpha;
+    float beta;
+    int act;
+    float mask_scale;
+} GemmArgs;
+
+int mtts_gemm_ex(const GemmArgs* args, void* stream);
+int mtts_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+              int transA, int transB, float alpha, float beta, const float* bias, int act, void* stream);
+
+/* ---- BatchNorm + activation + dropout (+ highway gate), channel-last, fwd/bwd ------------------------------
+ * Replaces BatchNorm1d/F.batch_norm + activation + Dropout of modules/layers.py:78-86, modules/generated.py:94-96
+ * and the highway combination modules/layers.py:149-153,174-178.  Statistics cover all R rows (padding included). */
+typedef struct BnArgs {
+    const float* x;        /* [R, C] conv output */
+    const float* gamma;
+    const float* beta;
+    float* running_mean;   /* updated when training (nullable in bwd) */
+    float* running_var;
+    float* save_mean;      /* [C] written by fwd, read by bwd */
+    float* save_rstd;
+    const uint8_t* mask;   /* [R, C] keep flags or NULL */
+    const float* resid;    /* highway input [R, C/2] or NULL */
+    float* y;              /* [R, C] or [R, C/2] (highway) */
+    float* ws;             /* mtts_bn_workspace_floats(C) floats */
+    int R;
+    int C;
+    int training;
+    float momentum;
+    float eps;
+    int act;
+    float mask_scale;
+    int hw_groups;         /* 0 plain; G > 0 highway with G groups, C = 2*G*Cg, gate chunk then value chunk per group */
+    const float* dy;       /* bwd: [R, Cy] */
+    float* dx;             /* bwd: [R, C] gradient w.r.t. the conv output */
+    float* dgamma;
+    float* dbeta;
+    float* dresid;         /* bwd: [R, C/2] gradient w.r.t. the highway input (overwritten) or NULL */
+} BnArgs;
+
+long mtts_bn_workspace_floats(int C);
+int mtts_bn_act_fwd(const BnArgs* args, void* stream);
+int mtts_bn_act_bwd(const BnArgs* args, void* stream);
+
+/* ---- skinny GEMM (batch rows x streamed weight rows) with fused epilogues ----------------------------------
+ * Replaces torch.nn.LSTMCell (modules/layers.py:18-47, called at modules/tacotron2.py:185,188), the attention
+ * query projection (modules/attention.py:68), per-step prenet (modules/tacotron2.py:37-46,181) and the
+ * frame/stop projection (modules/tacotron2.py:192-193).  Y[B,N] = sum_s X_s[B,K_s] W_s[N,K_s]^T. */
+typedef struct SkSeg {
+    const float* x;
+    const float* w;
+    int K;
+    int ldx;
+    int ldw;
+} SkSeg;
+
+typedef struct SkinnyArgs {
+    SkSeg seg[3];
+    int nseg;
+    int B;
+    int N;
+    int ksplit;            /* > 1: raw partial sums out[ks*out_ks + row*ldo + col] */
+    float* out;
+    int ldo;
+    long out_ks;
+    const float* bias;
+    int act;
+    const uint8_t* mask;
+    int ldmask;
+    float mask_scale;
+    int lstm;              /* != 0: fused LSTM cell epilogue, N = 4H, gate order i,f,g,o */
+    int H;
+    const float* pre;      /* [B,4H] precomputed addend or NULL */
+    int ldpre;
+    const float* b_ih;
+    const float* b_hh;
+    const float* h_prev;
+    const float* c_prev;
+    float* h_out;
+    float* c_out;
+    float* gates_out;      /* [B,4H] activated gates saved for backward or NULL */
+    const uint8_t* hmask;
+    const uint8_t* cmask;
+    float hscale;
+    int zone;              /* 0 dropout on h (layers.py:44-47); 1 zoneout training; 2 zoneout eval (layers.py:26-34) */
+    float zh;
+    float zc;
+    const int* lengths;    /* packed-sequence carry: rows with t >= lengths[row] keep their state (encoder.py:41-44) */
+    int t;
+    float* y_out;
+    int ldy;
+} SkinnyArgs;
+
+int mtts_skinny_gemm(const SkinnyArgs* args, void* stream);
+
+/* ---- location-sensitive attention step -------------------------------------------------------------------
+ * Replaces LocationSensitiveAttention.forward for one decoder step: modules/attention.py:39-45,67-86.
+ * The location Conv1d(1->C,k) followed by Linear(C->A) is applied as ONE k-tap filter bank U = W_loc * W_conv
+ * ([A,k]); PL = M + bias + loc(cum) is produced for the NEXT step by the current one (it only depends on the
+ * cumulative alignment), so the per-step critical path is energies -> masked softmax -> context. */
+typedef struct AttnStepArgs {
+    const float* qpart;    /* [kq][B][A] partial query projections (summed here) */
+    int kq;
+    long q_ks;
+    const float* PL;       /* [B,L,A] = M + bias + loc(cum_in) */
+    float* PL_next;        /* [B,L,A] for cum_out (nullable) */
+    const float* Mt;       /* [B,L,A] memory transform */
+    const float* U;        /* [A,ksz] */
+    const float* bias;     /* [A] */
+    const float* v;        /* [A] energy weights */
+    const float* memory;   /* [B,L,Dm] */
+    const int* lengths;    /* [B] */
+    const float* cum_in;   /* [B,L] */
+    float* cum_out;        /* [B,L] */
+    float* w_out;          /* [B,L] alignment of this step */
+    float* ctx_out;        /* [B,Dm] */
+    int B;
+    int L;
+    int A;
+    int Dm;
+    int ksz;
+    int nch;               /* workgroups per sample */
+} AttnStepArgs;
+
+int mtts_attn_step_fwd(const AttnStepArgs* args, void* stream);
+
+/* ---- whole decoder loop, forward ----------------------------------------------------------------------------
+ * Replaces Decoder._decode (modules/tacotron2.py:148-209) incl. _target_init (:126-133), the attention reset
+ * (modules/attention.py:23-28) and both regularised LSTM cells.  Time-major saved state so that step slices are
+ * contiguous.  Steps [t0, t1) are executed; state arrays are indexed by absolute step, so a call can resume. */
+typedef struct DecoderArgs {
+    int B;
+    int L;
+    int T;                 /* allocated steps */
+    int t0;
+    int t1;
+    int M;                 /* num_mels */
+    int P;                 /* prenet width */
+    int H;
+    int A;
+    int Dm;
+    int ksz;
+    int C;                 /* location channels */
+    int n_prenet;          /* prenet layers (<= 4) */
+    int training;
+    int zone;              /* decoder_regularization: 0 dropout, 1 zoneout */
+    float p_prenet;        /* dropout prob of the prenet (always on) */
+    float p_hidden;        /* dropout_hidden, or zoneout_hidden */
+    float p_cell;          /* zoneout_cell */
+    /* inputs */
+    const float* memory;   /* [B,L,Dm] encoder output (+ embeddings) */
+    const int* lengths;    /* [B] */
+    const float* frames_in;/* [T,B,M] teacher frames (frame fed at step t), NULL when free running */
+    const uint8_t* teacher;/* HOST array [T]: 1 = feed frames_in[t], 0 = feed own prediction (modules/tacotron2.py:171,181) */
+    /* weights */
+    const float* prenet_w[4];
+    const float* prenet_b[4];
+    const float* att_w_ih; /* [4H, P+Dm] */
+    const float* att_w_hh; /* [4H, H] */
+    const float* att_b_ih;
+    const float* att_b_hh;
+    const float* gen_w_ih; /* [4H, H+Dm] */
+    const float* gen_w_hh;
+    const float* gen_b_ih;
+    const float* gen_b_hh;
+    const float* w_query;  /* [A,H] */
+    const float* w_memory; /* [A,Dm] */
+    const float* w_loc;    /* [A,C] */
+    const float* w_conv;   /* [C,ksz] */
+    const float* att_bias; /* [A] */
+    const float* w_energy; /* [A] */
+    const float* w_out;    /* [M+1, H+Dm] frame rows then the stop row */
+    const float* b_out;    /* [M+1] */
+    /* dropout / zoneout keep flags (NULL = none) */
+    const uint8_t* prenet_mask[4];  /* teacher path: [T,B,P] each; free-running steps index the same arrays by t */
+    const uint8_t* att_hmask;       /* [T,B,H] */
+    const uint8_t* att_cmask;
+    const uint8_t* gen_hmask;
+    const uint8_t* gen_cmask;
+    /* saved state / outputs (time-major) */
+    float* prenet_act[4];  /* [T,B,P] activations of every prenet layer (last = LSTM input) */
+    float* U;              /* [A,ksz] */
+    float* Mt;             /* [B,L,A] */
+    float* PL;             /* [2,B,L,A] ping-pong */
+    float* qpart;          /* [kq,B,A] */
+    int kq;
+    float* h_att;          /* [T+1,B,H], slot 0 = initial state */
+    float* c_att;
+    float* h_gen;
+    float* c_gen;
+    float* ctx;            /* [T+1,B,Dm] */
+    float* cum;            /* [T+1,B,L] */
+    float* align;          /* [T,B,L] */
+    float* gates_att;      /* [T,B,4H] or NULL */
+    float* gates_gen;
+    float* out;            /* [T+1,B,Mo] (Mo = M+1 rounded up to 4): slot t+1 = frame + stop logit of step t, slot 0 = zero frame */
+    float* pre_att;        /* [T,B,4H] hoisted input projection workspace (fast path) or NULL */
+    float* pre_gen;        /* [T,B,4H] */
+    int fast;              /* 1: all steps teacher forced -> hoisted projections + deferred generator chain */
+} DecoderArgs;
+
+int mtts_decoder_fwd(const DecoderArgs* args, void* stream);
+
+/* ---- bidirectional LSTM over padded batch with packed-sequence semantics ----------------------------------
+ * Replaces nn.LSTM(bidirectional) + pack/pad of modules/encoder.py:41-44. */
+typedef struct BiLstmArgs {
+    int B;
+    int L;
+    int Cin;
+    int H;                 /* per direction */
+    const float* x;        /* [B,L,Cin] */
+    const int* lengths;
+    const float* w_ih[2];  /* [4H,Cin] fwd, reverse */
+    const float* w_hh[2];  /* [4H,H] */
+    const float* b_ih[2];
+    const float* b_hh[2];
+    float* xproj[2];       /* [B,L,4H] workspace */
+    float* h[2];           /* [L+1,B,H] */
+    float* c[2];
+    float* gates[2];       /* [L,B,4H] or NULL */
+    float* y;              /* [B,L,2H] */
+} BiLstmArgs;
+
+int mtts_bilstm_fwd(const BiLstmArgs* args, void* stream);
+
+/* ---- small data-movement kernels --------------------------------------------------------------------------- */
+/* Embedding lookup (modules/tacotron2.py:363, :122 speaker/language tables): out[r, col0:col0+D] = table[ids[r]] */
+int mtts_embedding_fwd(const float* table, const int64_t* ids, float* out, int rows, int D, int ldo, int col0, void* stream);
+/* dtable[ids[r]] += dout[r, col0:col0+D]; rows with ids == padding_idx are skipped (padding_idx < 0: none) */
+int mtts_embedding_bwd(const float* dout, const int64_t* ids, float* dtable, int rows, int D, int ldo, int col0,
+                       int padding_idx, void* stream);
+/* out[r*ldo + c] = in[r*ldi + c] for c < cols (strided 2-D copy, used for concatenations) */
+int mtts_copy2d(const float* in, float* out, int rows, int cols, int ldi, int ldo, void* stream);
+/* [O, I, k] <-> [O, k, I] weight repack for the implicit-GEMM convolution (to_packed != 0: torch layout -> packed) */
+int mtts_conv_weight_pack(const float* in, float* out, int O, int I, int k, int to_packed, void* stream);
+
+/* Gradient reversal backward (modules/classifier.py:16-18): out = clamp(g, -c, c) * (-l) */
+int mtts_grad_reverse_clamp(const float* g, float* out, long n, float l, float c, void* stream);
+
+const char* mtts_last_error(void);
+int mtts_version(void);
+/* sizeof() of the structs above in declaration order (0 = GemmArgs ... 6 = BiLstmArgs); -1 when out of range */
+int mtts_sizeof_struct(int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,79 @@
+// Shared device/host helpers for libmtts_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/mtts.h"
+
+#define MTTS_API extern "C" __attribute__((visibility("default")))
+
+// Thread-local last-error text, readable through mtts_last_error().
+extern thread_local char g_mtts_err[512];
+int mtts_fail(const char* fmt, ...);
+
+#define MTTS_CHECK_HIP(expr)                                                         \
+    do {                                                                             \
+        hipError_t _e = (expr);                                                      \
+        if (_e != hipSuccess) return mtts_fail("%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+#define MTTS_CHECK_LAUNCH(name)                                                      \
+    do {                                                                             \
+        hipError_t _e = hipGetLastError();                                           \
+        if (_e != hipSuccess) return mtts_fail("launch %s: %s", name, hipGetErrorString(_e)); \
+    } while (0)
+
+#define MTTS_REQUIRE(cond, ...)                                                      \
+    do {                                                                             \
+        if (!(cond)) return mtts_fail(__VA_ARGS__);                                  \
+    } while (0)
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// tanh through exp: accurate to ~1e-7 abs, saturates cleanly.
+__device__ __forceinline__ float tanhf_(float x) {
+    float ax = fabsf(x);
+    float e = __expf(-2.0f * ax);
+    float r = (1.0f - e) / (1.0f + e);
+    return copysignf(r, x);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+
+__device__ __forceinline__ float apply_act(int act, float v) {
+    switch (act) {
+        case MTTS_ACT_RELU: return fmaxf(v, 0.0f);
+        case MTTS_ACT_TANH: return tanhf_(v);
+        case MTTS_ACT_SIGMOID: return sigmoidf_(v);
+        default: return v;
+    }
+}
+
+// ---- internal cross-file entry points (host) ----
+int gemm_plain(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, bool tA,
+               bool tB, float alpha, float beta, const float* bias, int act, hipStream_t s);
+int skinny_launch(const SkinnyArgs& p, hipStream_t s);
+int attn_step_launch(const AttnStepArgs& p, hipStream_t s);
+int attn_pl_init(const float* Mt, const float* bias, float* PL, long total, int A, hipStream_t s);
+int copy2d(const float* in, float* out, int rows, int cols, int ldi, int ldo, hipStream_t s);
+
+#define MTTS_TRY(expr)            \
+    do {                          \
+        int _rc = (expr);         \
+        if (_rc) return _rc;      \
+    } while (0)

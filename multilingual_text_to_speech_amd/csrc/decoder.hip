@@ -1,0 +1,197 @@
+// Host orchestration of the autoregressive decoder loop and the encoder BiLSTM (forward).
+// Reference: Decoder._decode modules/tacotron2.py:148-209; Encoder BiLSTM modules/encoder.py:41-44.
+//
+// Two schedules over the same kernels:
+//   general  - every step runs prenet(step) | att-LSTM | query | attention | gen-LSTM | frame/stop projection;
+//              needed whenever a step consumes the model's own previous frame (inference, teacher forcing < 1).
+//   fast     - all steps teacher forced: everything that does not sit on the recurrence is hoisted into large
+//              MFMA GEMMs (prenet over all frames, att-LSTM input projection, gen-LSTM input projection,
+//              frame/stop projection); the sequential part shrinks to
+//              chain A: att-LSTM([ctx,h]) -> query -> attention      (per step)
+//              chain B: gen-LSTM(h_gen) with precomputed input gates  (per step, after chain A).
+#include "common.h"
+
+static inline int round4(int x) { return (x + 3) & ~3; }
+
+static void lstm_reg(const DecoderArgs& a, SkinnyArgs& k, const uint8_t* hmask, const uint8_t* cmask, int t) {
+    const long off = (long)t * a.B * a.H;
+    if (a.zone) {
+        if (a.training) { k.zone = 1; k.hmask = hmask ? hmask + off : nullptr; k.cmask = cmask ? cmask + off : nullptr; }
+        else { k.zone = 2; k.zh = a.p_hidden; k.zc = a.p_cell; }
+    } else if (a.training && hmask && a.p_hidden > 0.f) {
+        k.zone = 0; k.hmask = hmask + off; k.hscale = 1.f / (1.f - a.p_hidden);
+    }
+}
+
+MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
+    const DecoderArgs& a = *args;
+    hipStream_t s = (hipStream_t)stream;
+    const int B = a.B, L = a.L, M = a.M, P = a.P, H = a.H, A = a.A, Dm = a.Dm;
+    const int Mo = round4(M + 1);
+    const long BH = (long)B * H, BD = (long)B * Dm, BL = (long)B * L, B4H = 4 * BH, BP = (long)B * P;
+    MTTS_REQUIRE((P & 3) == 0 && (H & 3) == 0 && (Dm & 3) == 0 && (M & 3) == 0,
+                 "decoder: P, H, Dm, num_mels must be multiples of 4 (P=%d H=%d Dm=%d M=%d)", P, H, Dm, M);
+    MTTS_REQUIRE(a.n_prenet >= 1 && a.n_prenet <= 4, "decoder: 1..4 prenet layers supported");
+    MTTS_REQUIRE(a.t0 >= 0 && a.t1 <= a.T && a.t0 <= a.t1, "decoder: bad step range");
+    const float pscale = a.p_prenet > 0.f ? 1.f / (1.f - a.p_prenet) : 1.f;
+    const int nsteps = a.t1 - a.t0;
+    if (nsteps == 0) return 0;
+
+    if (a.t0 == 0) {
+        // U = W_loc [A,C] * W_conv [C,ksz];  Mt = memory W_memory^T;  PL[0] = Mt + bias   (attention.py:23-28)
+        MTTS_TRY(gemm_plain(a.w_loc, a.w_conv, a.U, A, a.ksz, a.C, a.C, a.ksz, a.ksz, false, true, 1.f, 0.f, nullptr, 0, s));
+        MTTS_TRY(gemm_plain(a.memory, a.w_memory, a.Mt, B * L, A, Dm, Dm, Dm, A, false, false, 1.f, 0.f, nullptr, 0, s));
+        MTTS_TRY(attn_pl_init(a.Mt, a.att_bias, a.PL, BL * A, A, s));
+    }
+
+    // prenet over the teacher frames of this range (tacotron2.py:126-133)
+    if (a.frames_in) {
+        for (int i = 0; i < a.n_prenet; ++i) {
+            GemmArgs g; memset(&g, 0, sizeof(g));
+            const int Kin = i == 0 ? M : P;
+            g.A = (i == 0 ? a.frames_in + (long)a.t0 * B * M : a.prenet_act[i - 1] + a.t0 * BP);
+            g.B = a.prenet_w[i]; g.C = a.prenet_act[i] + a.t0 * BP; g.bias = a.prenet_b[i];
+            g.M = nsteps * B; g.N = P; g.K = Kin; g.lda = Kin; g.ldb = Kin; g.ldc = P;
+            g.taps = 1; g.Kc = Kin; g.batch = 1; g.zt = 1; g.alpha = 1.f; g.act = MTTS_ACT_RELU;
+            if (a.prenet_mask[i] && a.p_prenet > 0.f) { g.mask = a.prenet_mask[i] + a.t0 * BP; g.ldmask = P; g.mask_scale = pscale; }
+            MTTS_TRY(mtts_gemm_ex(&g, s));
+        }
+    }
+    float* pren = a.prenet_act[a.n_prenet - 1];
+
+    if (a.fast) {
+        MTTS_REQUIRE(a.pre_att && a.pre_gen && a.frames_in, "decoder fast path needs pre_att/pre_gen workspaces and frames_in");
+        MTTS_TRY(gemm_plain(pren + a.t0 * BP, a.att_w_ih, a.pre_att + a.t0 * B4H, nsteps * B, 4 * H, P, P, P + Dm, 4 * H, false,
+                            false, 1.f, 0.f, nullptr, 0, s));
+    }
+
+    for (int t = a.t0; t < a.t1; ++t) {
+        const bool teach = a.frames_in && a.teacher && a.teacher[t];
+        if (!teach) {
+            // prenet on the model's own previous frame (tacotron2.py:181), out slot t holds frame t-1 (slot 0 = zeros)
+            for (int i = 0; i < a.n_prenet; ++i) {
+                SkinnyArgs k; memset(&k, 0, sizeof(k));
+                k.nseg = 1; k.B = B; k.N = P; k.ksplit = 1;
+                if (i == 0) k.seg[0] = SkSeg{a.out + (long)t * B * Mo, a.prenet_w[0], M, Mo, M};
+                else k.seg[0] = SkSeg{a.prenet_act[i - 1] + t * BP, a.prenet_w[i], P, P, P};
+                k.out = a.prenet_act[i] + t * BP; k.ldo = P; k.bias = a.prenet_b[i]; k.act = MTTS_ACT_RELU;
+                if (a.prenet_mask[i] && a.p_prenet > 0.f) { k.mask = a.prenet_mask[i] + t * BP; k.ldmask = P; k.mask_scale = pscale; }
+                MTTS_TRY(skinny_launch(k, s));
+            }
+        }
+        {   // attention LSTM (tacotron2.py:184-185)
+            SkinnyArgs k; memset(&k, 0, sizeof(k));
+            k.B = B; k.N = 4 * H; k.ksplit = 1; k.lstm = 1; k.H = H;
+            if (a.fast) {
+                k.nseg = 2;
+                k.seg[0] = SkSeg{a.ctx + t * BD, a.att_w_ih + P, Dm, Dm, P + Dm};
+                k.seg[1] = SkSeg{a.h_att + t * BH, a.att_w_hh, H, H, H};
+                k.pre = a.pre_att + t * B4H; k.ldpre = 4 * H;
+            } else {
+                k.nseg = 3;
+                k.seg[0] = SkSeg{pren + t * BP, a.att_w_ih, P, P, P + Dm};
+                k.seg[1] = SkSeg{a.ctx + t * BD, a.att_w_ih + P, Dm, Dm, P + Dm};
+                k.seg[2] = SkSeg{a.h_att + t * BH, a.att_w_hh, H, H, H};
+            }
+            k.b_ih = a.att_b_ih; k.b_hh = a.att_b_hh;
+            k.h_prev = a.h_att + t * BH; k.c_prev = a.c_att + t * BH;
+            k.h_out = a.h_att + (t + 1) * BH; k.c_out = a.c_att + (t + 1) * BH;
+            k.gates_out = a.gates_att ? a.gates_att + t * B4H : nullptr;
+            lstm_reg(a, k, a.att_hmask, a.att_cmask, t);
+            MTTS_TRY(skinny_launch(k, s));
+        }
+        {   // query projection partials (attention.py:68)
+            SkinnyArgs k; memset(&k, 0, sizeof(k));
+            k.nseg = 1; k.B = B; k.N = A; k.ksplit = a.kq;
+            k.seg[0] = SkSeg{a.h_att + (t + 1) * BH, a.w_query, H, H, H};
+            k.out = a.qpart; k.ldo = A; k.out_ks = (long)B * A;
+            MTTS_TRY(skinny_launch(k, s));
+        }
+        {   // energies -> softmax -> context, PL for the next step (attention.py:39-45,67-86)
+            AttnStepArgs q; memset(&q, 0, sizeof(q));
+            q.qpart = a.qpart; q.kq = a.kq; q.q_ks = (long)B * A;
+            q.PL = a.PL + (long)(t & 1) * BL * A; q.PL_next = a.PL + (long)((t + 1) & 1) * BL * A;
+            q.Mt = a.Mt; q.U = a.U; q.bias = a.att_bias; q.v = a.w_energy; q.memory = a.memory; q.lengths = a.lengths;
+            q.cum_in = a.cum + t * BL; q.cum_out = a.cum + (t + 1) * BL; q.w_out = a.align + t * BL;
+            q.ctx_out = a.ctx + (t + 1) * BD;
+            q.B = B; q.L = L; q.A = A; q.Dm = Dm; q.ksz = a.ksz;
+            q.nch = (Dm + 511) / 512; if (q.nch < 4 && B * 4 <= 1024) q.nch = 4;
+            MTTS_TRY(attn_step_launch(q, s));
+        }
+        if (!a.fast) {
+            {   // generator LSTM (tacotron2.py:187-188)
+                SkinnyArgs k; memset(&k, 0, sizeof(k));
+                k.B = B; k.N = 4 * H; k.ksplit = 1; k.lstm = 1; k.H = H; k.nseg = 3;
+                k.seg[0] = SkSeg{a.h_att + (t + 1) * BH, a.gen_w_ih, H, H, H + Dm};
+                k.seg[1] = SkSeg{a.ctx + (t + 1) * BD, a.gen_w_ih + H, Dm, Dm, H + Dm};
+                k.seg[2] = SkSeg{a.h_gen + t * BH, a.gen_w_hh, H, H, H};
+                k.b_ih = a.gen_b_ih; k.b_hh = a.gen_b_hh;
+                k.h_prev = a.h_gen + t * BH; k.c_prev = a.c_gen + t * BH;
+                k.h_out = a.h_gen + (t + 1) * BH; k.c_out = a.c_gen + (t + 1) * BH;
+                k.gates_out = a.gates_gen ? a.gates_gen + t * B4H : nullptr;
+                lstm_reg(a, k, a.gen_hmask, a.gen_cmask, t);
+                MTTS_TRY(skinny_launch(k, s));
+            }
+            {   // frame + stop projection (tacotron2.py:191-193)
+                SkinnyArgs k; memset(&k, 0, sizeof(k));
+                k.nseg = 2; k.B = B; k.N = M + 1; k.ksplit = 1;
+                k.seg[0] = SkSeg{a.h_gen + (t + 1) * BH, a.w_out, H, H, H + Dm};
+                k.seg[1] = SkSeg{a.ctx + (t + 1) * BD, a.w_out + H, Dm, Dm, H + Dm};
+                k.out = a.out + (long)(t + 1) * B * Mo; k.ldo = Mo; k.bias = a.b_out;
+                MTTS_TRY(skinny_launch(k, s));
+            }
+        }
+    }
+
+    if (a.fast) {
+        // generator-LSTM input gates for all steps of the range: [h_att, ctx] W_ih^T
+        MTTS_TRY(gemm_plain(a.h_att + (a.t0 + 1) * BH, a.gen_w_ih, a.pre_gen + a.t0 * B4H, nsteps * B, 4 * H, H, H, H + Dm, 4 * H,
+                            false, false, 1.f, 0.f, nullptr, 0, s));
+        MTTS_TRY(gemm_plain(a.ctx + (a.t0 + 1) * BD, a.gen_w_ih + H, a.pre_gen + a.t0 * B4H, nsteps * B, 4 * H, Dm, Dm, H + Dm, 4 * H,
+                            false, false, 1.f, 1.f, nullptr, 0, s));
+        for (int t = a.t0; t < a.t1; ++t) {
+            SkinnyArgs k; memset(&k, 0, sizeof(k));
+            k.B = B; k.N = 4 * H; k.ksplit = 1; k.lstm = 1; k.H = H; k.nseg = 1;
+            k.seg[0] = SkSeg{a.h_gen + t * BH, a.gen_w_hh, H, H, H};
+            k.pre = a.pre_gen + t * B4H; k.ldpre = 4 * H;
+            k.b_ih = a.gen_b_ih; k.b_hh = a.gen_b_hh;
+            k.h_prev = a.h_gen + t * BH; k.c_prev = a.c_gen + t * BH;
+            k.h_out = a.h_gen + (t + 1) * BH; k.c_out = a.c_gen + (t + 1) * BH;
+            k.gates_out = a.gates_gen ? a.gates_gen + t * B4H : nullptr;
+            lstm_reg(a, k, a.gen_hmask, a.gen_cmask, t);
+            MTTS_TRY(skinny_launch(k, s));
+        }
+        float* o = a.out + (long)(a.t0 + 1) * B * Mo;
+        MTTS_TRY(gemm_plain(a.h_gen + (a.t0 + 1) * BH, a.w_out, o, nsteps * B, M + 1, H, H, H + Dm, Mo, false, false, 1.f, 0.f,
+                            a.b_out, 0, s));
+        MTTS_TRY(gemm_plain(a.ctx + (a.t0 + 1) * BD, a.w_out + H, o, nsteps * B, M + 1, Dm, Dm, H + Dm, Mo, false, false, 1.f, 1.f,
+                            nullptr, 0, s));
+    }
+    return 0;
+}
+
+MTTS_API int mtts_bilstm_fwd(const BiLstmArgs* args, void* stream) {
+    const BiLstmArgs& a = *args;
+    hipStream_t s = (hipStream_t)stream;
+    const int B = a.B, L = a.L, H = a.H;
+    MTTS_REQUIRE((H & 3) == 0 && (a.Cin & 3) == 0, "bilstm: H and Cin must be multiples of 4");
+    const long BH = (long)B * H;
+    for (int d = 0; d < 2; ++d) {
+        MTTS_TRY(gemm_plain(a.x, a.w_ih[d], a.xproj[d], B * L, 4 * H, a.Cin, a.Cin, a.Cin, 4 * H, false, false, 1.f, 0.f, nullptr, 0, s));
+        for (int st = 0; st < L; ++st) {
+            const int t = d == 0 ? st : L - 1 - st;
+            SkinnyArgs k; memset(&k, 0, sizeof(k));
+            k.B = B; k.N = 4 * H; k.ksplit = 1; k.lstm = 1; k.H = H; k.nseg = 1;
+            k.seg[0] = SkSeg{a.h[d] + st * BH, a.w_hh[d], H, H, H};
+            k.pre = a.xproj[d] + (long)t * 4 * H; k.ldpre = L * 4 * H;
+            k.b_ih = a.b_ih[d]; k.b_hh = a.b_hh[d];
+            k.h_prev = a.h[d] + st * BH; k.c_prev = a.c[d] + st * BH;
+            k.h_out = a.h[d] + (st + 1) * BH; k.c_out = a.c[d] + (st + 1) * BH;
+            k.gates_out = a.gates[d] ? a.gates[d] + (long)st * 4 * BH : nullptr;
+            k.lengths = a.lengths; k.t = t;
+            k.y_out = a.y + (long)t * 2 * H + d * H; k.ldy = L * 2 * H;
+            MTTS_TRY(skinny_launch(k, s));
+        }
+    }
+    return 0;
+}

@@ -1,0 +1,283 @@
+// fp32 MFMA GEMM for gfx950 (v_mfma_f32_32x32x2_f32: exact f32, 157 TF peak).
+//
+//   C[M,N] = epilogue( alpha * sum_k A(m,k) * B(n,k) )
+//
+// One kernel serves every *batched* dense contraction of the text->mel path:
+//   * Linear layers            y = x W^T          (A,B both K-contiguous)
+//   * input-gradient GEMMs     dx = dy W          (B "transposed": n contiguous)
+//   * weight-gradient GEMMs    dW = dy^T x        (A and B "transposed": reduction over rows)
+//   * 1-D convolution as an implicit GEMM over channel-last activations [rows=(n,l), C]:
+//     K is decomposed as (tap t, channel c); tap t reads activation row r + shift_t and is
+//     zero outside the sequence ('same' padding, dilation) -- no im2col buffer is materialised.
+//   * grouped convolutions / per-tap weight gradients through the grid.z batch strides.
+//
+// Tile: 128x128x32 per 256-thread workgroup (4 waves as 2x2, each wave 64x64 = 2x2 MFMA 32x32 tiles),
+// register-staged global->LDS double buffering.  LDS image per operand is either
+//   KC  [rows][32+4]   (k contiguous; ds_read_b128 feeds 4 MFMA k-steps via the k-slot trick), or
+//   MC  [32][128+4]    (row contiguous, for transposed sources; ds_read_b32 per k-step).
+// The k-slot trick: instruction s of group g uses slot q (=lane>>5) as k = 8g + 4q + s for BOTH
+// operands, so a lane's float4 along k supplies four consecutive instructions.
+#include "common.h"
+
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int KC_LD = BK + 4;     // 36 floats: conflict-free ds_read_b128 (36*i mod 64 distinct over 16 rows)
+constexpr int MC_LD = BM + 4;
+
+template <bool T>
+struct Tile {                      // registers holding one thread's share of a 128x32 tile (4 float4)
+    float4 v[4];
+};
+
+// Load one float4 of operand X (rows = BM-tile rows, kk along K).  Generic + slow-path safe.
+template <bool TRANS, bool IS_A>
+__device__ __forceinline__ void load_tile(const GemmArgs& p, const float* __restrict__ base, int row0, int k0,
+                                          int rows_total, int ld, bool vec_ok, int shift_z, Tile<TRANS>& t) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!TRANS) {
+            // 8 threads cover one row's 32 k (128 B), 32 rows per pass
+            const int r = row0 + it * 32 + (tid >> 3);
+            const int kk = k0 + (tid & 7) * 4;
+            if (r < rows_total && kk < p.K) {
+                long off; bool valid = true; int kk_in = kk;
+                if (IS_A && p.shift_mode == 1) {
+                    const int tap = kk / p.Kc; kk_in = kk - tap * p.Kc;
+                    const int sh = p.shift0 + tap * p.dshift;
+                    const int l = r % p.seq_len;
+                    valid = (l + sh >= 0) && (l + sh < p.seq_len);
+                    off = (long)(r + sh) * ld + kk_in;
+                } else {
+                    off = (long)r * ld + kk;
+                }
+                if (valid) {
+                    if (vec_ok && kk + 3 < p.K) {
+                        out = *reinterpret_cast<const float4*>(base + off);
+                    } else {
+                        float tmp[4] = {0.f, 0.f, 0.f, 0.f};
+                        for (int j = 0; j < 4; ++j) {
+                            if (kk + j < p.K) {
+                                if (IS_A && p.shift_mode == 1) {
+                                    const int kj = kk + j; const int tap = kj / p.Kc; const int c = kj - tap * p.Kc;
+                                    const int sh = p.shift0 + tap * p.dshift; const int l = r % p.seq_len;
+                                    if (l + sh >= 0 && l + sh < p.seq_len) tmp[j] = base[(long)(r + sh) * ld + c];
+                                } else tmp[j] = base[(long)r * ld + kk + j];
+                            }
+                        }
+                        out = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
+                    }
+                }
+            }
+        } else {
+            // transposed source: element (row, kk) at base[kk*ld + row] (+ tap offset); float4 along rows
+            const int kk = k0 + it * 8 + (tid >> 5);
+            const int r = row0 + (tid & 31) * 4;
+            if (kk < p.K && r < rows_total) {
+                long koff; bool valid = true;
+                if (!IS_A && p.shift_mode == 2) {          // wgrad: k index is an activation row, shifted
+                    const int l = kk % p.seq_len;
+                    valid = (l + shift_z >= 0) && (l + shift_z < p.seq_len);
+                    koff = (long)(kk + shift_z) * ld;
+                } else if (!IS_A && p.taps > 1 && p.shift_mode == 1) {   // conv bwd-data weights: kk = (tap, c)
+                    const int tap = kk / p.Kc; const int c = kk - tap * p.Kc;
+                    koff = (long)c * ld + (long)tap * p.b_tap;
+                } else {
+                    koff = (long)kk * ld;
+                }
+                if (valid) {
+                    if (vec_ok && r + 3 < rows_total) {
+                        out = *reinterpret_cast<const float4*>(base + koff + r);
+                    } else {
+                        float tmp[4] = {0.f, 0.f, 0.f, 0.f};
+                        for (int j = 0; j < 4; ++j) if (r + j < rows_total) tmp[j] = base[koff + r + j];
+                        out = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
+                    }
+                }
+            }
+        }
+        t.v[it] = out;
+    }
+}
+
+template <bool TRANS>
+__device__ __forceinline__ void store_tile(float* __restrict__ lds, const Tile<TRANS>& t) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        if (!TRANS) {
+            const int r = it * 32 + (tid >> 3);
+            const int k = (tid & 7) * 4;
+            *reinterpret_cast<float4*>(lds + r * KC_LD + k) = t.v[it];
+        } else {
+            const int k = it * 8 + (tid >> 5);
+            const int r = (tid & 31) * 4;
+            *reinterpret_cast<float4*>(lds + k * MC_LD + r) = t.v[it];
+        }
+    }
+}
+
+constexpr int LDS_A = (BM * KC_LD > BK * MC_LD) ? BM * KC_LD : BK * MC_LD;   // floats per operand buffer
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // buffer b: A at smem + 2*b*LDS_A, B right behind it
+
+    // XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8); remap so that each XCD
+    // walks a contiguous run of tiles (neighbouring tiles share A/B panels in that XCD's L2).
+    const int ntx = (p.N + BN - 1) / BN, nty = (p.M + BM - 1) / BM;
+    const int nt = ntx * nty;
+    int id = blockIdx.x;
+    {
+        const int q = nt / 8, r = nt % 8, xcd = id % 8, idx = id / 8;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = id / ntx, tile_n = id % ntx;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int z = blockIdx.z;
+    const int zb = z / p.zt, ztap = z % p.zt;
+    const float* A = p.A + (long)zb * p.a_z;
+    const float* B = p.B + (long)zb * p.b_z;
+    float* C = p.C + (long)zb * p.c_z + (long)ztap * p.c_ztap;
+    const float* bias = p.bias ? p.bias + (long)zb * p.bias_z : nullptr;
+    const int shift_z = p.shift0 + ztap * p.dshift;
+
+    const bool vecA = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((p.Kc & 3) == 0) &&
+                      ((p.a_z & 3) == 0);
+    const bool vecB = ((p.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && ((p.Kc & 3) == 0) &&
+                      ((p.b_z & 3) == 0) && ((p.b_tap & 3) == 0);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int li = lane & 31, lq = lane >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    Tile<TA> ta; Tile<TB> tb;
+    const int nk = (p.K + BK - 1) / BK;
+    load_tile<TA, true>(p, A, m0, 0, p.M, p.lda, vecA, shift_z, ta);
+    load_tile<TB, false>(p, B, n0, 0, p.N, p.ldb, vecB, shift_z, tb);
+    store_tile<TA>(smem, ta);
+    store_tile<TB>(smem + LDS_A, tb);
+    __syncthreads();
+
+    for (int kb = 0; kb < nk; ++kb) {
+        const int cur = kb & 1;
+        if (kb + 1 < nk) {
+            load_tile<TA, true>(p, A, m0, (kb + 1) * BK, p.M, p.lda, vecA, shift_z, ta);
+            load_tile<TB, false>(p, B, n0, (kb + 1) * BK, p.N, p.ldb, vecB, shift_z, tb);
+        }
+        const float* as = smem + cur * 2 * LDS_A;
+        const float* bs = as + LDS_A;
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+            float4 a[2], b[2];
+            float as_[2][4], bs_[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (!TA) {
+                    a[i] = *reinterpret_cast<const float4*>(as + (wm + i * 32 + li) * KC_LD + g * 8 + lq * 4);
+                    as_[i][0] = a[i].x; as_[i][1] = a[i].y; as_[i][2] = a[i].z; as_[i][3] = a[i].w;
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) as_[i][s] = as[(g * 8 + lq * 4 + s) * MC_LD + wm + i * 32 + li];
+                }
+                if (!TB) {
+                    b[i] = *reinterpret_cast<const float4*>(bs + (wn + i * 32 + li) * KC_LD + g * 8 + lq * 4);
+                    bs_[i][0] = b[i].x; bs_[i][1] = b[i].y; bs_[i][2] = b[i].z; bs_[i][3] = b[i].w;
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) bs_[i][s] = bs[(g * 8 + lq * 4 + s) * MC_LD + wn + i * 32 + li];
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(as_[i][s], bs_[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (kb + 1 < nk) {
+            store_tile<TA>(smem + (cur ^ 1) * 2 * LDS_A, ta);
+            store_tile<TB>(smem + (cur ^ 1) * 2 * LDS_A + LDS_A, tb);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn + j * 32 + li;
+            if (col >= p.N) continue;
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lq;
+                if (row >= p.M) continue;
+                float v = p.alpha * acc[i][j][r] + bv;
+                float* cp = C + (long)row * p.ldc + col;
+                if (p.beta != 0.f) v += p.beta * (*cp);
+                v = apply_act(p.act, v);
+                if (p.mask) v = p.mask[(long)row * p.ldmask + col] ? v * p.mask_scale : 0.f;
+                *cp = v;
+            }
+        }
+}
+
+MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
+    GemmArgs p = *args;
+    if (p.M <= 0 || p.N <= 0) return 0;
+    MTTS_REQUIRE(p.K >= 0 && p.taps >= 1 && p.taps * p.Kc == p.K, "mtts_gemm_ex: K=%d must equal taps*Kc=%d*%d", p.K,
+                 p.taps, p.Kc);
+    if (p.batch < 1) p.batch = 1;
+    if (p.zt < 1) p.zt = 1;
+    MTTS_REQUIRE(p.shift_mode == 0 || p.seq_len > 0, "mtts_gemm_ex: shift_mode needs seq_len");
+    const int ntx = cdiv(p.N, BN), nty = cdiv(p.M, BM);
+    dim3 grid(ntx * nty, 1, p.batch * p.zt);
+    const size_t lds = 4 * LDS_A * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr_done = false;
+    if (!attr_done) {   // > 64 KiB of dynamic LDS needs the opt-in attribute
+        hipFuncSetAttribute((const void*)gemm_mfma_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)gemm_mfma_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)gemm_mfma_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)gemm_mfma_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    if (!p.transA && !p.transB) hipLaunchKernelGGL((gemm_mfma_kernel<false, false>), grid, dim3(256), lds, s, p);
+    else if (!p.transA && p.transB) hipLaunchKernelGGL((gemm_mfma_kernel<false, true>), grid, dim3(256), lds, s, p);
+    else if (p.transA && !p.transB) hipLaunchKernelGGL((gemm_mfma_kernel<true, false>), grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((gemm_mfma_kernel<true, true>), grid, dim3(256), lds, s, p);
+    MTTS_CHECK_LAUNCH("gemm_mfma_kernel");
+    return 0;
+}
+
+// Plain GEMM convenience wrapper used by host code in this library.
+int gemm_plain(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, bool tA,
+               bool tB, float alpha, float beta, const float* bias, int act, hipStream_t s) {
+    GemmArgs p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.B = B; p.C = C; p.bias = bias;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.transA = tA; p.transB = tB; p.taps = 1; p.Kc = K; p.batch = 1; p.zt = 1;
+    p.alpha = alpha; p.beta = beta; p.act = act; p.mask_scale = 1.f;
+    return mtts_gemm_ex(&p, s);
+}
+
+MTTS_API int mtts_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                       int transA, int transB, float alpha, float beta, const float* bias, int act, void* stream) {
+    return gemm_plain(A, B, C, M, N, K, lda, ldb, ldc, transA != 0, transB != 0, alpha, beta, bias, act,
+                      (hipStream_t)stream);
+}

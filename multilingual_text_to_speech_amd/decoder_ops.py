@@ -1,0 +1,184 @@
+"""Decoder loop (attention + 2 LSTM cells + projections) through mtts_decoder_fwd / mtts_decoder_bwd.
+
+reference: Decoder._decode, modules/tacotron2.py:148-209.
+"""
+import ctypes
+
+import torch
+
+from . import _C
+from ._C import check, lib, ptr, require_gpu, stream_ptr
+
+
+def _round4(x):
+    return (x + 3) & ~3
+
+
+class DecoderState:
+    """Device buffers of one decode (time-major, see DecoderArgs in include/mtts.h)."""
+
+    def __init__(self, B, L, T, dims, device, n_prenet, save_gates=True, fast=False, kq=8):
+        M, P, H, A, Dm, ksz, C = dims
+        self.B, self.L, self.T, self.dims, self.n_prenet, self.kq, self.fast = B, L, T, dims, n_prenet, kq, fast
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
+        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)
+        self.Mo = _round4(M + 1)
+        self.prenet_act = [e(T, B, P) for _ in range(n_prenet)]
+        self.U, self.Mt, self.PL = e(A, ksz), e(B, L, A), e(2, B, L, A)
+        self.qpart = e(kq, B, A)
+        self.h_att, self.c_att = z(T + 1, B, H), z(T + 1, B, H)
+        self.h_gen, self.c_gen = z(T + 1, B, H), z(T + 1, B, H)
+        self.ctx, self.cum = z(T + 1, B, Dm), z(T + 1, B, L)
+        self.align = e(T, B, L)
+        self.gates_att = e(T, B, 4 * H) if save_gates else None
+        self.gates_gen = e(T, B, 4 * H) if save_gates else None
+        self.out = z(T + 1, B, self.Mo)
+        self.pre_att = e(T, B, 4 * H) if fast else None
+        self.pre_gen = e(T, B, 4 * H) if fast else None
+
+
+def fill_decoder_args(a, st, w, memory, lengths32, frames_in, teacher_host, masks, cfg):
+    """Populate a DecoderArgs struct.  `w` maps weight names to contiguous tensors, `masks` to uint8 tensors."""
+    M, P, H, A, Dm, ksz, C = st.dims
+    a.B, a.L, a.T, a.M, a.P, a.H, a.A, a.Dm, a.ksz, a.C = st.B, st.L, st.T, M, P, H, A, Dm, ksz, C
+    a.n_prenet = st.n_prenet
+    a.training, a.zone = int(cfg['training']), int(cfg['zone'])
+    a.p_prenet, a.p_hidden, a.p_cell = cfg['p_prenet'], cfg['p_hidden'], cfg['p_cell']
+    a.memory, a.lengths, a.frames_in = ptr(memory), ptr(lengths32), ptr(frames_in)
+    a.teacher = ctypes.cast(teacher_host, ctypes.c_void_p) if teacher_host is not None else None
+    for i in range(st.n_prenet):
+        a.prenet_w[i], a.prenet_b[i] = w['prenet_w'][i].data_ptr(), w['prenet_b'][i].data_ptr()
+        pm = masks.get(f'prenet.{i}')
+        a.prenet_mask[i] = pm.data_ptr() if pm is not None else None
+        a.prenet_act[i] = st.prenet_act[i].data_ptr()
+    for name in ('att_w_ih', 'att_w_hh', 'att_b_ih', 'att_b_hh', 'gen_w_ih', 'gen_w_hh', 'gen_b_ih', 'gen_b_hh', 'w_query',
+                 'w_memory', 'w_loc', 'w_conv', 'att_bias', 'w_energy', 'w_out', 'b_out'):
+        setattr(a, name, ptr(w[name]))
+    a.att_hmask, a.att_cmask = ptr(masks.get('att_h')), ptr(masks.get('att_c'))
+    a.gen_hmask, a.gen_cmask = ptr(masks.get('gen_h')), ptr(masks.get('gen_c'))
+    for name in ('U', 'Mt', 'PL', 'qpart', 'h_att', 'c_att', 'h_gen', 'c_gen', 'ctx', 'cum', 'align', 'gates_att', 'gates_gen',
+                 'out', 'pre_att', 'pre_gen'):
+        setattr(a, name, ptr(getattr(st, name)))
+    a.kq, a.fast = st.kq, int(st.fast)
+    return a
+
+
+def decoder_weights(dec, attention, prenet):
+    """Collect contiguous weight tensors from the module tree (names follow DecoderArgs)."""
+    w = {
+        'prenet_w': [l.weight.contiguous() for l in prenet._layers],
+        'prenet_b': [l.bias.contiguous() for l in prenet._layers],
+        'att_w_ih': dec._attention_lstm.weight_ih, 'att_w_hh': dec._attention_lstm.weight_hh,
+        'att_b_ih': dec._attention_lstm.bias_ih, 'att_b_hh': dec._attention_lstm.bias_hh,
+        'gen_w_ih': dec._generator_lstm.weight_ih, 'gen_w_hh': dec._generator_lstm.weight_hh,
+        'gen_b_ih': dec._generator_lstm.bias_ih, 'gen_b_hh': dec._generator_lstm.bias_hh,
+        'w_query': attention._query.weight, 'w_memory': attention._memory.weight,
+        'w_loc': attention._location.weight, 'w_conv': attention._loc_features.weight.view(attention._loc_features.weight.shape[0], -1),
+        'att_bias': attention._bias.view(-1), 'w_energy': attention._energy.weight.view(-1),
+        'w_out': torch.cat((dec._frame_prediction.weight, dec._stop_prediction.weight), 0),
+        'b_out': torch.cat((dec._frame_prediction.bias, dec._stop_prediction.bias), 0),
+    }
+    return {k: (v if isinstance(v, list) else v.contiguous()) for k, v in w.items()}
+
+
+WEIGHT_ORDER = ['att_w_ih', 'att_w_hh', 'att_b_ih', 'att_b_hh', 'gen_w_ih', 'gen_w_hh', 'gen_b_ih', 'gen_b_hh', 'w_query',
+                'w_memory', 'w_loc', 'w_conv', 'att_bias', 'w_energy', 'w_out', 'b_out']
+
+
+def run_decoder(st, w, memory, lengths32, frames_in, teacher, masks, cfg, t0, t1):
+    a = _C.DecoderArgs()
+    th = None
+    if teacher is not None:
+        th = (ctypes.c_uint8 * st.T)(*[int(bool(x)) for x in teacher])
+    fill_decoder_args(a, st, w, memory, lengths32, frames_in, th, masks, cfg)
+    a.t0, a.t1 = t0, t1
+    check(lib().mtts_decoder_fwd(ctypes.byref(a), stream_ptr()), 'mtts_decoder_fwd')
+    return a
+
+
+class DecoderFn(torch.autograd.Function):
+    """Teacher-forced (or mixed) training decode.  Inputs: memory [B,L,Dm], target frames [B,T,M] channel-last,
+    then the flat weight list (prenet w/b pairs, WEIGHT_ORDER)."""
+
+    @staticmethod
+    def forward(ctx, memory, target, lengths, teacher, masks, cfg, n_prenet, *flat):
+        require_gpu(memory, target)
+        memory = memory.contiguous()
+        B, L, Dm = memory.shape
+        T, M = target.shape[1], target.shape[2]
+        w = {'prenet_w': list(flat[0:2 * n_prenet:2]), 'prenet_b': list(flat[1:2 * n_prenet:2])}
+        for i, name in enumerate(WEIGHT_ORDER):
+            w[name] = flat[2 * n_prenet + i]
+        w = {k: ([t.contiguous() for t in v] if isinstance(v, list) else v.contiguous()) for k, v in w.items()}
+        P, H = w['prenet_w'][0].shape[0], w['att_w_hh'].shape[1]
+        A, C, ksz = w['w_query'].shape[0], w['w_conv'].shape[0], w['w_conv'].shape[1]
+        dev = memory.device
+        teacher = [bool(x) for x in teacher]
+        fast = all(teacher) and cfg.get('allow_fast', True)
+        st = DecoderState(B, L, T, (M, P, H, A, Dm, ksz, C), dev, n_prenet, save_gates=True, fast=fast, kq=cfg.get('kq', 8))
+        # frame fed at step t: zero frame at t=0, target[t-1] afterwards (tacotron2.py:129-131), time-major
+        frames_in = torch.zeros(T, B, M, dtype=torch.float32, device=dev)
+        frames_in[1:] = target[:, :T - 1].transpose(0, 1)
+        lengths32 = lengths.to(device=dev, dtype=torch.int32).contiguous()
+        run_decoder(st, w, memory, lengths32, frames_in, teacher, masks, cfg, 0, T)
+        ctx.st, ctx.w, ctx.masks, ctx.cfg, ctx.teacher, ctx.n_prenet = st, w, masks, cfg, teacher, n_prenet
+        ctx.memory, ctx.lengths32, ctx.frames_in = memory, lengths32, frames_in
+        spec = st.out[1:, :, :M].transpose(0, 1).contiguous()          # [B,T,M]
+        stop = st.out[1:, :, M].transpose(0, 1).contiguous()           # [B,T]
+        align = st.align.transpose(0, 1).contiguous()                  # [B,T,L]
+        return spec, stop, align
+
+    @staticmethod
+    def backward(ctx, dspec, dstop, dalign):
+        from .backward import decoder_bwd
+        return decoder_bwd(ctx, dspec, dstop, dalign)
+
+
+def decode_train(memory, target, lengths, teacher, masks, cfg, w):
+    n = len(w['prenet_w'])
+    flat = []
+    for i in range(n):
+        flat += [w['prenet_w'][i], w['prenet_b'][i]]
+    flat += [w[k] for k in WEIGHT_ORDER]
+    return DecoderFn.apply(memory, target, lengths, teacher, masks, cfg, n, *flat)
+
+
+def decode_free(memory, lengths, w, cfg, masks, max_frames, stop_frames, chunk=32, stop_threshold=0.5, dims=None):
+    """Free-running decode with the reference's stop rule (tacotron2.py:201-207), batch >= 1.
+
+    Steps run in chunks of `chunk` on the device; after each chunk the stop logits come back to the host and
+    the rule is evaluated per sample.  Returns (frames [B,T',M], stop [B,T'], align [B,T',L], n_frames [B])."""
+    require_gpu(memory)
+    memory = memory.contiguous()
+    B, L, Dm = memory.shape
+    M = w['w_out'].shape[0] - 1
+    P, H = w['prenet_w'][0].shape[0], w['att_w_hh'].shape[1]
+    A, C, ksz = w['w_query'].shape[0], w['w_conv'].shape[0], w['w_conv'].shape[1]
+    dev = memory.device
+    st = DecoderState(B, L, max_frames, (M, P, H, A, Dm, ksz, C), dev, len(w['prenet_w']), save_gates=False, fast=False,
+                      kq=cfg.get('kq', 8))
+    lengths32 = lengths.to(device=dev, dtype=torch.int32).contiguous()
+    armed = [-1] * B
+    done = [None] * B
+    t = 0
+    while t < max_frames and any(d is None for d in done):
+        t1 = min(max_frames, t + chunk)
+        run_decoder(st, w, memory, lengths32, None, None, masks, cfg, t, t1)
+        stops = torch.sigmoid(st.out[t + 1:t1 + 1, :, M]).cpu()
+        for i in range(t, t1):
+            for b in range(B):
+                if done[b] is not None or not bool(stops[i - t, b] >= stop_threshold):
+                    continue
+                if armed[b] == -1:
+                    armed[b] = stop_frames
+                    continue
+                armed[b] -= 1
+                if armed[b] == 0:
+                    done[b] = i + 1
+        t = t1
+    n = [d if d is not None else max_frames for d in done]
+    Tn = max(n)
+    frames = st.out[1:Tn + 1, :, :M].transpose(0, 1).contiguous()
+    stop = st.out[1:Tn + 1, :, M].transpose(0, 1).contiguous()
+    align = st.align[:Tn].transpose(0, 1).contiguous()
+    return frames, stop, align, n

@@ -1,0 +1,298 @@
+"""Thin Python wrappers over the C-ABI: argument packing + torch.autograd glue.
+
+Every compute step goes through libmtts_hip.so; torch is used for device memory, streams and
+autograd bookkeeping only.  Activations are channel-last ([N, L, C]).
+"""
+import ctypes
+
+import torch
+
+from . import _C
+from ._C import check, lib, ptr, require_gpu, stream_ptr
+
+ACT = {'identity': 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3}
+
+
+def _f32(*shape, device):
+    return torch.empty(*shape, dtype=torch.float32, device=device)
+
+
+def keep_mask(shape, p, device, generator=None):
+    """uint8 keep flags for dropout probability p (1 = keep)."""
+    return (torch.rand(shape, device=device, generator=generator) >= p).to(torch.uint8)
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM
+# ------------------------------------------------------------------------------------------------
+
+def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, alpha=1.0, beta=0.0, bias=None, act=0,
+         mask=None, mask_scale=1.0, **kw):
+    """C = epilogue(alpha * A(m,k) B(n,k) + beta C).  Extra GemmArgs fields via **kw (conv / batch modes)."""
+    g = _C.GemmArgs()
+    g.A, g.B, g.C, g.bias, g.mask = ptr(A), ptr(B), ptr(C), ptr(bias), ptr(mask)
+    g.M, g.N, g.K, g.lda, g.ldb, g.ldc = M, N, K, lda, ldb, ldc
+    g.ldmask = kw.pop('ldmask', N)
+    g.transA, g.transB = int(transA), int(transB)
+    g.taps, g.Kc, g.batch, g.zt = 1, K, 1, 1
+    g.alpha, g.beta, g.act, g.mask_scale = alpha, beta, act, mask_scale
+    for k, v in kw.items():
+        setattr(g, k, v)
+    check(lib().mtts_gemm_ex(ctypes.byref(g), stream_ptr()), 'mtts_gemm_ex')
+    return C
+
+
+def linear_fwd(x, weight, bias=None, act=0, mask=None, mask_scale=1.0):
+    """y = act(x W^T + b) [* dropout]; x [..., K] contiguous, weight [N, K] (torch Linear layout)."""
+    require_gpu(x, weight)
+    K = x.shape[-1]
+    N = weight.shape[0]
+    x2 = x.reshape(-1, K)
+    y = _f32(x2.shape[0], N, device=x.device)
+    gemm(x2, weight, y, x2.shape[0], N, K, K, K, N, bias=bias, act=act, mask=mask, mask_scale=mask_scale)
+    return y.reshape(*x.shape[:-1], N)
+
+
+def linear_bwd(x, weight, dy, need_dx=True):
+    """Gradients of y = x W^T + b given dy (pre-activation gradient)."""
+    K = x.shape[-1]
+    N = weight.shape[0]
+    x2, dy2 = x.reshape(-1, K), dy.reshape(-1, N)
+    R = x2.shape[0]
+    dW = _f32(N, K, device=x.device)
+    gemm(dy2, x2, dW, N, K, R, N, K, K, transA=True, transB=True)
+    db = dy2.sum(0)
+    dx = None
+    if need_dx:
+        dx = _f32(R, K, device=x.device)
+        gemm(dy2, weight, dx, R, K, N, N, K, K, transB=True)
+        dx = dx.reshape(x.shape)
+    return dx, dW, db
+
+
+class LinearFn(torch.autograd.Function):
+    """Linear (+ReLU +dropout) through the MFMA GEMM.  mask: uint8 keep flags or None."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, mask, mask_scale):
+        x = x.contiguous()
+        y = linear_fwd(x, weight, bias, act, mask, mask_scale)
+        ctx.save_for_backward(x, weight, y, mask)
+        ctx.act, ctx.mask_scale, ctx.has_bias = act, mask_scale, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y, mask = ctx.saved_tensors
+        dz = dy.contiguous()
+        if mask is not None:
+            dz = dz * mask.view_as(dz) * ctx.mask_scale
+        if ctx.act == 1:
+            dz = dz * (y > 0)
+        elif ctx.act != 0:
+            raise NotImplementedError('LinearFn backward supports identity/relu')
+        dx, dW, db = linear_bwd(x, weight, dz, ctx.needs_input_grad[0])
+        return dx, dW, (db if ctx.has_bias else None), None, None, None
+
+
+def linear(x, weight, bias=None, act='identity', mask=None, mask_scale=1.0):
+    return LinearFn.apply(x, weight, bias, ACT[act], mask, mask_scale)
+
+
+# ------------------------------------------------------------------------------------------------
+# Embedding
+# ------------------------------------------------------------------------------------------------
+
+class EmbeddingFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, ids, padding_idx):
+        require_gpu(table, ids)
+        ids = ids.contiguous()
+        D = table.shape[1]
+        out = _f32(*ids.shape, D, device=table.device)
+        check(lib().mtts_embedding_fwd(ptr(table), ptr(ids), ptr(out), ids.numel(), D, D, 0, stream_ptr()), 'embedding_fwd')
+        ctx.save_for_backward(ids)
+        ctx.shape, ctx.padding_idx = table.shape, padding_idx
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (ids,) = ctx.saved_tensors
+        dout = dout.contiguous()
+        D = ctx.shape[1]
+        dtable = torch.zeros(ctx.shape, dtype=torch.float32, device=dout.device)
+        check(lib().mtts_embedding_bwd(ptr(dout), ptr(ids), ptr(dtable), ids.numel(), D, D, 0,
+                                       -1 if ctx.padding_idx is None else ctx.padding_idx, stream_ptr()), 'embedding_bwd')
+        return dtable, None, None
+
+
+def embedding(table, ids, padding_idx=None):
+    return EmbeddingFn.apply(table, ids, padding_idx)
+
+
+# ------------------------------------------------------------------------------------------------
+# Conv1d (+BN +act +dropout +highway), channel-last
+# ------------------------------------------------------------------------------------------------
+
+def pack_conv_weight(weight):
+    """torch [O, I, k] -> implicit-GEMM layout [O, k, I]."""
+    O, I, k = weight.shape
+    out = _f32(O, k, I, device=weight.device)
+    check(lib().mtts_conv_weight_pack(ptr(weight.contiguous()), ptr(out), O, I, k, 1, stream_ptr()), 'conv_weight_pack')
+    return out
+
+
+def unpack_conv_weight(packed, O, I, k):
+    out = _f32(O, I, k, device=packed.device)
+    check(lib().mtts_conv_weight_pack(ptr(packed), ptr(out), O, I, k, 0, stream_ptr()), 'conv_weight_pack')
+    return out
+
+
+def conv1d_fwd(x, wp, k, dilation, groups):
+    """x [N, L, Cin] channel-last, wp packed [O, k, Cin/G] -> [N, L, O] ('same' zero padding)."""
+    N_, L, Cin = x.shape
+    O = wp.shape[0]
+    Cg, Og = Cin // groups, O // groups
+    y = _f32(N_, L, O, device=x.device)
+    p = (k - 1) * dilation // 2
+    gemm(x, wp, y, N_ * L, Og, k * Cg, Cin, k * Cg, O, taps=k, Kc=Cg, seq_len=L, shift_mode=1, shift0=-p, dshift=dilation,
+         batch=groups, a_z=Cg, b_z=Og * k * Cg, c_z=Og)
+    return y
+
+
+def conv1d_bwd(x, wp, dy, k, dilation, groups, need_dx=True):
+    """Gradients of conv1d_fwd: dx [N,L,Cin], dwp packed [O,k,Cin/G]."""
+    N_, L, Cin = x.shape
+    O = wp.shape[0]
+    Cg, Og = Cin // groups, O // groups
+    R = N_ * L
+    p = (k - 1) * dilation // 2
+    dwp = _f32(O, k, Cg, device=x.device)
+    # dW[o, t, c] = sum_r dy[r, o] * x[r + shift_t, c]   (one TN GEMM per tap through grid.z)
+    gemm(dy, x, dwp, Og, Cg, R, O, Cin, k * Cg, transA=True, transB=True, seq_len=L, shift_mode=2, shift0=-p,
+         dshift=dilation, batch=groups, zt=k, a_z=Og, b_z=Cg, c_z=Og * k * Cg, c_ztap=Cg)
+    dx = None
+    if need_dx:
+        dx = _f32(N_, L, Cin, device=x.device)
+        # dx[r, c] = sum_t sum_o dy[r - shift_t, o] * w[o, t, c]
+        gemm(dy, wp, dx, R, Cg, k * Og, O, k * Cg, Cin, transB=True, taps=k, Kc=Og, seq_len=L, shift_mode=1, shift0=p,
+             dshift=-dilation, b_tap=Cg, batch=groups, a_z=Og, b_z=Og * k * Cg, c_z=Cg)
+    return dx, dwp
+
+
+def _bn_args(x2, gamma, beta, rmean, rvar, smean, srstd, mask, resid, y, ws, training, momentum, eps, act, mask_scale,
+             hw_groups):
+    a = _C.BnArgs()
+    a.x, a.gamma, a.beta = ptr(x2), ptr(gamma), ptr(beta)
+    a.running_mean, a.running_var, a.save_mean, a.save_rstd = ptr(rmean), ptr(rvar), ptr(smean), ptr(srstd)
+    a.mask, a.resid, a.y, a.ws = ptr(mask), ptr(resid), ptr(y), ptr(ws)
+    a.R, a.C = x2.shape[0], x2.shape[1]
+    a.training, a.momentum, a.eps, a.act, a.mask_scale, a.hw_groups = int(training), momentum, eps, act, mask_scale, hw_groups
+    return a
+
+
+class ConvBnActFn(torch.autograd.Function):
+    """pad -> conv1d(groups, dilation, no bias) -> BatchNorm -> act -> dropout [-> highway gate], channel-last.
+
+    reference: ConvBlock modules/layers.py:50-86, HighwayConvBlock :134-153 and the generated variants :89-178
+    (the generated kernel / affine tensors are passed in as `weight`, `gamma`, `beta`)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, rmean, rvar, mask, cfg):
+        k, dilation, groups, act, training, momentum, eps, mask_scale, highway = cfg
+        require_gpu(x, weight)
+        x = x.contiguous()
+        N_, L, Cin = x.shape
+        O = weight.shape[0]
+        wp = pack_conv_weight(weight)
+        conv = conv1d_fwd(x, wp, k, dilation, groups)
+        conv2 = conv.view(N_ * L, O)
+        dev = x.device
+        smean, srstd = _f32(O, device=dev), _f32(O, device=dev)
+        ws = _f32(int(lib().mtts_bn_workspace_floats(O)), device=dev)
+        Cy = O // 2 if highway else O
+        y = _f32(N_, L, Cy, device=dev)
+        a = _bn_args(conv2, gamma.contiguous(), beta.contiguous(), rmean, rvar, smean, srstd, mask, x if highway else None, y, ws,
+                     training, momentum, eps, act, mask_scale, groups if highway else 0)
+        check(lib().mtts_bn_act_fwd(ctypes.byref(a), stream_ptr()), 'bn_act_fwd')
+        ctx.save_for_backward(x, wp, conv, gamma, beta, smean, srstd, mask)
+        ctx.cfg, ctx.wshape = cfg, tuple(weight.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wp, conv, gamma, beta, smean, srstd, mask = ctx.saved_tensors
+        k, dilation, groups, act, training, momentum, eps, mask_scale, highway = ctx.cfg
+        N_, L, Cin = x.shape
+        O = conv.shape[2]
+        dev = x.device
+        dy = dy.contiguous()
+        dconv = _f32(N_, L, O, device=dev)
+        dgamma, dbeta = _f32(O, device=dev), _f32(O, device=dev)
+        dresid = _f32(N_, L, O // 2, device=dev) if highway else None
+        ws = _f32(int(lib().mtts_bn_workspace_floats(O)), device=dev)
+        a = _bn_args(conv.view(N_ * L, O), gamma.contiguous(), beta.contiguous(), None, None, smean, srstd, mask,
+                     x if highway else None, None, ws, training, momentum, eps, act, mask_scale, groups if highway else 0)
+        a.dy, a.dx, a.dgamma, a.dbeta, a.dresid = ptr(dy), ptr(dconv), ptr(dgamma), ptr(dbeta), ptr(dresid)
+        check(lib().mtts_bn_act_bwd(ctypes.byref(a), stream_ptr()), 'bn_act_bwd')
+        dx, dwp = conv1d_bwd(x, wp, dconv, k, dilation, groups, ctx.needs_input_grad[0] or highway)
+        if highway:
+            dx = dx + dresid
+        dw = unpack_conv_weight(dwp, *ctx.wshape)
+        return dx, dw, dgamma, dbeta, None, None, None, None
+
+
+def conv_bn_act(x, weight, gamma, beta, rmean, rvar, mask, *, kernel, dilation=1, groups=1, act='identity', training=True,
+                momentum=0.1, eps=1e-5, mask_scale=1.0, highway=False):
+    cfg = (kernel, dilation, groups, ACT[act], training, momentum, eps, mask_scale, highway)
+    return ConvBnActFn.apply(x, weight, gamma, beta, rmean, rvar, mask, cfg)
+
+
+# ------------------------------------------------------------------------------------------------
+# BiLSTM (packed-sequence semantics)
+# ------------------------------------------------------------------------------------------------
+
+class BiLstmFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, lengths, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+        require_gpu(x, w_ih)
+        x = x.contiguous()
+        B, L, Cin = x.shape
+        H = w_hh.shape[1]
+        dev = x.device
+        a = _C.BiLstmArgs()
+        a.B, a.L, a.Cin, a.H = B, L, Cin, H
+        lengths32 = lengths.to(device=dev, dtype=torch.int32).contiguous()
+        a.x, a.lengths = ptr(x), ptr(lengths32)
+        ws = [(w_ih.contiguous(), w_hh.contiguous(), b_ih.contiguous(), b_hh.contiguous()),
+              (w_ih_r.contiguous(), w_hh_r.contiguous(), b_ih_r.contiguous(), b_hh_r.contiguous())]
+        xproj = [_f32(B, L, 4 * H, device=dev) for _ in range(2)]
+        h = [torch.zeros(L + 1, B, H, device=dev) for _ in range(2)]
+        c = [torch.zeros(L + 1, B, H, device=dev) for _ in range(2)]
+        gates = [_f32(L, B, 4 * H, device=dev) for _ in range(2)]
+        y = _f32(B, L, 2 * H, device=dev)
+        for d in range(2):
+            a.w_ih[d], a.w_hh[d], a.b_ih[d], a.b_hh[d] = (t.data_ptr() for t in ws[d])
+            a.xproj[d], a.h[d], a.c[d], a.gates[d] = xproj[d].data_ptr(), h[d].data_ptr(), c[d].data_ptr(), gates[d].data_ptr()
+        a.y = ptr(y)
+        check(lib().mtts_bilstm_fwd(ctypes.byref(a), stream_ptr()), 'bilstm_fwd')
+        ctx.save_for_backward(x, lengths32, *ws[0], *ws[1], *h, *c, *gates)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .backward import bilstm_bwd
+        return bilstm_bwd(ctx, dy)
+
+
+def bilstm(x, lengths, params):
+    return BiLstmFn.apply(x, lengths, *params)
+
+
+def grad_reverse_clamp(g, l, c):
+    """clamp(g, -c, c) * (-l): gradient-reversal backward (reference modules/classifier.py:16-18)."""
+    require_gpu(g)
+    g = g.contiguous()
+    out = torch.empty_like(g)
+    check(lib().mtts_grad_reverse_clamp(ptr(g), ptr(out), g.numel(), float(l), float(c), stream_ptr()), 'grad_reverse_clamp')
+    return out

@@ -1,0 +1,288 @@
+"""Tacotron 2 assembly with the reference's public API (modules/tacotron2.py:222-408) on the HIP hot path.
+
+`Tacotron()` reads the global `hp`, exposes the same attribute tree and `state_dict` names (including the
+aliased `_prenet` / `_attention` entries), the same `forward(...)` 6-tuple and `inference(...)`.  All
+arithmetic is dispatched to libmtts_hip; there is no CPU execution path.
+"""
+import torch
+from torch.nn import functional as F
+from torch.nn import Sequential, ModuleList, Linear, Embedding, Module
+
+from .. import kernels as K
+from .. import decoder_ops as D
+from ..masks import provider
+from ..params.params import Params as hp
+from ..utils import lengths_to_mask
+from .layers import ZoneoutLSTMCell, DropoutLSTMCell, ConvBlock, _Slot
+from .attention import LocationSensitiveAttention
+from .encoder import Encoder, MultiEncoder, ConditionalEncoder, ConvolutionalEncoder, GeneratedConvolutionalEncoder
+from .classifier import ReversalClassifier
+
+
+class Prenet(Module):
+    """2x(Linear -> ReLU -> dropout that is ALWAYS on); reference modules/tacotron2.py:15-46.
+    Evaluated inside the decoder kernels (batched over teacher frames, or per free-running step)."""
+
+    def __init__(self, input_dim, output_dim, num_layers, dropout):
+        super().__init__()
+        assert num_layers > 0, 'There must be at least one layer in the pre-net.'
+        self._dropout_rate = dropout
+        self._activation = _Slot('relu')
+        self._layers = ModuleList([Linear(input_dim, output_dim)] + [Linear(output_dim, output_dim) for _ in range(num_layers - 1)])
+
+
+class Postnet(Module):
+    """5 ConvBlocks (tanh x4, identity) + residual on channel-last frames; reference modules/tacotron2.py:49-76."""
+
+    def __init__(self, input_dimension, postnet_dimension, num_blocks, kernel_size, dropout):
+        super().__init__()
+        assert num_blocks > 1, 'There must be at least two convolutional blocks in the post-net.'
+        self._convs = Sequential(
+            ConvBlock(input_dimension, postnet_dimension, kernel_size, dropout, 'tanh'),
+            *[ConvBlock(postnet_dimension, postnet_dimension, kernel_size, dropout, 'tanh') for _ in range(num_blocks - 2)],
+            ConvBlock(postnet_dimension, input_dimension, kernel_size, dropout, 'identity'))
+
+    def forward(self, x, x_lengths=None):
+        """x [B, T, M] channel-last -> [B, T, M]."""
+        residual = x
+        for i, block in enumerate(self._convs):
+            x = block(x, f'post.{i}')
+        return x + residual
+
+
+class Decoder(Module):
+    """Attention + 2 LSTM cells + frame/stop projections; reference modules/tacotron2.py:79-219."""
+
+    def __init__(self, output_dim, decoder_dim, attention, generator_rnn, attention_rnn, context_dim, prenet, prenet_dim,
+                 max_frames):
+        super().__init__()
+        self._prenet = prenet
+        self._attention = attention
+        self._output_dim = output_dim
+        self._decoder_dim = decoder_dim
+        self._max_frames = max_frames
+        self._attention_lstm = attention_rnn
+        self._generator_lstm = generator_rnn
+        self._frame_prediction = Linear(context_dim + decoder_dim, output_dim)
+        self._stop_prediction = Linear(context_dim + decoder_dim, 1)
+        self._speaker_embedding, self._language_embedding = None, None
+        if hp.multi_speaker and hp.speaker_embedding_dimension > 0:
+            self._speaker_embedding = self._get_embedding(hp.speaker_embedding_dimension, hp.speaker_number)
+        if hp.multi_language and hp.language_embedding_dimension > 0:
+            self._language_embedding = self._get_embedding(hp.language_embedding_dimension, len(hp.languages))
+
+    def _get_embedding(self, embedding_dimension, size=None):
+        embedding = Embedding(size, embedding_dimension)
+        torch.nn.init.xavier_uniform_(embedding.weight)
+        return embedding
+
+    def _memory(self, encoded_input, speaker, language):
+        """Concatenate speaker / language embedding rows to the encoder output (tacotron2.py:143-146,158-161)."""
+        parts = [encoded_input]
+        if hp.multi_speaker and self._speaker_embedding is not None:
+            parts.append(K.embedding(self._speaker_embedding.weight, speaker))
+        if hp.multi_language and self._language_embedding is not None:
+            parts.append(K.embedding(self._language_embedding.weight, language))
+        return torch.cat(parts, dim=-1) if len(parts) > 1 else encoded_input
+
+    def _cfg(self):
+        zone = hp.decoder_regularization == 'zoneout'
+        return dict(training=self.training, zone=zone, p_prenet=float(self._prenet._dropout_rate),
+                    p_hidden=float(hp.zoneout_hidden if zone else hp.dropout_hidden), p_cell=float(hp.zoneout_cell))
+
+    def _step_masks(self, T, B, device):
+        """uint8 keep flags for the decoder loop: prenet (always) and LSTM hidden-state regularisation (training)."""
+        P, H = hp.prenet_dimension, self._decoder_dim
+        masks = {}
+        for i in range(len(self._prenet._layers)):
+            masks[f'prenet.{i}'] = provider.keep(f'dec.prenet.{i}', (T, B, P), self._prenet._dropout_rate, device)
+        if self.training:
+            if hp.decoder_regularization == 'zoneout':
+                masks['att_h'] = provider.keep('dec.att_lstm.h', (T, B, H), hp.zoneout_hidden, device)
+                masks['att_c'] = provider.keep('dec.att_lstm.c', (T, B, H), hp.zoneout_cell, device)
+                masks['gen_h'] = provider.keep('dec.gen_lstm.h', (T, B, H), hp.zoneout_hidden, device)
+                masks['gen_c'] = provider.keep('dec.gen_lstm.c', (T, B, H), hp.zoneout_cell, device)
+            else:
+                masks['att_h'] = provider.keep('dec.att_lstm', (T, B, H), hp.dropout_hidden, device)
+                masks['gen_h'] = provider.keep('dec.gen_lstm', (T, B, H), hp.dropout_hidden, device)
+        return masks
+
+    def forward(self, encoded_input, encoded_lenghts, target, teacher_forcing_ratio, speaker, language):
+        """target [B, M, T] (reference layout) -> spectrogram [B,T,M], stop [B,T], alignments [B,T,L]."""
+        memory = self._memory(encoded_input, speaker, language)
+        B, T = target.shape[0], target.shape[2]
+        teacher = provider.teacher(T, teacher_forcing_ratio)
+        masks = self._step_masks(T, B, memory.device)
+        w = D.decoder_weights(self, self._attention, self._prenet)
+        tgt = target.transpose(1, 2).contiguous()
+        return D.decode_train(memory, tgt, encoded_lenghts, teacher, masks, self._cfg(), w)
+
+    def inference(self, encoded_input, speaker, language, lengths=None):
+        memory = self._memory(encoded_input, speaker, language)
+        B, L = memory.shape[0], memory.shape[1]
+        if lengths is None:
+            lengths = torch.full((B,), L, dtype=torch.int64)
+        masks = self._step_masks(self._max_frames, B, memory.device)
+        w = D.decoder_weights(self, self._attention, self._prenet)
+        with torch.no_grad():
+            frames, _, _, n = D.decode_free(memory, lengths, w, self._cfg(), masks, self._max_frames, hp.stop_frames)
+        return frames, n
+
+
+class Tacotron(Module):
+    """reference modules/tacotron2.py:222-408."""
+
+    def __init__(self):
+        super().__init__()
+        other_symbols = 3   # PAD, EOS, UNK
+        self._embedding = Embedding(hp.symbols_count() + other_symbols, hp.embedding_dimension, padding_idx=0)
+        torch.nn.init.xavier_uniform_(self._embedding.weight)
+        self._encoder = self._get_encoder(hp.encoder_type)
+        if hp.reversal_classifier:
+            self._reversal_classifier = self._get_adversarial_classifier(hp.reversal_classifier_type)
+        self._prenet = Prenet(hp.num_mels, hp.prenet_dimension, hp.prenet_layers, hp.dropout)
+        decoder_input_dimension = hp.encoder_dimension
+        if hp.multi_speaker:
+            decoder_input_dimension += hp.speaker_embedding_dimension
+        if hp.multi_language:
+            decoder_input_dimension += hp.language_embedding_dimension
+        self._attention = self._get_attention(hp.attention_type, decoder_input_dimension)
+        gen_cell_dimension = decoder_input_dimension + hp.decoder_dimension
+        att_cell_dimension = decoder_input_dimension + hp.prenet_dimension
+        if hp.decoder_regularization == 'zoneout':
+            generator_rnn = ZoneoutLSTMCell(gen_cell_dimension, hp.decoder_dimension, hp.zoneout_hidden, hp.zoneout_cell)
+            attention_rnn = ZoneoutLSTMCell(att_cell_dimension, hp.decoder_dimension, hp.zoneout_hidden, hp.zoneout_cell)
+        else:
+            generator_rnn = DropoutLSTMCell(gen_cell_dimension, hp.decoder_dimension, hp.dropout_hidden)
+            attention_rnn = DropoutLSTMCell(att_cell_dimension, hp.decoder_dimension, hp.dropout_hidden)
+        self._decoder = Decoder(hp.num_mels, hp.decoder_dimension, self._attention, generator_rnn, attention_rnn,
+                                decoder_input_dimension, self._prenet, hp.prenet_dimension, hp.max_output_length)
+        self._postnet = self._get_postnet("cbhg" if hp.predict_linear else "conv")
+
+    def _get_encoder(self, name):
+        args = (hp.embedding_dimension, hp.encoder_dimension, hp.encoder_blocks, hp.encoder_kernel_size, hp.dropout)
+        ln = 1 if not hp.multi_language else hp.language_number
+        if name == "simple":
+            return Encoder(*args)
+        elif name == "separate":
+            return MultiEncoder(hp.language_number, args)
+        elif name == "shared":
+            return ConditionalEncoder(hp.language_number, hp.input_language_embedding, args)
+        elif name == "convolutional":
+            return ConvolutionalEncoder(hp.embedding_dimension, hp.encoder_dimension, 0.05, ln)
+        elif name == "generated":
+            return GeneratedConvolutionalEncoder(hp.embedding_dimension, hp.encoder_dimension, 0.05, hp.generator_dim,
+                                                 hp.generator_bottleneck_dim, groups=ln)
+        raise ValueError(f'unknown encoder_type {name!r}')
+
+    def _get_adversarial_classifier(self, name):
+        if name == "reversal":
+            return ReversalClassifier(hp.encoder_dimension, hp.reversal_classifier_dim, hp.speaker_number,
+                                      hp.reversal_gradient_clipping)
+        raise NotImplementedError("only the 'reversal' classifier is provided ('cosine' does not converge per the reference)")
+
+    def _get_attention(self, name, memory_dimension):
+        if name == "location_sensitive":
+            return LocationSensitiveAttention(hp.attention_kernel_size, hp.attention_location_dimension, False,
+                                              hp.attention_dimension, hp.decoder_dimension, memory_dimension)
+        raise NotImplementedError("only 'location_sensitive' attention is provided (the reference marks the others undebugged)")
+
+    def _get_postnet(self, name):
+        if name == "conv":
+            return Postnet(hp.num_mels, hp.postnet_dimension, hp.postnet_blocks, hp.postnet_kernel_size, hp.dropout)
+        raise NotImplementedError('predict_linear=True (CBHG post-net) is outside the MI355X hot path')
+
+    def forward(self, text, text_length, target, target_length, speakers, languages, teacher_forcing_ratio=0.0):
+        if speakers is not None and speakers.dim() == 1:
+            speakers = speakers.unsqueeze(1).expand((-1, text.size(1)))
+        if languages is not None and languages.dim() == 1:
+            languages = languages.unsqueeze(1).expand((-1, text.size(1)))
+
+        embedded = K.embedding(self._embedding.weight, text, padding_idx=0)
+        encoded = self._encoder(embedded, text_length, languages)
+        encoder_output = encoded
+        speaker_prediction = self._reversal_classifier(encoded) if hp.reversal_classifier else None
+
+        if languages is not None and languages.dim() == 3:
+            languages = torch.argmax(languages, dim=2)
+        prediction, stop_token, alignment = self._decoder(encoded, text_length, target, teacher_forcing_ratio, speakers, languages)
+        post = self._postnet(prediction, target_length)                    # channel-last [B,T,M]
+        pre_prediction = prediction.transpose(1, 2)
+        post_prediction = post.transpose(1, 2)
+
+        target_mask = lengths_to_mask(target_length.to(stop_token.device), target.size(2))
+        stop_token = stop_token.masked_fill(~target_mask, 1000)
+        target_mask = target_mask.unsqueeze(1).float()
+        pre_prediction = pre_prediction * target_mask
+        post_prediction = post_prediction * target_mask
+        return post_prediction, pre_prediction, stop_token, alignment, speaker_prediction, encoder_output
+
+    def inference(self, text, speaker=None, language=None):
+        """Batch-1 synthesis with the reference's semantics (mutates `text` in place like tacotron2.py:389)."""
+        text.unsqueeze_(0)
+        if speaker is not None and speaker.dim() == 1:
+            speaker = speaker.unsqueeze(1).expand((-1, text.size(1)))
+        if language is not None and language.dim() == 1:
+            language = language.unsqueeze(1).expand((-1, text.size(1)))
+        with torch.no_grad():
+            embedded = K.embedding(self._embedding.weight, text, padding_idx=0)
+            encoded = self._encoder(embedded, torch.LongTensor([text.size(1)]), language)
+            if language is not None and language.dim() == 3:
+                language = torch.argmax(language, dim=2)
+            frames, n = self._decoder.inference(encoded, speaker, language)
+            post = self._postnet(frames[:, :n[0]].contiguous(), None)
+        return post.transpose(1, 2).squeeze(0)
+
+
+class TacotronLoss(Module):
+    """Loss wrapper with the reference's API and state (modules/tacotron2.py:411-485)."""
+
+    def __init__(self, guided_att_steps, guided_att_variance, guided_att_gamma):
+        super().__init__()
+        self._g = guided_att_variance
+        self._gamma = guided_att_gamma
+        self._g_steps = guided_att_steps
+
+    def load_state_dict(self, d):
+        for k, v in d.items():
+            setattr(self, k, v)
+
+    def state_dict(self):
+        return {"_g": self._g, "_g_steps": self._g_steps}
+
+    def update_states(self):
+        self._g *= self._gamma
+        self._g_steps = max(0, self._g_steps - 1)
+
+    def _guided_attention(self, alignments, input_lengths, target_lengths):
+        """Same weights as tacotron2.py:443-457, built for the whole batch at once (no per-sample Python loop)."""
+        if self._g_steps == 0:
+            return 0
+        dev = alignments.device
+        B, T, L = alignments.shape
+        f = target_lengths.to(dev).float().view(B, 1, 1)
+        l = input_lengths.to(dev).float().view(B, 1, 1)
+        gf = torch.arange(T, dtype=torch.float, device=dev).view(1, T, 1)
+        gl = torch.arange(L, dtype=torch.float, device=dev).view(1, 1, L)
+        weights = 1 - torch.exp(-(gl / l - gf / f) ** 2 / (2 * self._g ** 2))
+        weights = weights * (gf < f) * (gl < l)
+        loss = torch.sum(weights * alignments, dim=(1, 2))
+        return torch.mean(loss / target_lengths.to(dev).float())
+
+    def forward(self, source_length, target_length, pre_prediction, pre_target, post_prediction, post_target, stop, target_stop,
+                alignment, speaker, speaker_prediction, encoder_outputs, classifier):
+        pre_target.requires_grad = False
+        post_target.requires_grad = False
+        target_stop.requires_grad = False
+        stop_balance = torch.tensor([100], device=stop.device, dtype=torch.float32)
+        losses = {
+            'mel_pre': 2 * F.mse_loss(pre_prediction, pre_target),
+            'mel_pos': F.mse_loss(post_prediction, post_target),
+            'stop_token': F.binary_cross_entropy_with_logits(stop, target_stop, pos_weight=stop_balance) / (hp.num_mels + 2),
+        }
+        if hp.reversal_classifier:
+            losses['lang_class'] = ReversalClassifier.loss(source_length, speaker, speaker_prediction)
+            losses['lang_class'] *= hp.reversal_classifier_w / (hp.num_mels + 2)
+        if hp.guided_attention_loss:
+            losses['guided_att'] = self._guided_attention(alignment, source_length, target_length)
+        return sum(losses.values()), losses

@@ -48,3 +48,65 @@ def oracle_replay(fx, with_grads=False):
         loss.backward()
         grads = {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
     return out, loss, parts, grads
+
+
+# ------------------------------------------------------------------------------------------------
+# HIP-side helpers (GPU tests)
+# ------------------------------------------------------------------------------------------------
+
+def build_hip_model(fx, device='cuda'):
+    """Instantiate the product model for a fixture's hyper-parameters and load the reference weights."""
+    from multilingual_text_to_speech_amd.params import Params, reset_defaults
+    from multilingual_text_to_speech_amd.modules.tacotron2 import Tacotron
+    reset_defaults()
+    Params.load_state_dict(fx['hp'])
+    model = Tacotron()
+    missing, unexpected = model.load_state_dict(fx['state_dict'], strict=True), None
+    model.to(device)
+    model.train(fx['train'])
+    return model
+
+
+def injected_masks(fx, device='cuda'):
+    """Convert the reference's recorded dropout multipliers to the product's uint8 / channel-last layout."""
+    m = fx['masks']
+    out = {}
+    keep = lambda t: (t != 0).to(torch.uint8)
+    for k, v in m.items():
+        if k.startswith(('enc', 'post.')):
+            out[k] = keep(v).permute(0, 2, 1).contiguous().to(device)
+    teacher = fx.get('teacher')
+    if teacher is not None:
+        out['teacher'] = [bool(x) for x in teacher]
+        T = len(teacher)
+        i = 0
+        while f'prenet.{i}' in m:
+            pm = keep(m[f'prenet.{i}'])[:, :T].transpose(0, 1).contiguous()          # [T,B,P]
+            if f'prenet_step.{i}' in m:
+                ps = keep(m[f'prenet_step.{i}'])                                       # [T,B,P]
+                for t in range(T):
+                    if not out['teacher'][t]:
+                        pm[t] = ps[t]
+            out[f'dec.prenet.{i}'] = pm.to(device)
+            i += 1
+    else:
+        i = 0
+        while f'prenet_step.{i}' in m:
+            out[f'dec.prenet.{i}'] = keep(m[f'prenet_step.{i}']).contiguous().to(device)
+            i += 1
+    for src, dst in (('att_lstm', 'dec.att_lstm'), ('gen_lstm', 'dec.gen_lstm'), ('att_lstm.h', 'dec.att_lstm.h'),
+                     ('att_lstm.c', 'dec.att_lstm.c'), ('gen_lstm.h', 'dec.gen_lstm.h'), ('gen_lstm.c', 'dec.gen_lstm.c')):
+        if src in m:
+            out[dst] = keep(m[src]).contiguous().to(device)
+    return out
+
+
+def hip_forward(fx, model, device='cuda'):
+    from multilingual_text_to_speech_amd.masks import provider
+    provider.injected = injected_masks(fx, device)
+    try:
+        to = lambda t: None if t is None else t.to(device)
+        return model(to(fx['text']), fx['text_length'], to(fx['target']), fx['target_length'], to(fx['speakers']),
+                     to(fx['languages']), 1.0)
+    finally:
+        provider.injected = None
