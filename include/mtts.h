@@ -149,6 +149,23 @@ typedef struct SkinnyArgs {
     int t;
     float* y_out;
     int ldy;
+    /* lstm == 2: LSTM-cell BACKWARD epilogue.  The GEMM part (may be empty) yields one more addend of dh.
+       dh[b,u] = gemm + dh_a + dh_b + sum_k part[k] ;  outputs dgates (pre-activation gate gradients), dc_out,
+       and dh_carry_out (the part of dh that bypasses the cell: zoneout-kept or packed-sequence-carried rows). */
+    const float* dh_a;     /* [B, ld_dh_a] addend or NULL */
+    int ld_dh_a;
+    const float* dh_b;     /* [B,H] addend (carry from the later step) or NULL */
+    const float* part;     /* [n_part][B][part_ld] partial sums of the later step's input-gradient GEMM or NULL */
+    int n_part;
+    long part_ks;
+    int part_ld;
+    int part_col0;
+    const float* gates;    /* [B,4H] activated gates saved by the forward */
+    const float* dc_in;    /* [B,H] */
+    float* dc_out;         /* [B,H] */
+    float* dgates_out;     /* [B, ld_dgates] */
+    int ld_dgates;
+    float* dh_carry_out;   /* [B,H] or NULL */
 } SkinnyArgs;
 
 int mtts_skinny_gemm(const SkinnyArgs* args, void* stream);
@@ -174,6 +191,7 @@ typedef struct AttnStepArgs {
     float* cum_out;        /* [B,L] */
     float* w_out;          /* [B,L] alignment of this step */
     float* ctx_out;        /* [B,Dm] */
+    float* q_out;          /* [B,A] summed query projection saved for backward (nullable) */
     int B;
     int L;
     int A;
@@ -256,6 +274,7 @@ typedef struct DecoderArgs {
     float* out;            /* [T+1,B,Mo] (Mo = M+1 rounded up to 4): slot t+1 = frame + stop logit of step t, slot 0 = zero frame */
     float* pre_att;        /* [T,B,4H] hoisted input projection workspace (fast path) or NULL */
     float* pre_gen;        /* [T,B,4H] */
+    float* q_all;          /* [T,B,A] query projections saved for backward or NULL */
     int fast;              /* 1: all steps teacher forced -> hoisted projections + deferred generator chain */
 } DecoderArgs;
 
@@ -268,20 +287,134 @@ typedef struct BiLstmArgs {
     int L;
     int Cin;
     int H;                 /* per direction */
-    const float* x;        /* [B,L,Cin] */
+    const float* x;        /* [L,B,Cin] time-major */
     const int* lengths;
     const float* w_ih[2];  /* [4H,Cin] fwd, reverse */
     const float* w_hh[2];  /* [4H,H] */
     const float* b_ih[2];
     const float* b_hh[2];
-    float* xproj[2];       /* [B,L,4H] workspace */
-    float* h[2];           /* [L+1,B,H] */
+    float* xproj[2];       /* [L,B,4H] workspace */
+    float* h[2];           /* [L+1,B,H]; fwd: slot t -> t+1; reverse: slot t+1 -> t (slot L zero) */
     float* c[2];
     float* gates[2];       /* [L,B,4H] or NULL */
     float* y;              /* [B,L,2H] */
 } BiLstmArgs;
 
 int mtts_bilstm_fwd(const BiLstmArgs* args, void* stream);
+
+/* ---- attention step, backward ---------------------------------------------------------------------------------
+ * Gradient of one LocationSensitiveAttention step (modules/attention.py:39-45,67-86).  PL is recomputed from the
+ * saved cumulative alignment; per-workgroup slabs (dU, dv, dbias) avoid global atomics on shared parameters. */
+typedef struct AttnBwdArgs {
+    const float* q;        /* [B,A] saved query projection of this step */
+    const float* Mt;       /* [B,L,A] */
+    const float* U;        /* [A,ksz] */
+    const float* bias;
+    const float* v;
+    const float* memory;   /* [B,L,Dm] */
+    const float* ctx;      /* [B,Dm] context produced by this step */
+    const int* lengths;
+    const float* w;        /* [B,L] alignment of this step */
+    const float* cum_in;   /* [B,L] cumulative alignment fed to this step */
+    const float* dalign;   /* [B,L] external gradient w.r.t. the alignment or NULL */
+    const float* dcum_out; /* [B,L] gradient w.r.t. the cumulative alignment AFTER this step */
+    float* dcum_in;        /* [B,L] gradient w.r.t. cum_in (zero-initialised by the caller; accumulated atomically) */
+    const float* dctx;     /* [B,Dm] direct part of the context gradient */
+    float* dctx_total;     /* [B,Dm] out: direct + sum of partials (kept for the memory-gradient GEMM) */
+    const float* part;     /* [n_part][B][part_ld] partials carrying the remaining context gradient (columns [0,Dm)) or NULL */
+    int n_part;
+    long part_ks;
+    int part_ld;
+    float* dq;             /* [B,A] zero-initialised, accumulated atomically */
+    float* dMt;            /* [B,L,A] accumulated (+=) */
+    float* dU_slab;        /* [B*nch][A*ksz] accumulated (+=) */
+    float* dv_slab;        /* [B*nch][A] */
+    float* dbias_slab;     /* [B*nch][A] */
+    int B;
+    int L;
+    int A;
+    int Dm;
+    int ksz;
+    int nch;
+} AttnBwdArgs;
+
+int mtts_attn_step_bwd(const AttnBwdArgs* args, void* stream);
+
+/* ---- whole decoder loop, backward (BPTT) -------------------------------------------------------------------------
+ * Consumes the buffers saved by mtts_decoder_fwd (same DecoderArgs) plus the gradients of its outputs; all weight
+ * gradients are formed by large MFMA GEMMs over the saved per-step gate gradients after the sequential sweeps. */
+typedef struct DecoderGradArgs {
+    const float* dout;     /* [T+1,B,Mo] slot t+1 = gradient of (frame, stop) of step t */
+    const float* dalign;   /* [T,B,L] or NULL */
+    /* workspaces */
+    float* att_w_rec_T;    /* [Dm+H,4H] */
+    float* att_w_ih_T;     /* [P+Dm,4H] (general path) */
+    float* gen_w_hh_T;     /* [H,4H] */
+    float* gen_w_ih_T;     /* [H+Dm,4H] (general path) */
+    float* w_query_T;      /* [H,A] */
+    float* dG_att;         /* [T,B,4H] */
+    float* dG_gen;         /* [T,B,4H] */
+    float* dHG;            /* [T,B,H] */
+    float* dHA;            /* [T,B,H] */
+    float* dctx_all;       /* [T+1,B,Dm] direct (batched) parts, slot t+1 <-> context of step t */
+    float* dctx_tot;       /* [T+1,B,Dm] totals */
+    float* dcum_all;       /* [T+1,B,L] zero-initialised */
+    float* dq_all;         /* [T,B,A] zero-initialised */
+    float* part_gen;       /* [ksb,B,H] */
+    float* part_att;       /* [ksb,B,Dm+H] */
+    int ksb;
+    float* dc_att;         /* [2,B,H] zero-initialised */
+    float* dc_gen;         /* [2,B,H] zero-initialised */
+    float* dMt;            /* [B,L,A] zero-initialised */
+    float* dU_slab;        /* [B*nch,A*ksz] zero-initialised */
+    float* dv_slab;        /* [B*nch,A] zero-initialised */
+    float* dbias_slab;     /* [B*nch,A] zero-initialised */
+    int nch;
+    float* dU;             /* [A,ksz] */
+    float* dpren;          /* [n_prenet][T,B,P] gradient scratch for the prenet layers */
+    float* colsum_ws;      /* mtts_colsum_workspace_floats(max C) floats */
+    /* outputs */
+    float* dmemory;        /* [B,L,Dm] */
+    float* d_prenet_w[4];
+    float* d_prenet_b[4];
+    float* d_att_w_ih;
+    float* d_att_w_hh;
+    float* d_att_b_ih;
+    float* d_att_b_hh;
+    float* d_gen_w_ih;
+    float* d_gen_w_hh;
+    float* d_gen_b_ih;
+    float* d_gen_b_hh;
+    float* d_w_query;
+    float* d_w_memory;
+    float* d_w_loc;
+    float* d_w_conv;
+    float* d_att_bias;
+    float* d_w_energy;
+    float* d_w_out;
+    float* d_b_out;
+} DecoderGradArgs;
+
+int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* grad, void* stream);
+
+/* Backward of mtts_bilstm_fwd. */
+typedef struct BiLstmGradArgs {
+    const float* dy;       /* [B,L,2H] */
+    float* w_hh_T[2];      /* [H,4H] workspace */
+    float* dxproj[2];      /* [L,B,4H] gate gradients */
+    float* part;           /* [ksb,B,H] */
+    int ksb;
+    float* dc;             /* [2,B,H] zero-initialised */
+    float* dh_carry;       /* [2,B,H] zero-initialised */
+    float* colsum_ws;
+    float* dx;             /* [L,B,Cin] time-major */
+    float* d_w_ih[2];
+    float* d_w_hh[2];
+    float* d_b_ih[2];
+    float* d_b_hh[2];
+} BiLstmGradArgs;
+
+int mtts_bilstm_bwd(const BiLstmArgs* fwd, const BiLstmGradArgs* grad, void* stream);
 
 /* ---- small data-movement kernels --------------------------------------------------------------------------- */
 /* Embedding lookup (modules/tacotron2.py:363, :122 speaker/language tables): out[r, col0:col0+D] = table[ids[r]] */
@@ -294,12 +427,20 @@ int mtts_copy2d(const float* in, float* out, int rows, int cols, int ldi, int ld
 /* [O, I, k] <-> [O, k, I] weight repack for the implicit-GEMM convolution (to_packed != 0: torch layout -> packed) */
 int mtts_conv_weight_pack(const float* in, float* out, int O, int I, int k, int to_packed, void* stream);
 
+/* out[c, r] = in[r, c]  (in [rows, cols] row-major) */
+int mtts_transpose(const float* in, float* out, int rows, int cols, void* stream);
+/* out[c] = sum_r x[r*ld + c], deterministic two-stage reduction; ws: mtts_colsum_workspace_floats(cols) floats */
+long mtts_colsum_workspace_floats(int cols);
+int mtts_colsum(const float* x, float* out, int rows, int cols, int ld, float* ws, void* stream);
+/* dz = (y > 0) ? dy * scale : 0 -- backward of ReLU followed by dropout, y being the dropped activation */
+int mtts_relu_mask_bwd(const float* dy, const float* y, float* dz, long n, float scale, void* stream);
+
 /* Gradient reversal backward (modules/classifier.py:16-18): out = clamp(g, -c, c) * (-l) */
 int mtts_grad_reverse_clamp(const float* g, float* out, long n, float l, float c, void* stream);
 
 const char* mtts_last_error(void);
 int mtts_version(void);
-/* sizeof() of the structs above in declaration order (0 = GemmArgs ... 6 = BiLstmArgs); -1 when out of range */
+/* sizeof() of the structs above in declaration order (0 = GemmArgs ... 6 = BiLstmArgs, 7 = AttnBwdArgs, 8 = DecoderGradArgs, 9 = BiLstmGradArgs); -1 when out of range */
 int mtts_sizeof_struct(int which);
 
 #ifdef __cplusplus

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_kernel(AttnStepArgs p) 
     float* w = vv + A;                      // [L]
     float* cumw = w + L;                    // [L + ksz - 1]  cum_out with zero halo
     float* Us = cumw + L + ksz - 1;         // [A * ksz]
-    float* part = Us + A * ksz;             // [ATT_THREADS] context partials
+    float* part = sm + (((2 * A + 2 * L + ksz - 1 + A * ksz) + 3) & ~3);   // [4 * ATT_THREADS] context partials (16-B aligned)
     const int len = min(p.lengths[b], L);
 
     for (int a = tid; a < A; a += ATT_THREADS) {
@@ -28,22 +28,30 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_kernel(AttnStepArgs p) 
         for (int k = 0; k < p.kq; ++k) s += p.qpart[(long)k * p.q_ks + (long)b * A + a];
         q[a] = s;
         vv[a] = p.v[a];
+        if (ch == 0 && p.q_out) p.q_out[(long)b * A + a] = s;
     }
     if (p.PL_next)
         for (int i = tid; i < A * ksz; i += ATT_THREADS) Us[i] = p.U[i];
     __syncthreads();
 
-    // energies: one wave per position, lanes over the attention dimension
+    // energies: one wave per position (4 positions in flight per wave), lanes over the attention dimension
     const float* PLb = p.PL + (long)b * L * A;
-    for (int l = wave; l < L; l += nwaves) {
-        float e = 0.f;
-        if (l < len) {
-            for (int a = lane; a < A; a += 64) e += vv[a] * tanhf_(q[a] + PLb[(long)l * A + a]);
-            e = wave_sum(e);
-        } else {
-            e = -INFINITY;
+    for (int l0 = wave; l0 < L; l0 += 4 * nwaves) {
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int l = l0 + j * nwaves;
+            float acc = 0.f;
+            if (l < len)
+                for (int a = lane; a < A; a += 64) acc += vv[a] * tanhf_(q[a] + PLb[(long)l * A + a]);
+            e[j] = acc;
         }
-        if (lane == 0) w[l] = e;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int l = l0 + j * nwaves;
+            const float r = wave_sum(e[j]);
+            if (lane == 0 && l < L) w[l] = (l < len) ? r : -INFINITY;
+        }
     }
     __syncthreads();
 
@@ -67,25 +75,31 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_kernel(AttnStepArgs p) 
     }
     __syncthreads();
 
-    // context columns [d0, d1) of this chunk
+    // context columns [d0, d1) of this chunk: float4 columns x row groups, reduced through LDS
     {
-        const int dc = (Dm + p.nch - 1) / p.nch;
+        const int dc = (((Dm + p.nch - 1) / p.nch) + 3) & ~3;
         const int d0 = ch * dc, d1 = min(Dm, d0 + dc);
-        const int ncol = d1 - d0;
-        if (ncol > 0) {
-            const int ng = max(1, ATT_THREADS / ncol);
-            const int g = tid / ncol, col = d0 + tid % ncol;
-            float s = 0.f;
+        const int nc4 = (d1 - d0) >> 2;
+        if (nc4 > 0) {
+            const int ng = max(1, ATT_THREADS / nc4);
+            const int g = tid / nc4, c4 = tid % nc4;
+            float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (g < ng) {
-                const float* mem = p.memory + (long)b * L * Dm + col;
-                for (int l = g; l < len; l += ng) s += w[l] * mem[(long)l * Dm];
+                const float* mem = p.memory + (long)b * L * Dm + d0 + c4 * 4;
+#pragma unroll 4
+                for (int l = g; l < len; l += ng) {
+                    const float4 m4 = *reinterpret_cast<const float4*>(mem + (long)l * Dm);
+                    const float wl = w[l];
+                    s4.x += wl * m4.x; s4.y += wl * m4.y; s4.z += wl * m4.z; s4.w += wl * m4.w;
+                }
             }
-            part[tid] = s;
+            float4* part4 = reinterpret_cast<float4*>(part);
+            part4[tid] = s4;
             __syncthreads();
-            if (tid < ncol) {
-                float t = 0.f;
-                for (int k = 0; k < ng; ++k) t += part[k * ncol + tid];
-                p.ctx_out[(long)b * Dm + d0 + tid] = t;
+            if (tid < nc4) {
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int k = 0; k < ng; ++k) { const float4 v4 = part4[k * nc4 + tid]; t.x += v4.x; t.y += v4.y; t.z += v4.z; t.w += v4.w; }
+                *reinterpret_cast<float4*>(p.ctx_out + (long)b * Dm + d0 + tid * 4) = t;
             }
         }
     }
@@ -123,9 +137,9 @@ int attn_pl_init(const float* Mt, const float* bias, float* PL, long total, int 
 
 int attn_step_launch(const AttnStepArgs& p, hipStream_t s) {
     MTTS_REQUIRE((p.ksz & 1) == 1, "attention kernel size must be odd (got %d)", p.ksz);
-    const int dc = (p.Dm + p.nch - 1) / p.nch;
-    MTTS_REQUIRE(dc <= ATT_THREADS, "attn_step: Dm/nch = %d exceeds %d threads", dc, ATT_THREADS);
-    const size_t lds = sizeof(float) * (2 * p.A + 2 * p.L + p.ksz - 1 + (size_t)p.A * p.ksz + ATT_THREADS);
+    const int dc = (((p.Dm + p.nch - 1) / p.nch) + 3) & ~3;
+    MTTS_REQUIRE(dc / 4 <= ATT_THREADS && (p.Dm & 3) == 0, "attn_step: Dm/nch = %d too wide or Dm %% 4 != 0", dc);
+    const size_t lds = sizeof(float) * ((((size_t)2 * p.A + 2 * p.L + p.ksz - 1 + (size_t)p.A * p.ksz) + 3 & ~(size_t)3) + 4 * ATT_THREADS);
     MTTS_REQUIRE(lds <= 64 * 1024, "attn_step: LDS request %zu too large", lds);
     hipLaunchKernelGGL(attn_step_kernel, dim3(p.B, p.nch), dim3(ATT_THREADS), lds, s, p);
     MTTS_CHECK_LAUNCH("attn_step_kernel");

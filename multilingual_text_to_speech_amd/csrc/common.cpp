@@ -25,6 +25,9 @@ MTTS_API int mtts_sizeof_struct(int which) {
         case 4: return (int)sizeof(AttnStepArgs);
         case 5: return (int)sizeof(DecoderArgs);
         case 6: return (int)sizeof(BiLstmArgs);
+        case 7: return (int)sizeof(AttnBwdArgs);
+        case 8: return (int)sizeof(DecoderGradArgs);
+        case 9: return (int)sizeof(BiLstmGradArgs);
         default: return -1;
     }
 }

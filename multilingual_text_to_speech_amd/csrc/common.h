@@ -77,3 +77,7 @@ int copy2d(const float* in, float* out, int rows, int cols, int ldi, int ldo, hi
         int _rc = (expr);         \
         if (_rc) return _rc;      \
     } while (0)
+int transpose2d(const float* in, float* out, int rows, int cols, hipStream_t s);
+int transpose2d_ld(const float* in, float* out, int rows, int cols, int ldi, int ldo, hipStream_t s);
+int colsum(const float* x, float* out, int rows, int cols, int ld, float* ws, hipStream_t s);
+int relu_mask_bwd(const float* dy, const float* y, float* dz, long n, float scale, hipStream_t s);

@@ -114,6 +114,7 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
             q.Mt = a.Mt; q.U = a.U; q.bias = a.att_bias; q.v = a.w_energy; q.memory = a.memory; q.lengths = a.lengths;
             q.cum_in = a.cum + t * BL; q.cum_out = a.cum + (t + 1) * BL; q.w_out = a.align + t * BL;
             q.ctx_out = a.ctx + (t + 1) * BD;
+            q.q_out = a.q_all ? a.q_all + (long)t * B * A : nullptr;
             q.B = B; q.L = L; q.A = A; q.Dm = Dm; q.ksz = a.ksz;
             q.nch = (Dm + 511) / 512; if (q.nch < 4 && B * 4 <= 1024) q.nch = 4;
             MTTS_TRY(attn_step_launch(q, s));
@@ -171,6 +172,9 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
 }
 
 MTTS_API int mtts_bilstm_fwd(const BiLstmArgs* args, void* stream) {
+    // Time-major everywhere: x [L,B,Cin], xproj/gates [L,B,4H] indexed by the time step t.
+    // State arrays [L+1,B,H]: forward direction reads slot t / writes slot t+1; the reverse direction walks
+    // t = L-1..0, reads slot t+1 / writes slot t (slot L = zero initial state).
     const BiLstmArgs& a = *args;
     hipStream_t s = (hipStream_t)stream;
     const int B = a.B, L = a.L, H = a.H;
@@ -180,14 +184,15 @@ MTTS_API int mtts_bilstm_fwd(const BiLstmArgs* args, void* stream) {
         MTTS_TRY(gemm_plain(a.x, a.w_ih[d], a.xproj[d], B * L, 4 * H, a.Cin, a.Cin, a.Cin, 4 * H, false, false, 1.f, 0.f, nullptr, 0, s));
         for (int st = 0; st < L; ++st) {
             const int t = d == 0 ? st : L - 1 - st;
+            const int s_in = d == 0 ? t : t + 1, s_out = d == 0 ? t + 1 : t;
             SkinnyArgs k; memset(&k, 0, sizeof(k));
             k.B = B; k.N = 4 * H; k.ksplit = 1; k.lstm = 1; k.H = H; k.nseg = 1;
-            k.seg[0] = SkSeg{a.h[d] + st * BH, a.w_hh[d], H, H, H};
-            k.pre = a.xproj[d] + (long)t * 4 * H; k.ldpre = L * 4 * H;
+            k.seg[0] = SkSeg{a.h[d] + s_in * BH, a.w_hh[d], H, H, H};
+            k.pre = a.xproj[d] + (long)t * 4 * BH; k.ldpre = 4 * H;
             k.b_ih = a.b_ih[d]; k.b_hh = a.b_hh[d];
-            k.h_prev = a.h[d] + st * BH; k.c_prev = a.c[d] + st * BH;
-            k.h_out = a.h[d] + (st + 1) * BH; k.c_out = a.c[d] + (st + 1) * BH;
-            k.gates_out = a.gates[d] ? a.gates[d] + (long)st * 4 * BH : nullptr;
+            k.h_prev = a.h[d] + s_in * BH; k.c_prev = a.c[d] + s_in * BH;
+            k.h_out = a.h[d] + s_out * BH; k.c_out = a.c[d] + s_out * BH;
+            k.gates_out = a.gates[d] ? a.gates[d] + (long)t * 4 * BH : nullptr;
             k.lengths = a.lengths; k.t = t;
             k.y_out = a.y + (long)t * 2 * H + d * H; k.ldy = L * 2 * H;
             MTTS_TRY(skinny_launch(k, s));

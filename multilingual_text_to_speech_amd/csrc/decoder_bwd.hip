@@ -1,0 +1,203 @@
+// Back-propagation through time for the decoder loop and the encoder BiLSTM (host orchestration).
+//
+// The reference relies on autograd over 600 recorded steps (modules/tacotron2.py:180-198); here the sweep is
+// explicit.  With every step teacher forced the two recurrences decouple:
+//   chain B (generator LSTM) runs first: dh_gen_t = (batched projection part) + W_hh^T dG_{t+1}
+//   chain A (attention LSTM + attention) afterwards, fed by the batched input gradients of chain B.
+// Per step only skinny GEMMs against TRANSPOSED recurrent weights, the fused LSTM-cell backward epilogue and the
+// attention backward kernel run; every weight gradient is one large MFMA GEMM over the saved gate gradients.
+#include "common.h"
+
+static inline int round4(int x) { return (x + 3) & ~3; }
+
+static int gm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, bool tA, bool tB,
+              float beta, hipStream_t s) {
+    return gemm_plain(A, B, C, M, N, K, lda, ldb, ldc, tA, tB, 1.f, beta, nullptr, 0, s);
+}
+
+static void bwd_reg(const DecoderArgs& a, SkinnyArgs& k, const uint8_t* hmask, const uint8_t* cmask, int t) {
+    const long off = (long)t * a.B * a.H;
+    if (a.zone) { k.zone = 1; k.hmask = hmask ? hmask + off : nullptr; k.cmask = cmask ? cmask + off : nullptr; }
+    else if (a.training && hmask && a.p_hidden > 0.f) { k.zone = 0; k.hmask = hmask + off; k.hscale = 1.f / (1.f - a.p_hidden); }
+}
+
+MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* grad, void* stream) {
+    const DecoderArgs& a = *fwd;
+    const DecoderGradArgs& g = *grad;
+    hipStream_t s = (hipStream_t)stream;
+    const int B = a.B, L = a.L, T = a.T, M = a.M, P = a.P, H = a.H, A = a.A, Dm = a.Dm;
+    const int Mo = round4(M + 1), TB = T * B;
+    const long BH = (long)B * H, BD = (long)B * Dm, BL = (long)B * L, B4H = 4 * BH, BP = (long)B * P, BA = (long)B * A;
+    MTTS_REQUIRE(a.fast, "decoder backward: only the fully teacher-forced schedule is implemented (teacher forcing ratio 1.0)");
+    MTTS_REQUIRE(!a.zone, "decoder backward: zoneout regularisation is forward-only in this build");
+    MTTS_REQUIRE(a.q_all && a.gates_att && a.gates_gen, "decoder backward needs q_all and the saved gates");
+    MTTS_REQUIRE((A & 3) == 0, "attention dimension must be a multiple of 4");
+    const int ksb = g.ksb;
+
+    // ---- transposed recurrent weights
+    MTTS_TRY(transpose2d_ld(a.att_w_ih + P, g.att_w_rec_T, 4 * H, Dm, P + Dm, 4 * H, s));
+    MTTS_TRY(transpose2d(a.att_w_hh, g.att_w_rec_T + (long)Dm * 4 * H, 4 * H, H, s));
+    MTTS_TRY(transpose2d(a.gen_w_hh, g.gen_w_hh_T, 4 * H, H, s));
+    MTTS_TRY(transpose2d(a.w_query, g.w_query_T, A, H, s));
+
+    const float* dout1 = g.dout + (long)B * Mo;      // slot 1 = step 0
+    // ---- projection backward (batched): dHG = dout W_out[:, :H],  dctx_all[1:] = dout W_out[:, H:]
+    MTTS_TRY(gm(dout1, a.w_out, g.dHG, TB, H, M + 1, Mo, H + Dm, H, false, true, 0.f, s));
+    MTTS_TRY(gm(dout1, a.w_out + H, g.dctx_all + BD, TB, Dm, M + 1, Mo, H + Dm, Dm, false, true, 0.f, s));
+
+    // ---- chain B: generator LSTM, t = T-1 .. 0
+    for (int t = T - 1; t >= 0; --t) {
+        SkinnyArgs k; memset(&k, 0, sizeof(k));
+        k.B = B; k.H = H; k.lstm = 2; k.nseg = 0; k.ksplit = 1;
+        k.dh_a = g.dHG + t * BH; k.ld_dh_a = H;
+        if (t < T - 1) { k.part = g.part_gen; k.n_part = ksb; k.part_ks = BH; k.part_ld = H; k.part_col0 = 0; }
+        k.gates = a.gates_gen + t * B4H; k.c_prev = a.c_gen + t * BH;
+        k.dc_in = g.dc_gen + ((t + 1) & 1) * BH; k.dc_out = g.dc_gen + (t & 1) * BH;
+        k.dgates_out = g.dG_gen + t * B4H; k.ld_dgates = 4 * H;
+        bwd_reg(a, k, a.gen_hmask, a.gen_cmask, t);
+        MTTS_TRY(skinny_launch(k, s));
+        if (t > 0) {
+            SkinnyArgs q; memset(&q, 0, sizeof(q));
+            q.nseg = 1; q.B = B; q.N = H; q.ksplit = ksb;
+            q.seg[0] = SkSeg{g.dG_gen + t * B4H, g.gen_w_hh_T, 4 * H, 4 * H, 4 * H};
+            q.out = g.part_gen; q.ldo = H; q.out_ks = BH;
+            MTTS_TRY(skinny_launch(q, s));
+        }
+    }
+    // ---- input gradients of the generator LSTM (batched): dHA = dG_gen W_ih[:, :H];  dctx_all[1:] += dG_gen W_ih[:, H:]
+    MTTS_TRY(gm(g.dG_gen, a.gen_w_ih, g.dHA, TB, H, 4 * H, 4 * H, H + Dm, H, false, true, 0.f, s));
+    MTTS_TRY(gm(g.dG_gen, a.gen_w_ih + H, g.dctx_all + BD, TB, Dm, 4 * H, 4 * H, H + Dm, Dm, false, true, 1.f, s));
+
+    // ---- chain A: attention + attention LSTM, t = T-1 .. 0
+    for (int t = T - 1; t >= 0; --t) {
+        {
+            AttnBwdArgs q; memset(&q, 0, sizeof(q));
+            q.q = a.q_all + t * BA; q.Mt = a.Mt; q.U = a.U; q.bias = a.att_bias; q.v = a.w_energy; q.memory = a.memory;
+            q.ctx = a.ctx + (t + 1) * BD; q.lengths = a.lengths; q.w = a.align + t * BL; q.cum_in = a.cum + t * BL;
+            q.dalign = g.dalign ? g.dalign + t * BL : nullptr;
+            q.dcum_out = g.dcum_all + (t + 1) * BL; q.dcum_in = g.dcum_all + t * BL;
+            q.dctx = g.dctx_all + (t + 1) * BD; q.dctx_total = g.dctx_tot + (t + 1) * BD;
+            if (t < T - 1) { q.part = g.part_att; q.n_part = ksb; q.part_ks = (long)B * (Dm + H); q.part_ld = Dm + H; }
+            q.dq = g.dq_all + t * BA; q.dMt = g.dMt; q.dU_slab = g.dU_slab; q.dv_slab = g.dv_slab; q.dbias_slab = g.dbias_slab;
+            q.B = B; q.L = L; q.A = A; q.Dm = Dm; q.ksz = a.ksz; q.nch = g.nch;
+            MTTS_TRY(mtts_attn_step_bwd(&q, s));
+        }
+        {   // dh_att_t = dq W_q + dHA[t] + (recurrent part of step t+1) -> cell backward
+            SkinnyArgs k; memset(&k, 0, sizeof(k));
+            k.B = B; k.H = H; k.lstm = 2; k.nseg = 1; k.ksplit = 1;
+            k.seg[0] = SkSeg{g.dq_all + t * BA, g.w_query_T, A, A, A};
+            k.dh_a = g.dHA + t * BH; k.ld_dh_a = H;
+            if (t < T - 1) { k.part = g.part_att; k.n_part = ksb; k.part_ks = (long)B * (Dm + H); k.part_ld = Dm + H; k.part_col0 = Dm; }
+            k.gates = a.gates_att + t * B4H; k.c_prev = a.c_att + t * BH;
+            k.dc_in = g.dc_att + ((t + 1) & 1) * BH; k.dc_out = g.dc_att + (t & 1) * BH;
+            k.dgates_out = g.dG_att + t * B4H; k.ld_dgates = 4 * H;
+            bwd_reg(a, k, a.att_hmask, a.att_cmask, t);
+            MTTS_TRY(skinny_launch(k, s));
+        }
+        if (t > 0) {   // d[ctx_{t-1}, h_att_{t-1}] = dG_att_t [W_ih[:, P:] | W_hh]
+            SkinnyArgs q; memset(&q, 0, sizeof(q));
+            q.nseg = 1; q.B = B; q.N = Dm + H; q.ksplit = ksb;
+            q.seg[0] = SkSeg{g.dG_att + t * B4H, g.att_w_rec_T, 4 * H, 4 * H, 4 * H};
+            q.out = g.part_att; q.ldo = Dm + H; q.out_ks = (long)B * (Dm + H);
+            MTTS_TRY(skinny_launch(q, s));
+        }
+    }
+
+    // ---- prenet backward (batched over all frames)
+    const int n = a.n_prenet;
+    const float pscale = a.p_prenet > 0.f ? 1.f / (1.f - a.p_prenet) : 1.f;
+    float* dp_last = g.dpren + (long)(n - 1) * T * BP;
+    MTTS_TRY(gm(g.dG_att, a.att_w_ih, dp_last, TB, P, 4 * H, 4 * H, P + Dm, P, false, true, 0.f, s));
+    for (int i = n - 1; i >= 0; --i) {
+        float* dz = g.dpren + (long)i * T * BP;
+        MTTS_TRY(relu_mask_bwd(dz, a.prenet_act[i], dz, (long)T * BP, a.prenet_mask[i] ? pscale : 1.f, s));
+        const float* xin = i == 0 ? a.frames_in : a.prenet_act[i - 1];
+        const int Kin = i == 0 ? M : P;
+        MTTS_TRY(gm(dz, xin, g.d_prenet_w[i], P, Kin, TB, P, Kin, Kin, true, true, 0.f, s));
+        MTTS_TRY(colsum(dz, g.d_prenet_b[i], TB, P, P, g.colsum_ws, s));
+        if (i > 0) MTTS_TRY(gm(dz, a.prenet_w[i], g.dpren + (long)(i - 1) * T * BP, TB, P, P, P, P, P, false, true, 0.f, s));
+    }
+    const float* pren = a.prenet_act[n - 1];
+
+    // ---- LSTM weight gradients
+    MTTS_TRY(gm(g.dG_att, pren, g.d_att_w_ih, 4 * H, P, TB, 4 * H, P, P + Dm, true, true, 0.f, s));
+    MTTS_TRY(gm(g.dG_att, a.ctx, g.d_att_w_ih + P, 4 * H, Dm, TB, 4 * H, Dm, P + Dm, true, true, 0.f, s));
+    MTTS_TRY(gm(g.dG_att, a.h_att, g.d_att_w_hh, 4 * H, H, TB, 4 * H, H, H, true, true, 0.f, s));
+    MTTS_TRY(colsum(g.dG_att, g.d_att_b_ih, TB, 4 * H, 4 * H, g.colsum_ws, s));
+    MTTS_TRY(colsum(g.dG_att, g.d_att_b_hh, TB, 4 * H, 4 * H, g.colsum_ws, s));
+    MTTS_TRY(gm(g.dG_gen, a.h_att + BH, g.d_gen_w_ih, 4 * H, H, TB, 4 * H, H, H + Dm, true, true, 0.f, s));
+    MTTS_TRY(gm(g.dG_gen, a.ctx + BD, g.d_gen_w_ih + H, 4 * H, Dm, TB, 4 * H, Dm, H + Dm, true, true, 0.f, s));
+    MTTS_TRY(gm(g.dG_gen, a.h_gen, g.d_gen_w_hh, 4 * H, H, TB, 4 * H, H, H, true, true, 0.f, s));
+    MTTS_TRY(colsum(g.dG_gen, g.d_gen_b_ih, TB, 4 * H, 4 * H, g.colsum_ws, s));
+    MTTS_TRY(colsum(g.dG_gen, g.d_gen_b_hh, TB, 4 * H, 4 * H, g.colsum_ws, s));
+
+    // ---- frame/stop projection and query weights
+    MTTS_TRY(gm(dout1, a.h_gen + BH, g.d_w_out, M + 1, H, TB, Mo, H, H + Dm, true, true, 0.f, s));
+    MTTS_TRY(gm(dout1, a.ctx + BD, g.d_w_out + H, M + 1, Dm, TB, Mo, Dm, H + Dm, true, true, 0.f, s));
+    MTTS_TRY(colsum(dout1, g.d_b_out, TB, M + 1, Mo, g.colsum_ws, s));
+    MTTS_TRY(gm(g.dq_all, a.h_att + BH, g.d_w_query, A, H, TB, A, H, H, true, true, 0.f, s));
+
+    // ---- memory gradient: context path (per-sample align^T dctx), memory-transform path, and W_memory
+    {
+        GemmArgs q; memset(&q, 0, sizeof(q));
+        q.A = a.align; q.B = g.dctx_tot + BD; q.C = g.dmemory;
+        q.M = L; q.N = Dm; q.K = T; q.lda = B * L; q.ldb = B * Dm; q.ldc = Dm;
+        q.transA = 1; q.transB = 1; q.taps = 1; q.Kc = T; q.batch = B; q.zt = 1;
+        q.a_z = L; q.b_z = Dm; q.c_z = (long)L * Dm; q.alpha = 1.f; q.mask_scale = 1.f;
+        MTTS_TRY(mtts_gemm_ex(&q, s));
+    }
+    MTTS_TRY(gm(g.dMt, a.w_memory, g.dmemory, B * L, Dm, A, A, Dm, Dm, false, true, 1.f, s));
+    MTTS_TRY(gm(g.dMt, a.memory, g.d_w_memory, A, Dm, B * L, A, Dm, Dm, true, true, 0.f, s));
+
+    // ---- small attention parameters from the per-workgroup slabs
+    const int nslab = B * g.nch;
+    MTTS_TRY(colsum(g.dU_slab, g.dU, nslab, A * a.ksz, A * a.ksz, g.colsum_ws, s));
+    MTTS_TRY(gm(g.dU, a.w_conv, g.d_w_loc, A, a.C, a.ksz, a.ksz, a.ksz, a.C, false, false, 0.f, s));
+    MTTS_TRY(gm(a.w_loc, g.dU, g.d_w_conv, a.C, a.ksz, A, a.C, a.ksz, a.ksz, true, true, 0.f, s));
+    MTTS_TRY(colsum(g.dv_slab, g.d_w_energy, nslab, A, A, g.colsum_ws, s));
+    MTTS_TRY(colsum(g.dbias_slab, g.d_att_bias, nslab, A, A, g.colsum_ws, s));
+    return 0;
+}
+
+MTTS_API int mtts_bilstm_bwd(const BiLstmArgs* fwd, const BiLstmGradArgs* grad, void* stream) {
+    const BiLstmArgs& a = *fwd;
+    const BiLstmGradArgs& g = *grad;
+    hipStream_t s = (hipStream_t)stream;
+    const int B = a.B, L = a.L, H = a.H, Cin = a.Cin;
+    const long BH = (long)B * H, B4H = 4 * BH;
+    for (int d = 0; d < 2; ++d) {
+        MTTS_REQUIRE(a.gates[d], "bilstm backward needs the saved gates");
+        MTTS_TRY(transpose2d(a.w_hh[d], g.w_hh_T[d], 4 * H, H, s));
+        MTTS_CHECK_HIP(hipMemsetAsync(g.dc, 0, 2 * BH * sizeof(float), s));
+        MTTS_CHECK_HIP(hipMemsetAsync(g.dh_carry, 0, 2 * BH * sizeof(float), s));
+        for (int st = L - 1; st >= 0; --st) {      // reverse of the forward processing order
+            const int t = d == 0 ? st : L - 1 - st;
+            const int s_in = d == 0 ? t : t + 1;
+            SkinnyArgs k; memset(&k, 0, sizeof(k));
+            k.B = B; k.H = H; k.lstm = 2; k.nseg = 0; k.ksplit = 1;
+            k.dh_a = g.dy + (long)t * 2 * H + d * H; k.ld_dh_a = L * 2 * H;
+            k.dh_b = g.dh_carry + ((st + 1) & 1) * BH; k.dh_carry_out = g.dh_carry + (st & 1) * BH;
+            if (st < L - 1) { k.part = g.part; k.n_part = g.ksb; k.part_ks = BH; k.part_ld = H; k.part_col0 = 0; }
+            k.gates = a.gates[d] + (long)t * B4H; k.c_prev = a.c[d] + s_in * BH;
+            k.dc_in = g.dc + ((st + 1) & 1) * BH; k.dc_out = g.dc + (st & 1) * BH;
+            k.lengths = a.lengths; k.t = t;
+            k.dgates_out = g.dxproj[d] + (long)t * B4H; k.ld_dgates = 4 * H;
+            MTTS_TRY(skinny_launch(k, s));
+            if (st > 0) {
+                SkinnyArgs q; memset(&q, 0, sizeof(q));
+                q.nseg = 1; q.B = B; q.N = H; q.ksplit = g.ksb;
+                q.seg[0] = SkSeg{g.dxproj[d] + (long)t * B4H, g.w_hh_T[d], 4 * H, 4 * H, 4 * H};
+                q.out = g.part; q.ldo = H; q.out_ks = BH;
+                MTTS_TRY(skinny_launch(q, s));
+            }
+        }
+        // dx (+)= dG W_ih ; dW_ih = dG^T x ; dW_hh = dG^T h_prev ; biases
+        MTTS_TRY(gm(g.dxproj[d], a.w_ih[d], g.dx, L * B, Cin, 4 * H, 4 * H, Cin, Cin, false, true, d == 0 ? 0.f : 1.f, s));
+        MTTS_TRY(gm(g.dxproj[d], a.x, g.d_w_ih[d], 4 * H, Cin, L * B, 4 * H, Cin, Cin, true, true, 0.f, s));
+        const float* hprev = d == 0 ? a.h[d] : a.h[d] + BH;
+        MTTS_TRY(gm(g.dxproj[d], hprev, g.d_w_hh[d], 4 * H, H, L * B, 4 * H, H, H, true, true, 0.f, s));
+        MTTS_TRY(colsum(g.dxproj[d], g.d_b_ih[d], L * B, 4 * H, 4 * H, g.colsum_ws, s));
+        MTTS_TRY(colsum(g.dxproj[d], g.d_b_hh[d], L * B, 4 * H, 4 * H, g.colsum_ws, s));
+    }
+    return 0;
+}

@@ -145,9 +145,9 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs p) {
     const float* bias = p.bias ? p.bias + (long)zb * p.bias_z : nullptr;
     const int shift_z = p.shift0 + ztap * p.dshift;
 
-    const bool vecA = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((p.Kc & 3) == 0) &&
+    const bool vecA = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (p.shift_mode == 0 || (p.Kc & 3) == 0) &&
                       ((p.a_z & 3) == 0);
-    const bool vecB = ((p.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && ((p.Kc & 3) == 0) &&
+    const bool vecB = ((p.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (p.shift_mode == 0 || (p.Kc & 3) == 0) &&
                       ((p.b_z & 3) == 0) && ((p.b_tap & 3) == 0);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -88,3 +88,86 @@ MTTS_API int mtts_grad_reverse_clamp(const float* g, float* out, long n, float l
     MTTS_CHECK_LAUNCH("grad_reverse");
     return 0;
 }
+
+// out[c*rows + r] = in[r*cols + c], LDS-tiled 32x32
+__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols, int ldi, int ldo) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + threadIdx.x;
+        if (r < rows && c < cols) tile[i][threadIdx.x] = in[(long)r * ldi + c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + threadIdx.x;
+        if (r < rows && c < cols) out[(long)c * ldo + r] = tile[threadIdx.x][i];
+    }
+}
+
+int transpose2d_ld(const float* in, float* out, int rows, int cols, int ldi, int ldo, hipStream_t s) {
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(32, 8), 0, s, in, out, rows, cols, ldi, ldo);
+    MTTS_CHECK_LAUNCH("transpose");
+    return 0;
+}
+
+int transpose2d(const float* in, float* out, int rows, int cols, hipStream_t s) {
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(32, 8), 0, s, in, out, rows, cols, cols, rows);
+    MTTS_CHECK_LAUNCH("transpose");
+    return 0;
+}
+
+MTTS_API int mtts_transpose(const float* in, float* out, int rows, int cols, void* stream) {
+    return transpose2d(in, out, rows, cols, (hipStream_t)stream);
+}
+
+// column sums, two deterministic stages: partials [chunks, cols] then final
+constexpr int CS_CHUNKS = 64;
+__global__ void colsum_part_kernel(const float* __restrict__ x, float* __restrict__ ws, int rows, int cols, int ld) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    const int nch = gridDim.y;
+    const int per = (rows + nch - 1) / nch;
+    const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+    float s = 0.f;
+    if (c < cols)
+        for (int r = r0 + threadIdx.y; r < r1; r += 4) s += x[(long)r * ld + c];
+    red[threadIdx.y][threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.y == 0 && c < cols) ws[(long)blockIdx.y * cols + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ void colsum_final_kernel(const float* __restrict__ ws, float* __restrict__ out, int cols, int nch) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < nch; ++k) s += ws[(long)k * cols + c];
+    out[c] = s;
+}
+
+int colsum(const float* x, float* out, int rows, int cols, int ld, float* ws, hipStream_t s) {
+    int nch = cdiv(rows, 256); nch = nch < 1 ? 1 : (nch > CS_CHUNKS ? CS_CHUNKS : nch);
+    hipLaunchKernelGGL(colsum_part_kernel, dim3(cdiv(cols, 64), nch), dim3(64, 4), 0, s, x, ws, rows, cols, ld);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, s, ws, out, cols, nch);
+    MTTS_CHECK_LAUNCH("colsum");
+    return 0;
+}
+
+MTTS_API long mtts_colsum_workspace_floats(int cols) { return (long)CS_CHUNKS * cols; }
+MTTS_API int mtts_colsum(const float* x, float* out, int rows, int cols, int ld, float* ws, void* stream) {
+    return colsum(x, out, rows, cols, ld, ws, (hipStream_t)stream);
+}
+
+__global__ void relu_mask_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dz, long n, float scale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dz[i] = y[i] > 0.f ? dy[i] * scale : 0.f;
+}
+
+int relu_mask_bwd(const float* dy, const float* y, float* dz, long n, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(relu_mask_bwd_kernel, dim3(nblocks(n)), dim3(256), 0, s, dy, y, dz, n, scale);
+    MTTS_CHECK_LAUNCH("relu_mask_bwd");
+    return 0;
+}
+
+MTTS_API int mtts_relu_mask_bwd(const float* dy, const float* y, float* dz, long n, float scale, void* stream) {
+    return relu_mask_bwd(dy, y, dz, n, scale, (hipStream_t)stream);
+}

@@ -35,6 +35,7 @@ class DecoderState:
         self.out = z(T + 1, B, self.Mo)
         self.pre_att = e(T, B, 4 * H) if fast else None
         self.pre_gen = e(T, B, 4 * H) if fast else None
+        self.q_all = e(T, B, A) if save_gates else None
 
 
 def fill_decoder_args(a, st, w, memory, lengths32, frames_in, teacher_host, masks, cfg):
@@ -57,7 +58,7 @@ def fill_decoder_args(a, st, w, memory, lengths32, frames_in, teacher_host, mask
     a.att_hmask, a.att_cmask = ptr(masks.get('att_h')), ptr(masks.get('att_c'))
     a.gen_hmask, a.gen_cmask = ptr(masks.get('gen_h')), ptr(masks.get('gen_c'))
     for name in ('U', 'Mt', 'PL', 'qpart', 'h_att', 'c_att', 'h_gen', 'c_gen', 'ctx', 'cum', 'align', 'gates_att', 'gates_gen',
-                 'out', 'pre_att', 'pre_gen'):
+                 'out', 'pre_att', 'pre_gen', 'q_all'):
         setattr(a, name, ptr(getattr(st, name)))
     a.kq, a.fast = st.kq, int(st.fast)
     return a

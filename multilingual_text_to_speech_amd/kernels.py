@@ -253,20 +253,22 @@ def conv_bn_act(x, weight, gamma, beta, rmean, rvar, mask, *, kernel, dilation=1
 # ------------------------------------------------------------------------------------------------
 
 class BiLstmFn(torch.autograd.Function):
+    """Bidirectional LSTM with packed-sequence semantics (reference modules/encoder.py:41-44); x [B, L, C]."""
+
     @staticmethod
     def forward(ctx, x, lengths, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
         require_gpu(x, w_ih)
-        x = x.contiguous()
         B, L, Cin = x.shape
+        x_tm = x.transpose(0, 1).contiguous()            # time-major [L, B, C]
         H = w_hh.shape[1]
         dev = x.device
         a = _C.BiLstmArgs()
         a.B, a.L, a.Cin, a.H = B, L, Cin, H
         lengths32 = lengths.to(device=dev, dtype=torch.int32).contiguous()
-        a.x, a.lengths = ptr(x), ptr(lengths32)
+        a.x, a.lengths = ptr(x_tm), ptr(lengths32)
         ws = [(w_ih.contiguous(), w_hh.contiguous(), b_ih.contiguous(), b_hh.contiguous()),
               (w_ih_r.contiguous(), w_hh_r.contiguous(), b_ih_r.contiguous(), b_hh_r.contiguous())]
-        xproj = [_f32(B, L, 4 * H, device=dev) for _ in range(2)]
+        xproj = [_f32(L, B, 4 * H, device=dev) for _ in range(2)]
         h = [torch.zeros(L + 1, B, H, device=dev) for _ in range(2)]
         c = [torch.zeros(L + 1, B, H, device=dev) for _ in range(2)]
         gates = [_f32(L, B, 4 * H, device=dev) for _ in range(2)]
@@ -276,7 +278,7 @@ class BiLstmFn(torch.autograd.Function):
             a.xproj[d], a.h[d], a.c[d], a.gates[d] = xproj[d].data_ptr(), h[d].data_ptr(), c[d].data_ptr(), gates[d].data_ptr()
         a.y = ptr(y)
         check(lib().mtts_bilstm_fwd(ctypes.byref(a), stream_ptr()), 'bilstm_fwd')
-        ctx.save_for_backward(x, lengths32, *ws[0], *ws[1], *h, *c, *gates)
+        ctx.save_for_backward(x_tm, lengths32, *ws[0], *ws[1], *h, *c, *gates)
         return y
 
     @staticmethod
@@ -294,5 +296,6 @@ def grad_reverse_clamp(g, l, c):
     require_gpu(g)
     g = g.contiguous()
     out = torch.empty_like(g)
-    check(lib().mtts_grad_reverse_clamp(ptr(g), ptr(out), g.numel(), float(l), float(c), stream_ptr()), 'grad_reverse_clamp')
+    check(lib().mtts_grad_reverse_clamp(ptr(g), ptr(out), ctypes.c_long(g.numel()), ctypes.c_float(l), ctypes.c_float(c),
+                                        stream_ptr()), 'grad_reverse_clamp')
     return out

@@ -1,0 +1,15 @@
+cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof_sk -o sk -- python /root/repo/scripts/bench_skinny.py > /dev/null 2>&1
+python - <<'PY'
+import sqlite3
+db = sqlite3.connect('gpurun_out/prof_sk/sk_results.db'); cur = db.cursor()
+tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+kd = [t for t in tabs if t.startswith('rocpd_kernel_dispatch')][0]
+ks = [t for t in tabs if t.startswith('rocpd_info_kernel_symbol')][0]
+rows = list(cur.execute(f"select s.kernel_name, d.grid_size_x, d.grid_size_y, d.grid_size_z, d.start, d.end from {kd} d join {ks} s on d.kernel_id=s.id where s.kernel_name like '%skinny%' order by d.start"))
+import itertools
+i = 0
+for key, grp in itertools.groupby(rows, key=lambda r: r[:4]):
+    g = list(grp); durs = sorted((r[5]-r[4])/1e3 for r in g)
+    gaps = sorted((g[j+1][4]-g[j][5])/1e3 for j in range(len(g)-1))
+    print(key[0][:28], key[1:4], 'n=%d med %.2f us min %.2f | gap med %.2f' % (len(g), durs[len(durs)//2], durs[0], gaps[len(gaps)//2] if gaps else 0))
+PY

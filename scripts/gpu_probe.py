@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from tests.helpers import build_hip_model, golden_names, hip_forward, load_golden
 for name in golden_names('train'):
     fx = load_golden(name)
