@@ -438,6 +438,12 @@ int mtts_relu_mask_bwd(const float* dy, const float* y, float* dz, long n, float
 /* Gradient reversal backward (modules/classifier.py:16-18): out = clamp(g, -c, c) * (-l) */
 int mtts_grad_reverse_clamp(const float* g, float* out, long n, float l, float c, void* stream);
 
+/* Sampling of the dominant step kernel (attention-LSTM skinny GEMM) with HIP events on the launch stream:
+ * begin() creates `max_samples` event pairs and samples every `stride`-th decoder step; end() synchronises
+ * them and returns the summed duration in ms and the sample count.  Not for use inside timed regions' setup. */
+int mtts_prof_begin(int max_samples, int stride);
+int mtts_prof_end(float* total_ms, int* count);
+
 const char* mtts_last_error(void);
 int mtts_version(void);
 /* sizeof() of the structs above in declaration order (0 = GemmArgs ... 6 = BiLstmArgs, 7 = AttnBwdArgs, 8 = DecoderGradArgs, 9 = BiLstmGradArgs); -1 when out of range */

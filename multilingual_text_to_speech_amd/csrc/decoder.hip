@@ -98,7 +98,9 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
             k.h_out = a.h_att + (t + 1) * BH; k.c_out = a.c_att + (t + 1) * BH;
             k.gates_out = a.gates_att ? a.gates_att + t * B4H : nullptr;
             lstm_reg(a, k, a.att_hmask, a.att_cmask, t);
+            const bool sampled = prof_sample(t, s, 0);
             MTTS_TRY(skinny_launch(k, s));
+            if (sampled) prof_sample(t, s, 1);
         }
         {   // query projection partials (attention.py:68)
             SkinnyArgs k; memset(&k, 0, sizeof(k));

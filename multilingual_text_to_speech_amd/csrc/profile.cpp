@@ -1,0 +1,55 @@
+// Optional in-library sampling of the dominant step kernel with HIP events (used by bench.py for the roofline
+// line).  Events are created by mtts_prof_begin() OUTSIDE the timed launches; recording is a no-op otherwise.
+#include "common.h"
+#include <vector>
+
+namespace {
+struct Prof {
+    bool on = false;
+    int stride = 1, used = 0;
+    std::vector<hipEvent_t> e0, e1;
+} g_prof;
+}
+
+bool prof_sample(int t, hipStream_t s, int phase) {
+    // phase 0: before the kernel, 1: after.  Returns true when this step is being sampled.
+    if (!g_prof.on || (t % g_prof.stride) != 0) return false;
+    if (phase == 0) {
+        if (g_prof.used >= (int)g_prof.e0.size()) return false;
+        hipEventRecord(g_prof.e0[g_prof.used], s);
+        return true;
+    }
+    hipEventRecord(g_prof.e1[g_prof.used], s);
+    g_prof.used++;
+    return true;
+}
+
+MTTS_API int mtts_prof_begin(int max_samples, int stride) {
+    for (auto e : g_prof.e0) hipEventDestroy(e);
+    for (auto e : g_prof.e1) hipEventDestroy(e);
+    g_prof.e0.assign(max_samples, nullptr);
+    g_prof.e1.assign(max_samples, nullptr);
+    for (int i = 0; i < max_samples; ++i) {
+        MTTS_CHECK_HIP(hipEventCreate(&g_prof.e0[i]));
+        MTTS_CHECK_HIP(hipEventCreate(&g_prof.e1[i]));
+    }
+    g_prof.stride = stride < 1 ? 1 : stride;
+    g_prof.used = 0;
+    g_prof.on = true;
+    return 0;
+}
+
+// Synchronises the recorded events; returns the number of samples and their summed duration (ms).
+MTTS_API int mtts_prof_end(float* total_ms, int* count) {
+    g_prof.on = false;
+    float tot = 0.f;
+    for (int i = 0; i < g_prof.used; ++i) {
+        float ms = 0.f;
+        MTTS_CHECK_HIP(hipEventSynchronize(g_prof.e1[i]));
+        MTTS_CHECK_HIP(hipEventElapsedTime(&ms, g_prof.e0[i], g_prof.e1[i]));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *count = g_prof.used;
+    return 0;
+}

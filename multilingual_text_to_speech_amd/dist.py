@@ -1,0 +1,95 @@
+"""Data-parallel training across the GPUs of one node: one process per GPU, RCCL (torch.distributed backend
+"nccl" on ROCm) gradient all-reduce over xGMI.
+
+Replaces the reference's single-process torch.nn.DataParallel (train.py:173-179,255-256): no per-step parameter
+broadcast and no output gather - every rank owns a full replica, computes its local loss and the gradients are
+summed bucket by bucket.  BatchNorm statistics stay per rank, which is what DataParallel does per replica.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init(backend=None):
+    """Initialise the default process group from the torchrun environment (RANK/WORLD_SIZE/LOCAL_RANK)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    return rank, world, local
+
+
+def shard_bounds(global_batch, rank, world, groups=1):
+    """Contiguous shard [lo, hi) of the global batch for `rank` (what DataParallel.scatter does on dim 0).
+    Grouped encoders need whole language groups per shard: sample i belongs to language i mod G
+    (reference utils/samplers.py:70-73, modules/encoder.py:206-208)."""
+    if global_batch % (groups * world) != 0:
+        raise ValueError(f'global batch {global_batch} must be divisible by languages*ranks = {groups}*{world}')
+    per = global_batch // world
+    return rank * per, (rank + 1) * per
+
+
+class GradientBuckets:
+    """Flat fp32 buckets over the parameters (reverse registration order ~ backward order); all-reduce (sum) each
+    bucket and scale by 1/world so that the result equals the gradient of the global-batch mean loss.
+
+    Bucket size is chosen for xGMI's point-to-point links: a few large collectives (default 64 MiB) rather than
+    per-tensor launches."""
+
+    def __init__(self, params, bucket_bytes=64 << 20):
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets = []
+        cur, cur_n = [], 0
+        for p in reversed(self.params):
+            cur.append(p)
+            cur_n += p.numel()
+            if cur_n * 4 >= bucket_bytes:
+                self.buckets.append(cur)
+                cur, cur_n = [], 0
+        if cur:
+            self.buckets.append(cur)
+        self.flat = [None] * len(self.buckets)
+
+    def all_reduce(self, world=None, async_op=True):
+        if not dist.is_initialized():
+            return
+        world = world or dist.get_world_size()
+        if world == 1:
+            return
+        works = []
+        for i, bucket in enumerate(self.buckets):
+            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket]
+            flat = torch.cat([g.reshape(-1) for g in grads])
+            self.flat[i] = flat
+            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op))
+        for i, bucket in enumerate(self.buckets):
+            if async_op:
+                works[i].wait()
+            flat = self.flat[i]
+            flat.mul_(1.0 / world)
+            off = 0
+            for p in bucket:
+                n = p.numel()
+                if p.grad is None:
+                    p.grad = flat[off:off + n].view_as(p).clone()
+                else:
+                    p.grad.copy_(flat[off:off + n].view_as(p))
+                off += n
+
+
+def broadcast_parameters(module, src=0):
+    """Make every rank start from rank `src`'s weights and buffers (one-time, replaces DataParallel's per-step replicate)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src)
