@@ -14,6 +14,7 @@
 #ifndef MTTS_H
 #define MTTS_H
 #include <stdint.h>
+#include <stddef.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -65,6 +66,8 @@ typedef struct GemmArgs {
 } GemmArgs;
 
 int mtts_gemm_ex(const GemmArgs* args, void* stream);
+/* Scratch arena for split-K partial tiles, provided by the caller (the library never allocates); NULL disables split-K. */
+int mtts_set_workspace(void* ptr, size_t bytes);
 int mtts_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
               int transA, int transB, float alpha, float beta, const float* bias, int act, void* stream);
 

@@ -6,76 +6,230 @@
 // produce PL for step t+1 (31-tap filter bank U = W_loc * W_conv over the LDS-staged cum window).
 // Grid (B, nch): every workgroup of a sample recomputes the (cheap) energies/softmax so that the context
 // columns and the PL_next rows of that sample can be split over nch CUs without a second launch.
+//
+// The step is latency bound (a few hundred KB per sample behind ~1-2 us memory round trips), so the fast
+// kernel requests EVERYTHING it will need - query partials, PL, cumulative alignment, its memory columns,
+// its rows of the memory transform, the filter bank - in one burst at entry (none of those addresses
+// depends on computed data) and only then starts the dependent phases.  A generic kernel without the
+// register-resident prefetch covers shapes outside the fast kernel's static bounds.
 #include "common.h"
 
 constexpr int ATT_THREADS = 512;
+constexpr int NE_MAX = 32;    // PL elements per thread     (L*A      <= NE_MAX * ATT_THREADS)
+constexpr int NC_MAX = 8;     // memory float4 per thread   (ceil(L/ng) <= NC_MAX)
+constexpr int NM_MAX = 8;     // Mt elements per thread     (rows*A   <= NM_MAX * ATT_THREADS)
+constexpr int NU_MAX = 8;     // U elements per thread      (A*ksz    <= NU_MAX * ATT_THREADS)
+constexpr int KQ_MAX = 8;
 
+struct AttLds {
+    float *q, *vv, *bias, *w, *cumw, *Us, *part;
+};
+
+__device__ __forceinline__ AttLds att_carve(float* sm, int A, int L, int ksz) {
+    AttLds s;
+    s.q = sm; s.vv = s.q + A; s.bias = s.vv + A; s.w = s.bias + A; s.cumw = s.w + L; s.Us = s.cumw + L + ksz - 1;
+    s.part = sm + (((3 * A + 2 * L + ksz - 1 + A * ksz) + 3) & ~3);
+    return s;
+}
+static inline size_t att_lds_bytes(int A, int L, int ksz) {
+    return sizeof(float) * ((((size_t)3 * A + 2 * L + ksz - 1 + (size_t)A * ksz + 3) & ~(size_t)3) + 4 * ATT_THREADS);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// fast kernel: all global loads up front
+// ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(ATT_THREADS) void attn_step_kernel(AttnStepArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.x, ch = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int L = p.L, A = p.A, Dm = p.Dm, ksz = p.ksz, pad = (ksz - 1) / 2;
+    const AttLds s = att_carve(sm, A, L, ksz);
+    const int LA = L * A;
+
+    // ---- geometry of this workgroup's shares
+    const int dc = (((Dm + p.nch - 1) / p.nch) + 3) & ~3;
+    const int d0 = ch * dc, d1 = min(Dm, d0 + dc);
+    const int nc4 = max(0, (d1 - d0) >> 2);
+    const int ng = nc4 > 0 ? max(1, ATT_THREADS / nc4) : 1;
+    const int cg = nc4 > 0 ? tid / nc4 : ng, c4 = nc4 > 0 ? tid % nc4 : 0;
+    const int lc = (L + p.nch - 1) / p.nch;
+    const int l0 = ch * lc, l1 = min(L, l0 + lc);
+    const int nlA = max(0, l1 - l0) * A;
+
+    // ---- burst of independent loads
+    const int len = min(p.lengths[b], L);
+    float qp[KQ_MAX];
+    {
+        const int a = min(tid, A - 1);
+#pragma unroll
+        for (int k = 0; k < KQ_MAX; ++k) qp[k] = (k < p.kq) ? p.qpart[(long)k * p.q_ks + (long)b * A + a] : 0.f;
+    }
+    const float v_r = p.v[min(tid, A - 1)];
+    const float bias_r = p.bias[min(tid, A - 1)];
+    const float cum_r = p.cum_in[(long)b * L + min(tid, L - 1)];
+    float pl[NE_MAX];
+    {
+        const float* PLb = p.PL + (long)b * LA;
+#pragma unroll
+        for (int j = 0; j < NE_MAX; ++j) pl[j] = PLb[min(tid + j * ATT_THREADS, LA - 1)];
+    }
+    float4 mem4[NC_MAX];
+    {
+        const float* mem = p.memory + (long)b * L * Dm + d0 + c4 * 4;
+#pragma unroll
+        for (int j = 0; j < NC_MAX; ++j) {
+            const int l = min(cg + j * ng, L - 1);
+            mem4[j] = (nc4 > 0) ? *reinterpret_cast<const float4*>(mem + (long)l * Dm) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    float mt[NM_MAX], us[NU_MAX];
+    if (p.PL_next) {
+        const float* Mb = p.Mt + ((long)b * L + l0) * A;
+#pragma unroll
+        for (int j = 0; j < NM_MAX; ++j) mt[j] = Mb[min(tid + j * ATT_THREADS, max(nlA - 1, 0))];
+#pragma unroll
+        for (int j = 0; j < NU_MAX; ++j) us[j] = p.U[min(tid + j * ATT_THREADS, A * ksz - 1)];
+    }
+
+    // ---- q, v, bias, filter bank -> LDS; energy accumulators cleared
+    if (tid < A) {
+        float qs = 0.f;
+#pragma unroll
+        for (int k = 0; k < KQ_MAX; ++k) qs += qp[k];
+        s.q[tid] = qs; s.vv[tid] = v_r; s.bias[tid] = bias_r;
+        if (ch == 0 && p.q_out) p.q_out[(long)b * A + tid] = qs;
+    }
+    if (tid < L) s.w[tid] = 0.f;
+    if (p.PL_next) {
+#pragma unroll
+        for (int j = 0; j < NU_MAX; ++j) { const int i = tid + j * ATT_THREADS; if (i < A * ksz) s.Us[i] = us[j]; }
+    }
+    __syncthreads();
+
+    // ---- energies
+    if ((A & 63) == 0) {
+#pragma unroll
+        for (int j = 0; j < NE_MAX; ++j) {
+            const int i = tid + j * ATT_THREADS;          // a wave's 64 elements share one position l
+            const int l = i / A, a = i - l * A;
+            float e = (i < LA) ? s.vv[a] * tanhf_(s.q[a] + pl[j]) : 0.f;
+            e = wave_sum(e);
+            if (lane == 0 && i < LA) atomicAdd(&s.w[l], e);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NE_MAX; ++j) {
+            const int i = tid + j * ATT_THREADS;
+            if (i < LA) { const int l = i / A, a = i - l * A; atomicAdd(&s.w[l], s.vv[a] * tanhf_(s.q[a] + pl[j])); }
+        }
+    }
+    __syncthreads();
+
+    // ---- masked softmax (wave 0), then the cumulative-alignment window
+    if (tid < 64) {
+        float mx = -INFINITY;
+        for (int l = lane; l < len; l += 64) mx = fmaxf(mx, s.w[l]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int l = lane; l < L; l += 64) { const float ex = (l < len) ? __expf(s.w[l] - mx) : 0.f; s.w[l] = ex; sum += ex; }
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+        for (int l = lane; l < L; l += 64) s.w[l] *= inv;
+    }
+    __syncthreads();
+    if (tid < L) {
+        const float wl = s.w[tid];
+        const float cn = cum_r + wl;
+        s.cumw[pad + tid] = cn;
+        if (ch == 0) { p.w_out[(long)b * L + tid] = wl; p.cum_out[(long)b * L + tid] = cn; }
+    }
+    if (tid < pad) { s.cumw[tid] = 0.f; s.cumw[pad + L + tid] = 0.f; }
+
+    // ---- context columns of this chunk (memory rows are already in registers)
+    float4* part4 = reinterpret_cast<float4*>(s.part);
+    {
+        float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < NC_MAX; ++j) {
+            const int l = cg + j * ng;
+            const float wl = (cg < ng && l < L) ? s.w[l] : 0.f;
+            s4.x += wl * mem4[j].x; s4.y += wl * mem4[j].y; s4.z += wl * mem4[j].z; s4.w += wl * mem4[j].w;
+        }
+        part4[tid] = s4;
+    }
+    __syncthreads();
+    if (tid < nc4) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < ng; ++k) { const float4 v4 = part4[k * nc4 + tid]; t.x += v4.x; t.y += v4.y; t.z += v4.z; t.w += v4.w; }
+        *reinterpret_cast<float4*>(p.ctx_out + (long)b * Dm + d0 + tid * 4) = t;
+    }
+
+    // ---- PL for the next step, rows [l0, l1)
+    if (p.PL_next) {
+        float* out = p.PL_next + ((long)b * L + l0) * A;
+#pragma unroll
+        for (int j = 0; j < NM_MAX; ++j) {
+            const int i = tid + j * ATT_THREADS;
+            if (i < nlA) {
+                const int r = i / A, a = i - r * A;
+                float acc = mt[j] + s.bias[a];
+                const float* u = s.Us + a * ksz;
+                const float* cw = s.cumw + l0 + r;
+                for (int jj = 0; jj < ksz; ++jj) acc += u[jj] * cw[jj];
+                out[i] = acc;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// generic kernel (any shape that fits the LDS budget)
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(ATT_THREADS) void attn_step_generic_kernel(AttnStepArgs p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x, ch = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = ATT_THREADS / 64;
     const int L = p.L, A = p.A, Dm = p.Dm, ksz = p.ksz, pad = (ksz - 1) / 2;
-    float* q = sm;                          // [A]
-    float* vv = q + A;                      // [A]
-    float* w = vv + A;                      // [L]
-    float* cumw = w + L;                    // [L + ksz - 1]  cum_out with zero halo
-    float* Us = cumw + L + ksz - 1;         // [A * ksz]
-    float* part = sm + (((2 * A + 2 * L + ksz - 1 + A * ksz) + 3) & ~3);   // [4 * ATT_THREADS] context partials (16-B aligned)
+    const AttLds s = att_carve(sm, A, L, ksz);
     const int len = min(p.lengths[b], L);
 
     for (int a = tid; a < A; a += ATT_THREADS) {
-        float s = 0.f;
-        for (int k = 0; k < p.kq; ++k) s += p.qpart[(long)k * p.q_ks + (long)b * A + a];
-        q[a] = s;
-        vv[a] = p.v[a];
-        if (ch == 0 && p.q_out) p.q_out[(long)b * A + a] = s;
+        float qs = 0.f;
+        for (int k = 0; k < p.kq; ++k) qs += p.qpart[(long)k * p.q_ks + (long)b * A + a];
+        s.q[a] = qs; s.vv[a] = p.v[a]; s.bias[a] = p.bias[a];
+        if (ch == 0 && p.q_out) p.q_out[(long)b * A + a] = qs;
     }
     if (p.PL_next)
-        for (int i = tid; i < A * ksz; i += ATT_THREADS) Us[i] = p.U[i];
+        for (int i = tid; i < A * ksz; i += ATT_THREADS) s.Us[i] = p.U[i];
     __syncthreads();
 
-    // energies: one wave per position (4 positions in flight per wave), lanes over the attention dimension
     const float* PLb = p.PL + (long)b * L * A;
-    for (int l0 = wave; l0 < L; l0 += 4 * nwaves) {
-        float e[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int l = l0 + j * nwaves;
-            float acc = 0.f;
-            if (l < len)
-                for (int a = lane; a < A; a += 64) acc += vv[a] * tanhf_(q[a] + PLb[(long)l * A + a]);
-            e[j] = acc;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int l = l0 + j * nwaves;
-            const float r = wave_sum(e[j]);
-            if (lane == 0 && l < L) w[l] = (l < len) ? r : -INFINITY;
-        }
+    for (int l = wave; l < L; l += nwaves) {
+        float e = 0.f;
+        if (l < len)
+            for (int a = lane; a < A; a += 64) e += s.vv[a] * tanhf_(s.q[a] + PLb[(long)l * A + a]);
+        e = wave_sum(e);
+        if (lane == 0) s.w[l] = (l < len) ? e : -INFINITY;
     }
     __syncthreads();
-
-    // masked softmax (wave 0) + cumulative alignment window
     if (wave == 0) {
         float mx = -INFINITY;
-        for (int l = lane; l < L; l += 64) mx = fmaxf(mx, w[l]);
+        for (int l = lane; l < L; l += 64) mx = fmaxf(mx, s.w[l]);
         mx = wave_max(mx);
-        float s = 0.f;
-        for (int l = lane; l < L; l += 64) { const float ex = (l < len) ? __expf(w[l] - mx) : 0.f; w[l] = ex; s += ex; }
-        s = wave_sum(s);
-        const float inv = 1.f / s;
+        float sum = 0.f;
+        for (int l = lane; l < L; l += 64) { const float ex = (l < len) ? __expf(s.w[l] - mx) : 0.f; s.w[l] = ex; sum += ex; }
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
         for (int l = lane; l < L; l += 64) {
-            const float wl = w[l] * inv;
-            w[l] = wl;
+            const float wl = s.w[l] * inv;
+            s.w[l] = wl;
             const float cn = p.cum_in[(long)b * L + l] + wl;
-            cumw[pad + l] = cn;
+            s.cumw[pad + l] = cn;
             if (ch == 0) { p.w_out[(long)b * L + l] = wl; p.cum_out[(long)b * L + l] = cn; }
         }
-        for (int i = lane; i < pad; i += 64) { cumw[i] = 0.f; cumw[pad + L + i] = 0.f; }
+        for (int i = lane; i < pad; i += 64) { s.cumw[i] = 0.f; s.cumw[pad + L + i] = 0.f; }
     }
     __syncthreads();
-
-    // context columns [d0, d1) of this chunk: float4 columns x row groups, reduced through LDS
     {
         const int dc = (((Dm + p.nch - 1) / p.nch) + 3) & ~3;
         const int d0 = ch * dc, d1 = min(Dm, d0 + dc);
@@ -86,14 +240,13 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_kernel(AttnStepArgs p) 
             float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (g < ng) {
                 const float* mem = p.memory + (long)b * L * Dm + d0 + c4 * 4;
-#pragma unroll 4
                 for (int l = g; l < len; l += ng) {
                     const float4 m4 = *reinterpret_cast<const float4*>(mem + (long)l * Dm);
-                    const float wl = w[l];
+                    const float wl = s.w[l];
                     s4.x += wl * m4.x; s4.y += wl * m4.y; s4.z += wl * m4.z; s4.w += wl * m4.w;
                 }
             }
-            float4* part4 = reinterpret_cast<float4*>(part);
+            float4* part4 = reinterpret_cast<float4*>(s.part);
             part4[tid] = s4;
             __syncthreads();
             if (tid < nc4) {
@@ -103,8 +256,6 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_kernel(AttnStepArgs p) 
             }
         }
     }
-
-    // PL for the next step, rows [l0, l1) of this chunk
     if (p.PL_next) {
         const int lc = (L + p.nch - 1) / p.nch;
         const int l0 = ch * lc, l1 = min(L, l0 + lc);
@@ -112,11 +263,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_kernel(AttnStepArgs p) 
         float* out = p.PL_next + (long)b * L * A;
         for (int i = tid; i < (l1 - l0) * A; i += ATT_THREADS) {
             const int l = l0 + i / A, a = i % A;
-            float s = Mb[(long)l * A + a] + p.bias[a];
-            const float* u = Us + a * ksz;
-            const float* cw = cumw + l;
-            for (int j = 0; j < ksz; ++j) s += u[j] * cw[j];
-            out[(long)l * A + a] = s;
+            float acc = Mb[(long)l * A + a] + s.bias[a];
+            const float* u = s.Us + a * ksz;
+            const float* cw = s.cumw + l;
+            for (int j = 0; j < ksz; ++j) acc += u[j] * cw[j];
+            out[(long)l * A + a] = acc;
         }
     }
 }
@@ -139,9 +290,15 @@ int attn_step_launch(const AttnStepArgs& p, hipStream_t s) {
     MTTS_REQUIRE((p.ksz & 1) == 1, "attention kernel size must be odd (got %d)", p.ksz);
     const int dc = (((p.Dm + p.nch - 1) / p.nch) + 3) & ~3;
     MTTS_REQUIRE(dc / 4 <= ATT_THREADS && (p.Dm & 3) == 0, "attn_step: Dm/nch = %d too wide or Dm %% 4 != 0", dc);
-    const size_t lds = sizeof(float) * ((((size_t)2 * p.A + 2 * p.L + p.ksz - 1 + (size_t)p.A * p.ksz) + 3 & ~(size_t)3) + 4 * ATT_THREADS);
+    const size_t lds = att_lds_bytes(p.A, p.L, p.ksz);
     MTTS_REQUIRE(lds <= 64 * 1024, "attn_step: LDS request %zu too large", lds);
-    hipLaunchKernelGGL(attn_step_kernel, dim3(p.B, p.nch), dim3(ATT_THREADS), lds, s, p);
+    const int nc4 = dc / 4, ng = nc4 > 0 ? (ATT_THREADS / nc4 > 0 ? ATT_THREADS / nc4 : 1) : 1;
+    const int lc = (p.L + p.nch - 1) / p.nch;
+    const bool fast = p.A <= ATT_THREADS && p.L <= ATT_THREADS && (long)p.L * p.A <= (long)NE_MAX * ATT_THREADS &&
+                      (p.L + ng - 1) / ng <= NC_MAX && (long)lc * p.A <= (long)NM_MAX * ATT_THREADS &&
+                      (long)p.A * p.ksz <= (long)NU_MAX * ATT_THREADS && p.kq <= KQ_MAX && (p.ksz - 1) / 2 <= ATT_THREADS;
+    if (fast) hipLaunchKernelGGL(attn_step_kernel, dim3(p.B, p.nch), dim3(ATT_THREADS), lds, s, p);
+    else hipLaunchKernelGGL(attn_step_generic_kernel, dim3(p.B, p.nch), dim3(ATT_THREADS), lds, s, p);
     MTTS_CHECK_LAUNCH("attn_step_kernel");
     return 0;
 }

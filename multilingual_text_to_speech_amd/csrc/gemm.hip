@@ -120,8 +120,39 @@ __device__ __forceinline__ void store_tile(float* __restrict__ lds, const Tile<T
 
 constexpr int LDS_A = (BM * KC_LD > BK * MC_LD) ? BM * KC_LD : BK * MC_LD;   // floats per operand buffer
 
+// Caller-provided scratch arena for split-K partial tiles (mtts_set_workspace); the library never allocates.
+static float* g_ws_host = nullptr;
+static size_t g_ws_bytes = 0;
+
+MTTS_API int mtts_set_workspace(void* ptr, size_t bytes) {
+    g_ws_host = (float*)ptr;
+    g_ws_bytes = bytes;
+    return 0;
+}
+
+// C = epilogue(alpha * sum_s partial_s ...) for split-K launches
+__global__ void gemm_splitk_reduce(GemmArgs p, const float* __restrict__ ws, int S) {
+    const int z = blockIdx.z;
+    const int zb = z / p.zt, ztap = z % p.zt;
+    float* C = p.C + (long)zb * p.c_z + (long)ztap * p.c_ztap;
+    const float* bias = p.bias ? p.bias + (long)zb * p.bias_z : nullptr;
+    const long MN = (long)p.M * p.N;
+    const float* W = ws + (long)z * S * MN;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < MN; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / p.N; const int col = (int)(i - row * p.N);
+        float a = 0.f;
+        for (int s = 0; s < S; ++s) a += W[s * MN + i];
+        float v = p.alpha * a + (bias ? bias[col] : 0.f);
+        float* cp = C + row * p.ldc + col;
+        if (p.beta != 0.f) v += p.beta * (*cp);
+        v = apply_act(p.act, v);
+        if (p.mask) v = p.mask[row * p.ldmask + col] ? v * p.mask_scale : 0.f;
+        *cp = v;
+    }
+}
+
 template <bool TA, bool TB>
-__global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs p) {
+__global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs p, float* g_ws) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // buffer b: A at smem + 2*b*LDS_A, B right behind it
 
@@ -163,15 +194,19 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     Tile<TA> ta; Tile<TB> tb;
-    const int nk = (p.K + BK - 1) / BK;
-    load_tile<TA, true>(p, A, m0, 0, p.M, p.lda, vecA, shift_z, ta);
-    load_tile<TB, false>(p, B, n0, 0, p.N, p.ldb, vecB, shift_z, tb);
+    // split-K: blockIdx.y owns the K blocks [kb0, nk)
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int per_split = (nk_all + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int kb0 = blockIdx.y * per_split;
+    const int nk = min(nk_all, kb0 + per_split);
+    load_tile<TA, true>(p, A, m0, kb0 * BK, p.M, p.lda, vecA, shift_z, ta);
+    load_tile<TB, false>(p, B, n0, kb0 * BK, p.N, p.ldb, vecB, shift_z, tb);
     store_tile<TA>(smem, ta);
     store_tile<TB>(smem + LDS_A, tb);
     __syncthreads();
 
-    for (int kb = 0; kb < nk; ++kb) {
-        const int cur = kb & 1;
+    for (int kb = kb0; kb < nk; ++kb) {
+        const int cur = (kb - kb0) & 1;
         if (kb + 1 < nk) {
             load_tile<TA, true>(p, A, m0, (kb + 1) * BK, p.M, p.lda, vecA, shift_z, ta);
             load_tile<TB, false>(p, B, n0, (kb + 1) * BK, p.N, p.ldb, vecB, shift_z, tb);
@@ -214,7 +249,23 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs p) {
         __syncthreads();
     }
 
-    // epilogue: C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (gridDim.y > 1) {      // split-K: raw partial tile into the workspace, epilogue in gemm_splitk_reduce
+        float* W = g_ws + ((long)z * gridDim.y + blockIdx.y) * (long)p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wn + j * 32 + li;
+                if (col >= p.N) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lq;
+                    if (row < p.M) W[(long)row * p.N + col] = acc[i][j][r];
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -245,7 +296,20 @@ MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
     if (p.zt < 1) p.zt = 1;
     MTTS_REQUIRE(p.shift_mode == 0 || p.seq_len > 0, "mtts_gemm_ex: shift_mode needs seq_len");
     const int ntx = cdiv(p.N, BN), nty = cdiv(p.M, BM);
-    dim3 grid(ntx * nty, 1, p.batch * p.zt);
+    // split-K when few output tiles face a long reduction (weight gradients): fill ~4 workgroups per CU
+    int S = 1;
+    {
+        const long tiles = (long)ntx * nty * p.batch * p.zt;
+        const int nkb = cdiv(p.K, BK);
+        if (g_ws_host && tiles < 512 && nkb >= 64) {
+            S = (int)((1024 + tiles - 1) / tiles);
+            if (S > nkb / 16) S = nkb / 16;
+            if (S > 32) S = 32;
+            while (S > 1 && (size_t)S * p.batch * p.zt * p.M * p.N * sizeof(float) > g_ws_bytes) --S;
+            if (S < 1) S = 1;
+        }
+    }
+    dim3 grid(ntx * nty, S, p.batch * p.zt);
     const size_t lds = 4 * LDS_A * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     static bool attr_done = false;
@@ -256,11 +320,18 @@ MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
         hipFuncSetAttribute((const void*)gemm_mfma_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    if (!p.transA && !p.transB) hipLaunchKernelGGL((gemm_mfma_kernel<false, false>), grid, dim3(256), lds, s, p);
-    else if (!p.transA && p.transB) hipLaunchKernelGGL((gemm_mfma_kernel<false, true>), grid, dim3(256), lds, s, p);
-    else if (p.transA && !p.transB) hipLaunchKernelGGL((gemm_mfma_kernel<true, false>), grid, dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((gemm_mfma_kernel<true, true>), grid, dim3(256), lds, s, p);
+    float* ws = g_ws_host;
+    if (!p.transA && !p.transB) hipLaunchKernelGGL((gemm_mfma_kernel<false, false>), grid, dim3(256), lds, s, p, ws);
+    else if (!p.transA && p.transB) hipLaunchKernelGGL((gemm_mfma_kernel<false, true>), grid, dim3(256), lds, s, p, ws);
+    else if (p.transA && !p.transB) hipLaunchKernelGGL((gemm_mfma_kernel<true, false>), grid, dim3(256), lds, s, p, ws);
+    else hipLaunchKernelGGL((gemm_mfma_kernel<true, true>), grid, dim3(256), lds, s, p, ws);
     MTTS_CHECK_LAUNCH("gemm_mfma_kernel");
+    if (S > 1) {
+        const long MN = (long)p.M * p.N;
+        int blocks = (int)((MN + 255) / 256); if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(gemm_splitk_reduce, dim3(blocks, 1, p.batch * p.zt), dim3(256), 0, s, p, ws, S);
+        MTTS_CHECK_LAUNCH("gemm_splitk_reduce");
+    }
     return 0;
 }
 

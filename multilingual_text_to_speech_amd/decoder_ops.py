@@ -87,6 +87,7 @@ WEIGHT_ORDER = ['att_w_ih', 'att_w_hh', 'att_b_ih', 'att_b_hh', 'gen_w_ih', 'gen
 
 
 def run_decoder(st, w, memory, lengths32, frames_in, teacher, masks, cfg, t0, t1):
+    _C.ensure_workspace(memory.device)
     a = _C.DecoderArgs()
     th = None
     if teacher is not None:

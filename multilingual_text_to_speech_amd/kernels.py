@@ -29,6 +29,7 @@ def keep_mask(shape, p, device, generator=None):
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, alpha=1.0, beta=0.0, bias=None, act=0,
          mask=None, mask_scale=1.0, **kw):
     """C = epilogue(alpha * A(m,k) B(n,k) + beta C).  Extra GemmArgs fields via **kw (conv / batch modes)."""
+    _C.ensure_workspace(C.device)
     g = _C.GemmArgs()
     g.A, g.B, g.C, g.bias, g.mask = ptr(A), ptr(B), ptr(C), ptr(bias), ptr(mask)
     g.M, g.N, g.K, g.lda, g.ldb, g.ldc = M, N, K, lda, ldb, ldc
