@@ -1,0 +1,2 @@
+cd /root/repo
+timeout 600 python -m pytest tests -x -q -m gpu 2>&1 | tail -12

@@ -1,0 +1,85 @@
+"""CPU checks of the drop-in boundary: config surface and checkpoint (state_dict) layout."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from multilingual_text_to_speech_amd.params import Params as hp, presets, reset_defaults
+
+REF = '/root/reference'
+needs_ref = pytest.mark.skipif(not os.path.isdir(REF), reason='reference tree not present on this machine')
+
+
+def test_params_roundtrip_and_symbols(tmp_path):
+    reset_defaults()
+    assert hp.symbols_count() == 70 and hp.batch_size == 52 and hp.encoder_type == 'simple'
+    presets.apply('generated_switching')
+    assert hp.symbols_count() + 3 == 114 and hp.language_number == 5 and hp.generator_dim == 10
+    p = tmp_path / 'x.json'
+    hp.save(str(p))
+    d = json.load(open(p))
+    reset_defaults()
+    hp.load(str(p))
+    assert hp.encoder_type == 'generated' and hp.state_dict() == d
+    presets.apply('shared_training')
+    assert hp.symbols_count() + 3 == 147 and hp.language_embedding_dimension == 32
+
+
+@needs_ref
+def test_defaults_and_presets_equal_reference():
+    code = ("import sys, json; sys.path.insert(0, %r); from params.params import Params as R; "
+            "print(json.dumps(R.state_dict(), ensure_ascii=False))" % REF)
+    ref = json.loads(subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, check=True).stdout)
+    reset_defaults()
+    assert hp.state_dict() == ref
+    for name, overrides in presets.PRESETS.items():
+        with open(os.path.join(REF, 'params', name + '.json'), encoding='utf-8') as f:
+            assert json.load(f) == overrides, name
+
+
+@needs_ref
+@pytest.mark.parametrize('preset', ['shared_training', 'generated_switching', 'separate_training'])
+def test_state_dict_layout_equals_reference(preset):
+    """Same keys and shapes as the reference model => reference checkpoints load unchanged."""
+    code = ("import sys, json, torch; sys.path.insert(0, %r); import utils; from params.params import Params as hp; "
+            "from modules.tacotron2 import Tacotron; hp.load(%r); hp.language_number = len(hp.languages) if hp.multi_language else 0; "
+            "hp.speaker_number = 91 if hp.multi_speaker else 0; m = Tacotron(); "
+            "print(json.dumps({k: list(v.shape) for k, v in m.state_dict().items()}))"
+            % (REF, os.path.join(REF, 'params', preset + '.json')))
+    ref = json.loads(subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, check=True, cwd=REF).stdout)
+    from multilingual_text_to_speech_amd.modules.tacotron2 import Tacotron
+    presets.apply(preset, speaker_number=91 if presets.PRESETS[preset].get('multi_speaker') else 0)
+    ours = {k: list(v.shape) for k, v in Tacotron().state_dict().items()}
+    assert ours == ref
+
+
+def test_golden_state_dict_loads_strictly():
+    from tests.helpers import golden_names, load_golden
+    from multilingual_text_to_speech_amd.modules.tacotron2 import Tacotron
+    for name in golden_names():
+        fx = load_golden(name)
+        reset_defaults()
+        hp.load_state_dict(fx['hp'])
+        Tacotron().load_state_dict(fx['state_dict'], strict=True)
+
+
+def test_install_aliases_exposes_reference_import_names():
+    import multilingual_text_to_speech_amd as mtts
+    saved = {k: sys.modules.get(k) for k in ('params', 'params.params', 'modules', 'modules.tacotron2', 'utils')}
+    try:
+        for k in saved:
+            sys.modules.pop(k, None)
+        mtts.install_aliases()
+        from params.params import Params
+        from modules.tacotron2 import Tacotron
+        import utils
+        assert Params is hp and hasattr(utils, 'build_model') and Tacotron.__name__ == 'Tacotron'
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
