@@ -63,6 +63,7 @@ typedef struct GemmArgs {
     float beta;
     int act;
     float mask_scale;
+    int nosplit;      /* != 0: never use the split-K workspace (launches on a second stream) */
 } GemmArgs;
 
 int mtts_gemm_ex(const GemmArgs* args, void* stream);

@@ -31,3 +31,27 @@ MTTS_API int mtts_sizeof_struct(int which) {
         default: return -1;
     }
 }
+
+// ---- side stream + event pool for the two-chain decoder schedules (created once; streams/events are not memory) ----
+static hipStream_t g_side = nullptr;
+static hipEvent_t g_events[256];
+static int g_event_next = 0, g_event_count = 0;
+
+hipStream_t side_stream() {
+    if (!g_side) {
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);          // lo = least priority
+        if (hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, lo) != hipSuccess) g_side = nullptr;
+    }
+    return g_side;
+}
+
+hipEvent_t pool_event() {
+    if (g_event_count < 256) {
+        hipEventCreateWithFlags(&g_events[g_event_count], hipEventDisableTiming);
+        return g_events[g_event_count++];
+    }
+    hipEvent_t e = g_events[g_event_next];
+    g_event_next = (g_event_next + 1) % 256;
+    return e;
+}

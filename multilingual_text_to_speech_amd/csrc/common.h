@@ -82,3 +82,5 @@ int transpose2d_ld(const float* in, float* out, int rows, int cols, int ldi, int
 int colsum(const float* x, float* out, int rows, int cols, int ld, float* ws, hipStream_t s);
 int relu_mask_bwd(const float* dy, const float* y, float* dz, long n, float scale, hipStream_t s);
 bool prof_sample(int t, hipStream_t s, int phase);
+hipStream_t side_stream();
+hipEvent_t pool_event();

@@ -23,6 +23,41 @@ static void lstm_reg(const DecoderArgs& a, SkinnyArgs& k, const uint8_t* hmask, 
     }
 }
 
+// Chain B of the fast schedule for steps [c0, c1): generator-LSTM input gates (batched), the recurrent steps and the
+// frame/stop projection (batched).  Runs on its own low-priority stream behind chain A (see side_stream()).
+static int gen_chunk(const DecoderArgs& a, int c0, int c1, hipStream_t s) {
+    const int B = a.B, M = a.M, H = a.H, Dm = a.Dm;
+    const int Mo = round4(M + 1), n = c1 - c0;
+    const long BH = (long)B * H, BD = (long)B * Dm, B4H = 4 * BH;
+    GemmArgs g; memset(&g, 0, sizeof(g));
+    g.taps = 1; g.batch = 1; g.zt = 1; g.alpha = 1.f; g.mask_scale = 1.f; g.nosplit = 1;
+    // pre_gen = [h_att, ctx] W_ih^T
+    g.A = a.h_att + (c0 + 1) * BH; g.B = a.gen_w_ih; g.C = a.pre_gen + c0 * B4H;
+    g.M = n * B; g.N = 4 * H; g.K = H; g.Kc = H; g.lda = H; g.ldb = H + Dm; g.ldc = 4 * H; g.beta = 0.f;
+    MTTS_TRY(mtts_gemm_ex(&g, s));
+    g.A = a.ctx + (c0 + 1) * BD; g.B = a.gen_w_ih + H; g.K = Dm; g.Kc = Dm; g.lda = Dm; g.beta = 1.f;
+    MTTS_TRY(mtts_gemm_ex(&g, s));
+    for (int t = c0; t < c1; ++t) {
+        SkinnyArgs k; memset(&k, 0, sizeof(k));
+        k.B = B; k.N = 4 * H; k.ksplit = 1; k.lstm = 1; k.H = H; k.nseg = 1;
+        k.seg[0] = SkSeg{a.h_gen + t * BH, a.gen_w_hh, H, H, H};
+        k.pre = a.pre_gen + t * B4H; k.ldpre = 4 * H;
+        k.b_ih = a.gen_b_ih; k.b_hh = a.gen_b_hh;
+        k.h_prev = a.h_gen + t * BH; k.c_prev = a.c_gen + t * BH;
+        k.h_out = a.h_gen + (t + 1) * BH; k.c_out = a.c_gen + (t + 1) * BH;
+        k.gates_out = a.gates_gen ? a.gates_gen + t * B4H : nullptr;
+        lstm_reg(a, k, a.gen_hmask, a.gen_cmask, t);
+        MTTS_TRY(skinny_launch(k, s));
+    }
+    float* o = a.out + (long)(c0 + 1) * B * Mo;
+    g.A = a.h_gen + (c0 + 1) * BH; g.B = a.w_out; g.C = o; g.bias = a.b_out;
+    g.M = n * B; g.N = M + 1; g.K = H; g.Kc = H; g.lda = H; g.ldb = H + Dm; g.ldc = Mo; g.beta = 0.f;
+    MTTS_TRY(mtts_gemm_ex(&g, s));
+    g.A = a.ctx + (c0 + 1) * BD; g.B = a.w_out + H; g.bias = nullptr; g.K = Dm; g.Kc = Dm; g.lda = Dm; g.beta = 1.f;
+    MTTS_TRY(mtts_gemm_ex(&g, s));
+    return 0;
+}
+
 MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
     const DecoderArgs& a = *args;
     hipStream_t s = (hipStream_t)stream;
@@ -65,6 +100,10 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
                             false, 1.f, 0.f, nullptr, 0, s));
     }
 
+    // fast schedule: chain B trails chain A chunk by chunk on the side stream
+    const int CH = 48;
+    hipStream_t sb = a.fast ? side_stream() : nullptr;
+    if (a.fast && !sb) return mtts_fail("decoder: cannot create the side stream");
     for (int t = a.t0; t < a.t1; ++t) {
         const bool teach = a.frames_in && a.teacher && a.teacher[t];
         if (!teach) {
@@ -144,9 +183,22 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
                 MTTS_TRY(skinny_launch(k, s));
             }
         }
+        if (a.fast && (((t + 1 - a.t0) % CH) == 0 || t + 1 == a.t1)) {
+            const int c1 = t + 1, c0 = a.t0 + ((c1 - a.t0 - 1) / CH) * CH;
+            hipEvent_t ev = pool_event();
+            MTTS_CHECK_HIP(hipEventRecord(ev, s));
+            MTTS_CHECK_HIP(hipStreamWaitEvent(sb, ev, 0));
+            MTTS_TRY(gen_chunk(a, c0, c1, sb));
+        }
+    }
+    if (a.fast) {     // join: the caller's stream continues after chain B
+        hipEvent_t ev = pool_event();
+        MTTS_CHECK_HIP(hipEventRecord(ev, sb));
+        MTTS_CHECK_HIP(hipStreamWaitEvent(s, ev, 0));
+        return 0;
     }
 
-    if (a.fast) {
+    if (false) {
         // generator-LSTM input gates for all steps of the range: [h_att, ctx] W_ih^T
         MTTS_TRY(gemm_plain(a.h_att + (a.t0 + 1) * BH, a.gen_w_ih, a.pre_gen + a.t0 * B4H, nsteps * B, 4 * H, H, H, H + Dm, 4 * H,
                             false, false, 1.f, 0.f, nullptr, 0, s));

@@ -7,6 +7,8 @@
 // Per step only skinny GEMMs against TRANSPOSED recurrent weights, the fused LSTM-cell backward epilogue and the
 // attention backward kernel run; every weight gradient is one large MFMA GEMM over the saved gate gradients.
 #include "common.h"
+#include <algorithm>
+#include <vector>
 
 static inline int round4(int x) { return (x + 3) & ~3; }
 
@@ -45,31 +47,64 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
     MTTS_TRY(gm(dout1, a.w_out, g.dHG, TB, H, M + 1, Mo, H + Dm, H, false, true, 0.f, s));
     MTTS_TRY(gm(dout1, a.w_out + H, g.dctx_all + BD, TB, Dm, M + 1, Mo, H + Dm, Dm, false, true, 0.f, s));
 
-    // ---- chain B: generator LSTM, t = T-1 .. 0
-    for (int t = T - 1; t >= 0; --t) {
-        SkinnyArgs k; memset(&k, 0, sizeof(k));
-        k.B = B; k.H = H; k.lstm = 2; k.nseg = 0; k.ksplit = 1;
-        k.dh_a = g.dHG + t * BH; k.ld_dh_a = H;
-        if (t < T - 1) { k.part = g.part_gen; k.n_part = ksb; k.part_ks = BH; k.part_ld = H; k.part_col0 = 0; }
-        k.gates = a.gates_gen + t * B4H; k.c_prev = a.c_gen + t * BH;
-        k.dc_in = g.dc_gen + ((t + 1) & 1) * BH; k.dc_out = g.dc_gen + (t & 1) * BH;
-        k.dgates_out = g.dG_gen + t * B4H; k.ld_dgates = 4 * H;
-        bwd_reg(a, k, a.gen_hmask, a.gen_cmask, t);
-        MTTS_TRY(skinny_launch(k, s));
-        if (t > 0) {
-            SkinnyArgs q; memset(&q, 0, sizeof(q));
-            q.nseg = 1; q.B = B; q.N = H; q.ksplit = ksb;
-            q.seg[0] = SkSeg{g.dG_gen + t * B4H, g.gen_w_hh_T, 4 * H, 4 * H, 4 * H};
-            q.out = g.part_gen; q.ldo = H; q.out_ks = BH;
-            MTTS_TRY(skinny_launch(q, s));
-        }
+    // ---- chain B (generator LSTM, side stream) runs AHEAD of chain A (attention + attention LSTM, caller's stream),
+    //      chunk by chunk from the last step backwards; per chunk: recurrence -> batched input gradients -> event.
+    const int CH = 48;
+    hipStream_t sb = side_stream();
+    if (!sb) return mtts_fail("decoder backward: cannot create the side stream");
+    {
+        hipEvent_t ev = pool_event();
+        MTTS_CHECK_HIP(hipEventRecord(ev, s));
+        MTTS_CHECK_HIP(hipStreamWaitEvent(sb, ev, 0));
     }
-    // ---- input gradients of the generator LSTM (batched): dHA = dG_gen W_ih[:, :H];  dctx_all[1:] += dG_gen W_ih[:, H:]
-    MTTS_TRY(gm(g.dG_gen, a.gen_w_ih, g.dHA, TB, H, 4 * H, 4 * H, H + Dm, H, false, true, 0.f, s));
-    MTTS_TRY(gm(g.dG_gen, a.gen_w_ih + H, g.dctx_all + BD, TB, Dm, 4 * H, 4 * H, H + Dm, Dm, false, true, 1.f, s));
+    const int nchunks = (T + CH - 1) / CH;
+    std::vector<hipEvent_t> chunk_ev(nchunks);
+    for (int c = nchunks - 1; c >= 0; --c) {
+        const int c0 = c * CH, c1 = std::min(T, c0 + CH), n = c1 - c0;
+        for (int t = c1 - 1; t >= c0; --t) {
+            SkinnyArgs k; memset(&k, 0, sizeof(k));
+            k.B = B; k.H = H; k.lstm = 2; k.nseg = 0; k.ksplit = 1;
+            k.dh_a = g.dHG + t * BH; k.ld_dh_a = H;
+            if (t < T - 1) { k.part = g.part_gen; k.n_part = ksb; k.part_ks = BH; k.part_ld = H; k.part_col0 = 0; }
+            k.gates = a.gates_gen + t * B4H; k.c_prev = a.c_gen + t * BH;
+            k.dc_in = g.dc_gen + ((t + 1) & 1) * BH; k.dc_out = g.dc_gen + (t & 1) * BH;
+            k.dgates_out = g.dG_gen + t * B4H; k.ld_dgates = 4 * H;
+            bwd_reg(a, k, a.gen_hmask, a.gen_cmask, t);
+            MTTS_TRY(skinny_launch(k, sb));
+            if (t > 0) {
+                SkinnyArgs q; memset(&q, 0, sizeof(q));
+                q.nseg = 1; q.B = B; q.N = H; q.ksplit = ksb;
+                q.seg[0] = SkSeg{g.dG_gen + t * B4H, g.gen_w_hh_T, 4 * H, 4 * H, 4 * H};
+                q.out = g.part_gen; q.ldo = H; q.out_ks = BH;
+                MTTS_TRY(skinny_launch(q, sb));
+            }
+        }
+        // input gradients of the generator LSTM for this chunk: dHA = dG_gen W_ih[:, :H];  dctx_all[1:] += dG_gen W_ih[:, H:]
+        GemmArgs q; memset(&q, 0, sizeof(q));
+        q.taps = 1; q.batch = 1; q.zt = 1; q.alpha = 1.f; q.mask_scale = 1.f; q.nosplit = 1; q.transB = 1;
+        q.A = g.dG_gen + c0 * B4H; q.B = a.gen_w_ih; q.C = g.dHA + c0 * BH;
+        q.M = n * B; q.N = H; q.K = 4 * H; q.Kc = 4 * H; q.lda = 4 * H; q.ldb = H + Dm; q.ldc = H; q.beta = 0.f;
+        MTTS_TRY(mtts_gemm_ex(&q, sb));
+        q.B = a.gen_w_ih + H; q.C = g.dctx_all + (c0 + 1) * BD; q.N = Dm; q.ldc = Dm; q.beta = 1.f;
+        MTTS_TRY(mtts_gemm_ex(&q, sb));
+        chunk_ev[c] = pool_event();
+        MTTS_CHECK_HIP(hipEventRecord(chunk_ev[c], sb));
+    }
+    // generator-side weight gradients also go to the side stream (they only need dG_gen); no split-K there (shared scratch)
+    {
+        GemmArgs q; memset(&q, 0, sizeof(q));
+        q.taps = 1; q.batch = 1; q.zt = 1; q.alpha = 1.f; q.mask_scale = 1.f; q.nosplit = 1; q.transA = 1; q.transB = 1;
+        q.A = g.dG_gen; q.M = 4 * H; q.K = TB; q.Kc = TB; q.lda = 4 * H;
+        q.B = a.h_att + BH; q.C = g.d_gen_w_ih; q.N = H; q.ldb = H; q.ldc = H + Dm; MTTS_TRY(mtts_gemm_ex(&q, sb));
+        q.B = a.ctx + BD; q.C = g.d_gen_w_ih + H; q.N = Dm; q.ldb = Dm; MTTS_TRY(mtts_gemm_ex(&q, sb));
+        q.B = a.h_gen; q.C = g.d_gen_w_hh; q.N = H; q.ldb = H; q.ldc = H; MTTS_TRY(mtts_gemm_ex(&q, sb));
+    }
+    hipEvent_t ev_b_done = pool_event();
+    MTTS_CHECK_HIP(hipEventRecord(ev_b_done, sb));
 
     // ---- chain A: attention + attention LSTM, t = T-1 .. 0
     for (int t = T - 1; t >= 0; --t) {
+        if (t == T - 1 || ((t + 1) % CH) == 0) MTTS_CHECK_HIP(hipStreamWaitEvent(s, chunk_ev[t / CH], 0));
         {
             AttnBwdArgs q; memset(&q, 0, sizeof(q));
             q.q = a.q_all + t * BA; q.Mt = a.Mt; q.U = a.U; q.bias = a.att_bias; q.v = a.w_energy; q.memory = a.memory;
@@ -102,6 +137,7 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
             MTTS_TRY(skinny_launch(q, s));
         }
     }
+    MTTS_CHECK_HIP(hipStreamWaitEvent(s, ev_b_done, 0));     // join before the split-K weight-gradient GEMMs
 
     // ---- prenet backward (batched over all frames)
     const int n = a.n_prenet;
@@ -125,9 +161,6 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
     MTTS_TRY(gm(g.dG_att, a.h_att, g.d_att_w_hh, 4 * H, H, TB, 4 * H, H, H, true, true, 0.f, s));
     MTTS_TRY(colsum(g.dG_att, g.d_att_b_ih, TB, 4 * H, 4 * H, g.colsum_ws, s));
     MTTS_TRY(colsum(g.dG_att, g.d_att_b_hh, TB, 4 * H, 4 * H, g.colsum_ws, s));
-    MTTS_TRY(gm(g.dG_gen, a.h_att + BH, g.d_gen_w_ih, 4 * H, H, TB, 4 * H, H, H + Dm, true, true, 0.f, s));
-    MTTS_TRY(gm(g.dG_gen, a.ctx + BD, g.d_gen_w_ih + H, 4 * H, Dm, TB, 4 * H, Dm, H + Dm, true, true, 0.f, s));
-    MTTS_TRY(gm(g.dG_gen, a.h_gen, g.d_gen_w_hh, 4 * H, H, TB, 4 * H, H, H, true, true, 0.f, s));
     MTTS_TRY(colsum(g.dG_gen, g.d_gen_b_ih, TB, 4 * H, 4 * H, g.colsum_ws, s));
     MTTS_TRY(colsum(g.dG_gen, g.d_gen_b_hh, TB, 4 * H, 4 * H, g.colsum_ws, s));
 

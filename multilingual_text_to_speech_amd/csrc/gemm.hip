@@ -301,7 +301,7 @@ MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
     {
         const long tiles = (long)ntx * nty * p.batch * p.zt;
         const int nkb = cdiv(p.K, BK);
-        if (g_ws_host && tiles < 512 && nkb >= 64) {
+        if (g_ws_host && !p.nosplit && tiles < 512 && nkb >= 64) {
             S = (int)((1024 + tiles - 1) / tiles);
             if (S > nkb / 16) S = nkb / 16;
             if (S > 32) S = 32;
