@@ -116,6 +116,8 @@ typedef struct SkSeg {
     int K;
     int ldx;
     int ldw;
+    int xpack;             /* != 0: x is in the MFMA tile order written by the producer kernels (see mtts_pack_rows) */
+    int wpack;             /* != 0: w is in the MFMA tile order produced by mtts_pack_weight */
 } SkSeg;
 
 typedef struct SkinnyArgs {
@@ -170,9 +172,18 @@ typedef struct SkinnyArgs {
     float* dgates_out;     /* [B, ld_dgates] */
     int ld_dgates;
     float* dh_carry_out;   /* [B,H] or NULL */
+    float* h_pack_out;     /* lstm == 1: additional copy of h_out in MFMA tile order (K = H) or NULL */
+    float* dg_pack_out;    /* lstm == 2: additional copy of the gate gradients in MFMA tile order (K = 4H) or NULL */
 } SkinnyArgs;
 
 int mtts_skinny_gemm(const SkinnyArgs* args, void* stream);
+/* MFMA tile order ("packed"): a [rows, K] matrix (K % 16 == 0) is stored as [rows/16][K/16][64 lanes][4 floats]; lane
+ * l = 16*q + i holds row 16*tile + i, columns 16*chunk + 4*q .. +3.  One wave instruction then fetches a whole 16x16 tile
+ * as 1 KiB of contiguous memory directly in the v_mfma_f32_16x16x4_f32 operand layout.
+ * mtts_pack_weight: rows are weight rows; lstm_H > 0 applies the fused-LSTM column order (tile cb = units 4cb..4cb+3 x 4 gates).
+ * mtts_pack_rows: rows are batch rows (padded with zeros to a multiple of 16). */
+int mtts_pack_weight(const float* src, int ld, int N, int K, int lstm_H, float* dst, void* stream);
+int mtts_pack_rows(const float* src, int ld, int rows, int K, float* dst, void* stream);
 
 /* ---- location-sensitive attention step -------------------------------------------------------------------
  * Replaces LocationSensitiveAttention.forward for one decoder step: modules/attention.py:39-45,67-86.
@@ -196,6 +207,7 @@ typedef struct AttnStepArgs {
     float* w_out;          /* [B,L] alignment of this step */
     float* ctx_out;        /* [B,Dm] */
     float* q_out;          /* [B,A] summed query projection saved for backward (nullable) */
+    float* ctx_pack_out;   /* context in MFMA tile order (K = Dm, Dm % 16 == 0) or NULL */
     int B;
     int L;
     int A;
@@ -279,6 +291,14 @@ typedef struct DecoderArgs {
     float* pre_att;        /* [T,B,4H] hoisted input projection workspace (fast path) or NULL */
     float* pre_gen;        /* [T,B,4H] */
     float* q_all;          /* [T,B,A] query projections saved for backward or NULL */
+    /* optional MFMA-tile-order copies used by the step kernels (all NULL -> row-major operands); Bp = B rounded up to 16 */
+    float* h_att_p;        /* [T+1][Bp*H] */
+    float* h_gen_p;        /* [T+1][Bp*H] */
+    float* ctx_p;          /* [T+1][Bp*Dm] */
+    float* att_w_ctx_p;    /* packed W_ih[:, P:]  (4H x Dm, LSTM column order) */
+    float* att_w_hh_p;     /* packed W_hh         (4H x H) */
+    float* gen_w_hh_p;
+    float* w_query_p;      /* packed W_query      (A x H) */
     int fast;              /* 1: all steps teacher forced -> hoisted projections + deferred generator chain */
 } DecoderArgs;
 
@@ -358,6 +378,10 @@ typedef struct DecoderGradArgs {
     float* w_query_T;      /* [H,A] */
     float* dG_att;         /* [T,B,4H] */
     float* dG_gen;         /* [T,B,4H] */
+    float* dG_att_p;       /* [T][Bp*4H] MFMA tile order copies (optional) */
+    float* dG_gen_p;
+    float* att_w_rec_Tp;   /* packed [Dm+H, 4H] */
+    float* gen_w_hh_Tp;    /* packed [H, 4H] */
     float* dHG;            /* [T,B,H] */
     float* dHA;            /* [T,B,H] */
     float* dctx_all;       /* [T+1,B,Dm] direct (batched) parts, slot t+1 <-> context of step t */

@@ -55,6 +55,12 @@ def decoder_bwd(ctx, dspec, dstop, dalign):
     buf('w_query_T', _e(H, A, device=dev))
     buf('dG_att', _e(T, B, 4 * H, device=dev))
     buf('dG_gen', _e(T, B, 4 * H, device=dev))
+    if H % 16 == 0:      # MFMA-tile-order copies for the per-step input-gradient GEMMs
+        Bp = (B + 15) & ~15
+        buf('dG_att_p', _z(T, Bp * 4 * H, device=dev))
+        buf('dG_gen_p', _z(T, Bp * 4 * H, device=dev))
+        buf('att_w_rec_Tp', _e(((Dm + H + 15) & ~15) * 4 * H, device=dev))
+        buf('gen_w_hh_Tp', _e(H * 4 * H, device=dev))
     buf('dHG', _e(T, B, H, device=dev))
     buf('dHA', _e(T, B, H, device=dev))
     buf('dctx_all', _z(T + 1, B, Dm, device=dev))

@@ -162,6 +162,10 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_kernel(AttnStepArgs p) 
         float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int k = 0; k < ng; ++k) { const float4 v4 = part4[k * nc4 + tid]; t.x += v4.x; t.y += v4.y; t.z += v4.z; t.w += v4.w; }
         *reinterpret_cast<float4*>(p.ctx_out + (long)b * Dm + d0 + tid * 4) = t;
+        if (p.ctx_pack_out) {       // MFMA tile order copy: row b, columns d .. d+3 are exactly one lane's float4
+            const int d = d0 + tid * 4;
+            *reinterpret_cast<float4*>(p.ctx_pack_out + ((((long)(b >> 4) * (Dm >> 4) + (d >> 4)) * 64) + 4 * (d & 12) + (b & 15)) * 4) = t;
+        }
     }
 
     // ---- PL for the next step, rows [l0, l1)
@@ -253,6 +257,10 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_generic_kernel(AttnStep
                 float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
                 for (int k = 0; k < ng; ++k) { const float4 v4 = part4[k * nc4 + tid]; t.x += v4.x; t.y += v4.y; t.z += v4.z; t.w += v4.w; }
                 *reinterpret_cast<float4*>(p.ctx_out + (long)b * Dm + d0 + tid * 4) = t;
+                if (p.ctx_pack_out) {
+                    const int d = d0 + tid * 4;
+                    *reinterpret_cast<float4*>(p.ctx_pack_out + ((((long)(b >> 4) * (Dm >> 4) + (d >> 4)) * 64) + 4 * (d & 12) + (b & 15)) * 4) = t;
+                }
             }
         }
     }

@@ -23,6 +23,17 @@ static void lstm_reg(const DecoderArgs& a, SkinnyArgs& k, const uint8_t* hmask, 
     }
 }
 
+// Operand descriptors: MFMA-tile-order ("packed") copies are used whenever the caller provided them.
+static inline int bp16(int B) { return (B + 15) & ~15; }
+static SkSeg seg_h(const float* rowmajor, const float* packed, int t, int B, int K, const float* w, const float* wp, int ldw) {
+    SkSeg s; memset(&s, 0, sizeof(s));
+    s.K = K;
+    if (packed) { s.x = packed + (long)t * bp16(B) * K; s.xpack = 1; s.ldx = K; }
+    else { s.x = rowmajor + (long)t * B * K; s.ldx = K; }
+    if (wp) { s.w = wp; s.wpack = 1; s.ldw = K; } else { s.w = w; s.ldw = ldw; }
+    return s;
+}
+
 // Chain B of the fast schedule for steps [c0, c1): generator-LSTM input gates (batched), the recurrent steps and the
 // frame/stop projection (batched).  Runs on its own low-priority stream behind chain A (see side_stream()).
 static int gen_chunk(const DecoderArgs& a, int c0, int c1, hipStream_t s) {
@@ -40,12 +51,13 @@ static int gen_chunk(const DecoderArgs& a, int c0, int c1, hipStream_t s) {
     for (int t = c0; t < c1; ++t) {
         SkinnyArgs k; memset(&k, 0, sizeof(k));
         k.B = B; k.N = 4 * H; k.ksplit = 1; k.lstm = 1; k.H = H; k.nseg = 1;
-        k.seg[0] = SkSeg{a.h_gen + t * BH, a.gen_w_hh, H, H, H};
+        k.seg[0] = seg_h(a.h_gen, a.h_gen_p, t, B, H, a.gen_w_hh, a.gen_w_hh_p, H);
         k.pre = a.pre_gen + t * B4H; k.ldpre = 4 * H;
         k.b_ih = a.gen_b_ih; k.b_hh = a.gen_b_hh;
         k.h_prev = a.h_gen + t * BH; k.c_prev = a.c_gen + t * BH;
         k.h_out = a.h_gen + (t + 1) * BH; k.c_out = a.c_gen + (t + 1) * BH;
         k.gates_out = a.gates_gen ? a.gates_gen + t * B4H : nullptr;
+        k.h_pack_out = a.h_gen_p ? a.h_gen_p + (long)(t + 1) * bp16(B) * H : nullptr;
         lstm_reg(a, k, a.gen_hmask, a.gen_cmask, t);
         MTTS_TRY(skinny_launch(k, s));
     }
@@ -77,6 +89,10 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
         MTTS_TRY(gemm_plain(a.w_loc, a.w_conv, a.U, A, a.ksz, a.C, a.C, a.ksz, a.ksz, false, true, 1.f, 0.f, nullptr, 0, s));
         MTTS_TRY(gemm_plain(a.memory, a.w_memory, a.Mt, B * L, A, Dm, Dm, Dm, A, false, false, 1.f, 0.f, nullptr, 0, s));
         MTTS_TRY(attn_pl_init(a.Mt, a.att_bias, a.PL, BL * A, A, s));
+        if (a.att_w_ctx_p) MTTS_TRY(mtts_pack_weight(a.att_w_ih + P, P + Dm, 4 * H, Dm, H, a.att_w_ctx_p, s));
+        if (a.att_w_hh_p) MTTS_TRY(mtts_pack_weight(a.att_w_hh, H, 4 * H, H, H, a.att_w_hh_p, s));
+        if (a.gen_w_hh_p) MTTS_TRY(mtts_pack_weight(a.gen_w_hh, H, 4 * H, H, H, a.gen_w_hh_p, s));
+        if (a.w_query_p) MTTS_TRY(mtts_pack_weight(a.w_query, H, A, H, 0, a.w_query_p, s));
     }
 
     // prenet over the teacher frames of this range (tacotron2.py:126-133)
@@ -111,8 +127,8 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
             for (int i = 0; i < a.n_prenet; ++i) {
                 SkinnyArgs k; memset(&k, 0, sizeof(k));
                 k.nseg = 1; k.B = B; k.N = P; k.ksplit = 1;
-                if (i == 0) k.seg[0] = SkSeg{a.out + (long)t * B * Mo, a.prenet_w[0], M, Mo, M};
-                else k.seg[0] = SkSeg{a.prenet_act[i - 1] + t * BP, a.prenet_w[i], P, P, P};
+                if (i == 0) k.seg[0] = SkSeg{a.out + (long)t * B * Mo, a.prenet_w[0], M, Mo, M, 0, 0};
+                else k.seg[0] = SkSeg{a.prenet_act[i - 1] + t * BP, a.prenet_w[i], P, P, P, 0, 0};
                 k.out = a.prenet_act[i] + t * BP; k.ldo = P; k.bias = a.prenet_b[i]; k.act = MTTS_ACT_RELU;
                 if (a.prenet_mask[i] && a.p_prenet > 0.f) { k.mask = a.prenet_mask[i] + t * BP; k.ldmask = P; k.mask_scale = pscale; }
                 MTTS_TRY(skinny_launch(k, s));
@@ -123,19 +139,20 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
             k.B = B; k.N = 4 * H; k.ksplit = 1; k.lstm = 1; k.H = H;
             if (a.fast) {
                 k.nseg = 2;
-                k.seg[0] = SkSeg{a.ctx + t * BD, a.att_w_ih + P, Dm, Dm, P + Dm};
-                k.seg[1] = SkSeg{a.h_att + t * BH, a.att_w_hh, H, H, H};
+                k.seg[0] = seg_h(a.ctx, a.ctx_p, t, B, Dm, a.att_w_ih + P, a.att_w_ctx_p, P + Dm);
+                k.seg[1] = seg_h(a.h_att, a.h_att_p, t, B, H, a.att_w_hh, a.att_w_hh_p, H);
                 k.pre = a.pre_att + t * B4H; k.ldpre = 4 * H;
             } else {
                 k.nseg = 3;
-                k.seg[0] = SkSeg{pren + t * BP, a.att_w_ih, P, P, P + Dm};
-                k.seg[1] = SkSeg{a.ctx + t * BD, a.att_w_ih + P, Dm, Dm, P + Dm};
-                k.seg[2] = SkSeg{a.h_att + t * BH, a.att_w_hh, H, H, H};
+                k.seg[0] = SkSeg{pren + t * BP, a.att_w_ih, P, P, P + Dm, 0, 0};
+                k.seg[1] = seg_h(a.ctx, a.ctx_p, t, B, Dm, a.att_w_ih + P, a.att_w_ctx_p, P + Dm);
+                k.seg[2] = seg_h(a.h_att, a.h_att_p, t, B, H, a.att_w_hh, a.att_w_hh_p, H);
             }
             k.b_ih = a.att_b_ih; k.b_hh = a.att_b_hh;
             k.h_prev = a.h_att + t * BH; k.c_prev = a.c_att + t * BH;
             k.h_out = a.h_att + (t + 1) * BH; k.c_out = a.c_att + (t + 1) * BH;
             k.gates_out = a.gates_att ? a.gates_att + t * B4H : nullptr;
+            k.h_pack_out = a.h_att_p ? a.h_att_p + (long)(t + 1) * bp16(B) * H : nullptr;
             lstm_reg(a, k, a.att_hmask, a.att_cmask, t);
             const bool sampled = prof_sample(t, s, 0);
             MTTS_TRY(skinny_launch(k, s));
@@ -144,7 +161,7 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
         {   // query projection partials (attention.py:68)
             SkinnyArgs k; memset(&k, 0, sizeof(k));
             k.nseg = 1; k.B = B; k.N = A; k.ksplit = a.kq;
-            k.seg[0] = SkSeg{a.h_att + (t + 1) * BH, a.w_query, H, H, H};
+            k.seg[0] = seg_h(a.h_att, a.h_att_p, t + 1, B, H, a.w_query, a.w_query_p, H);
             k.out = a.qpart; k.ldo = A; k.out_ks = (long)B * A;
             MTTS_TRY(skinny_launch(k, s));
         }
@@ -156,6 +173,7 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
             q.cum_in = a.cum + t * BL; q.cum_out = a.cum + (t + 1) * BL; q.w_out = a.align + t * BL;
             q.ctx_out = a.ctx + (t + 1) * BD;
             q.q_out = a.q_all ? a.q_all + (long)t * B * A : nullptr;
+            q.ctx_pack_out = a.ctx_p ? a.ctx_p + (long)(t + 1) * bp16(B) * Dm : nullptr;
             q.B = B; q.L = L; q.A = A; q.Dm = Dm; q.ksz = a.ksz;
             q.nch = (Dm + 511) / 512; if (q.nch < 4 && B * 4 <= 1024) q.nch = 4;
             MTTS_TRY(attn_step_launch(q, s));
@@ -164,21 +182,22 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
             {   // generator LSTM (tacotron2.py:187-188)
                 SkinnyArgs k; memset(&k, 0, sizeof(k));
                 k.B = B; k.N = 4 * H; k.ksplit = 1; k.lstm = 1; k.H = H; k.nseg = 3;
-                k.seg[0] = SkSeg{a.h_att + (t + 1) * BH, a.gen_w_ih, H, H, H + Dm};
-                k.seg[1] = SkSeg{a.ctx + (t + 1) * BD, a.gen_w_ih + H, Dm, Dm, H + Dm};
-                k.seg[2] = SkSeg{a.h_gen + t * BH, a.gen_w_hh, H, H, H};
+                k.seg[0] = seg_h(a.h_att, a.h_att_p, t + 1, B, H, a.gen_w_ih, nullptr, H + Dm);
+                k.seg[1] = seg_h(a.ctx, a.ctx_p, t + 1, B, Dm, a.gen_w_ih + H, nullptr, H + Dm);
+                k.seg[2] = seg_h(a.h_gen, a.h_gen_p, t, B, H, a.gen_w_hh, a.gen_w_hh_p, H);
                 k.b_ih = a.gen_b_ih; k.b_hh = a.gen_b_hh;
                 k.h_prev = a.h_gen + t * BH; k.c_prev = a.c_gen + t * BH;
                 k.h_out = a.h_gen + (t + 1) * BH; k.c_out = a.c_gen + (t + 1) * BH;
                 k.gates_out = a.gates_gen ? a.gates_gen + t * B4H : nullptr;
+                k.h_pack_out = a.h_gen_p ? a.h_gen_p + (long)(t + 1) * bp16(B) * H : nullptr;
                 lstm_reg(a, k, a.gen_hmask, a.gen_cmask, t);
                 MTTS_TRY(skinny_launch(k, s));
             }
             {   // frame + stop projection (tacotron2.py:191-193)
                 SkinnyArgs k; memset(&k, 0, sizeof(k));
                 k.nseg = 2; k.B = B; k.N = M + 1; k.ksplit = 1;
-                k.seg[0] = SkSeg{a.h_gen + (t + 1) * BH, a.w_out, H, H, H + Dm};
-                k.seg[1] = SkSeg{a.ctx + (t + 1) * BD, a.w_out + H, Dm, Dm, H + Dm};
+                k.seg[0] = seg_h(a.h_gen, a.h_gen_p, t + 1, B, H, a.w_out, nullptr, H + Dm);
+                k.seg[1] = seg_h(a.ctx, a.ctx_p, t + 1, B, Dm, a.w_out + H, nullptr, H + Dm);
                 k.out = a.out + (long)(t + 1) * B * Mo; k.ldo = Mo; k.bias = a.b_out;
                 MTTS_TRY(skinny_launch(k, s));
             }
@@ -207,7 +226,7 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
         for (int t = a.t0; t < a.t1; ++t) {
             SkinnyArgs k; memset(&k, 0, sizeof(k));
             k.B = B; k.N = 4 * H; k.ksplit = 1; k.lstm = 1; k.H = H; k.nseg = 1;
-            k.seg[0] = SkSeg{a.h_gen + t * BH, a.gen_w_hh, H, H, H};
+            k.seg[0] = SkSeg{a.h_gen + t * BH, a.gen_w_hh, H, H, H, 0, 0};
             k.pre = a.pre_gen + t * B4H; k.ldpre = 4 * H;
             k.b_ih = a.gen_b_ih; k.b_hh = a.gen_b_hh;
             k.h_prev = a.h_gen + t * BH; k.c_prev = a.c_gen + t * BH;
@@ -241,7 +260,7 @@ MTTS_API int mtts_bilstm_fwd(const BiLstmArgs* args, void* stream) {
             const int s_in = d == 0 ? t : t + 1, s_out = d == 0 ? t + 1 : t;
             SkinnyArgs k; memset(&k, 0, sizeof(k));
             k.B = B; k.N = 4 * H; k.ksplit = 1; k.lstm = 1; k.H = H; k.nseg = 1;
-            k.seg[0] = SkSeg{a.h[d] + s_in * BH, a.w_hh[d], H, H, H};
+            k.seg[0] = SkSeg{a.h[d] + s_in * BH, a.w_hh[d], H, H, H, 0, 0};
             k.pre = a.xproj[d] + (long)t * 4 * BH; k.ldpre = 4 * H;
             k.b_ih = a.b_ih[d]; k.b_hh = a.b_hh[d];
             k.h_prev = a.h[d] + s_in * BH; k.c_prev = a.c[d] + s_in * BH;

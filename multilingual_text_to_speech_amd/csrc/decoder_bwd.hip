@@ -41,6 +41,9 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
     MTTS_TRY(transpose2d(a.att_w_hh, g.att_w_rec_T + (long)Dm * 4 * H, 4 * H, H, s));
     MTTS_TRY(transpose2d(a.gen_w_hh, g.gen_w_hh_T, 4 * H, H, s));
     MTTS_TRY(transpose2d(a.w_query, g.w_query_T, A, H, s));
+    if (g.att_w_rec_Tp) MTTS_TRY(mtts_pack_weight(g.att_w_rec_T, 4 * H, Dm + H, 4 * H, 0, g.att_w_rec_Tp, s));
+    if (g.gen_w_hh_Tp) MTTS_TRY(mtts_pack_weight(g.gen_w_hh_T, 4 * H, H, 4 * H, 0, g.gen_w_hh_Tp, s));
+    const long Bp4H = (long)((B + 15) & ~15) * 4 * H;
 
     const float* dout1 = g.dout + (long)B * Mo;      // slot 1 = step 0
     // ---- projection backward (batched): dHG = dout W_out[:, :H],  dctx_all[1:] = dout W_out[:, H:]
@@ -69,12 +72,15 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
             k.gates = a.gates_gen + t * B4H; k.c_prev = a.c_gen + t * BH;
             k.dc_in = g.dc_gen + ((t + 1) & 1) * BH; k.dc_out = g.dc_gen + (t & 1) * BH;
             k.dgates_out = g.dG_gen + t * B4H; k.ld_dgates = 4 * H;
+            k.dg_pack_out = g.dG_gen_p ? g.dG_gen_p + t * Bp4H : nullptr;
             bwd_reg(a, k, a.gen_hmask, a.gen_cmask, t);
             MTTS_TRY(skinny_launch(k, sb));
             if (t > 0) {
                 SkinnyArgs q; memset(&q, 0, sizeof(q));
                 q.nseg = 1; q.B = B; q.N = H; q.ksplit = ksb;
-                q.seg[0] = SkSeg{g.dG_gen + t * B4H, g.gen_w_hh_T, 4 * H, 4 * H, 4 * H};
+                q.seg[0] = SkSeg{g.dG_gen + t * B4H, g.gen_w_hh_T, 4 * H, 4 * H, 4 * H, 0, 0};
+                if (g.dG_gen_p) { q.seg[0].x = g.dG_gen_p + t * Bp4H; q.seg[0].xpack = 1; }
+                if (g.gen_w_hh_Tp) { q.seg[0].w = g.gen_w_hh_Tp; q.seg[0].wpack = 1; }
                 q.out = g.part_gen; q.ldo = H; q.out_ks = BH;
                 MTTS_TRY(skinny_launch(q, sb));
             }
@@ -120,19 +126,22 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
         {   // dh_att_t = dq W_q + dHA[t] + (recurrent part of step t+1) -> cell backward
             SkinnyArgs k; memset(&k, 0, sizeof(k));
             k.B = B; k.H = H; k.lstm = 2; k.nseg = 1; k.ksplit = 1;
-            k.seg[0] = SkSeg{g.dq_all + t * BA, g.w_query_T, A, A, A};
+            k.seg[0] = SkSeg{g.dq_all + t * BA, g.w_query_T, A, A, A, 0, 0};
             k.dh_a = g.dHA + t * BH; k.ld_dh_a = H;
             if (t < T - 1) { k.part = g.part_att; k.n_part = ksb; k.part_ks = (long)B * (Dm + H); k.part_ld = Dm + H; k.part_col0 = Dm; }
             k.gates = a.gates_att + t * B4H; k.c_prev = a.c_att + t * BH;
             k.dc_in = g.dc_att + ((t + 1) & 1) * BH; k.dc_out = g.dc_att + (t & 1) * BH;
             k.dgates_out = g.dG_att + t * B4H; k.ld_dgates = 4 * H;
+            k.dg_pack_out = g.dG_att_p ? g.dG_att_p + t * Bp4H : nullptr;
             bwd_reg(a, k, a.att_hmask, a.att_cmask, t);
             MTTS_TRY(skinny_launch(k, s));
         }
         if (t > 0) {   // d[ctx_{t-1}, h_att_{t-1}] = dG_att_t [W_ih[:, P:] | W_hh]
             SkinnyArgs q; memset(&q, 0, sizeof(q));
             q.nseg = 1; q.B = B; q.N = Dm + H; q.ksplit = ksb;
-            q.seg[0] = SkSeg{g.dG_att + t * B4H, g.att_w_rec_T, 4 * H, 4 * H, 4 * H};
+            q.seg[0] = SkSeg{g.dG_att + t * B4H, g.att_w_rec_T, 4 * H, 4 * H, 4 * H, 0, 0};
+            if (g.dG_att_p) { q.seg[0].x = g.dG_att_p + t * Bp4H; q.seg[0].xpack = 1; }
+            if (g.att_w_rec_Tp) { q.seg[0].w = g.att_w_rec_Tp; q.seg[0].wpack = 1; }
             q.out = g.part_att; q.ldo = Dm + H; q.out_ks = (long)B * (Dm + H);
             MTTS_TRY(skinny_launch(q, s));
         }
@@ -219,7 +228,7 @@ MTTS_API int mtts_bilstm_bwd(const BiLstmArgs* fwd, const BiLstmGradArgs* grad, 
             if (st > 0) {
                 SkinnyArgs q; memset(&q, 0, sizeof(q));
                 q.nseg = 1; q.B = B; q.N = H; q.ksplit = g.ksb;
-                q.seg[0] = SkSeg{g.dxproj[d] + (long)t * B4H, g.w_hh_T[d], 4 * H, 4 * H, 4 * H};
+                q.seg[0] = SkSeg{g.dxproj[d] + (long)t * B4H, g.w_hh_T[d], 4 * H, 4 * H, 4 * H, 0, 0};
                 q.out = g.part; q.ldo = H; q.out_ks = BH;
                 MTTS_TRY(skinny_launch(q, s));
             }

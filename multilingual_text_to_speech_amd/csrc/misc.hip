@@ -171,3 +171,42 @@ int relu_mask_bwd(const float* dy, const float* y, float* dz, long n, float scal
 MTTS_API int mtts_relu_mask_bwd(const float* dy, const float* y, float* dz, long n, float scale, void* stream) {
     return relu_mask_bwd(dy, y, dz, n, scale, (hipStream_t)stream);
 }
+
+// ---- MFMA tile order ("packed") copies: [tiles][K/16][64 lanes][4]; lane 16q+i <-> row 16*tile+i, columns 16c+4q..+3 ----
+__global__ void pack_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int ld, int N, int K, int lstm_H, int ntile) {
+    const int nc = K >> 4;
+    const long total = (long)ntile * nc * 64;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        const long tc = i >> 6;
+        const int c = (int)(tc % nc), cb = (int)(tc / nc);
+        const int j = lane & 15, q = lane >> 4;
+        int row; bool ok;
+        if (lstm_H > 0) { const int u = cb * 4 + (j & 3); row = (j >> 2) * lstm_H + u; ok = u < lstm_H; }
+        else { row = cb * 16 + j; ok = row < N; }
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) {
+            const float* sp = src + (long)row * ld + c * 16 + 4 * q;
+            v = make_float4(sp[0], sp[1], sp[2], sp[3]);
+        }
+        *reinterpret_cast<float4*>(dst + i * 4) = v;
+    }
+}
+
+MTTS_API int mtts_pack_weight(const float* src, int ld, int N, int K, int lstm_H, float* dst, void* stream) {
+    MTTS_REQUIRE((K & 15) == 0, "mtts_pack_weight: K = %d must be a multiple of 16", K);
+    const int ntile = lstm_H > 0 ? cdiv(lstm_H, 4) : cdiv(N, 16);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(nblocks((long)ntile * (K >> 4) * 64)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                       ld, N, K, lstm_H, ntile);
+    MTTS_CHECK_LAUNCH("pack_weight");
+    return 0;
+}
+
+MTTS_API int mtts_pack_rows(const float* src, int ld, int rows, int K, float* dst, void* stream) {
+    MTTS_REQUIRE((K & 15) == 0, "mtts_pack_rows: K = %d must be a multiple of 16", K);
+    const int ntile = cdiv(rows, 16);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(nblocks((long)ntile * (K >> 4) * 64)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                       ld, rows, K, 0, ntile);
+    MTTS_CHECK_LAUNCH("pack_rows");
+    return 0;
+}

@@ -29,7 +29,7 @@ constexpr int NW = 8;                 // waves per workgroup
 constexpr int NT = NW * 64;
 
 template <int MT>
-struct Frag { float4 w; float4 x[MT]; };
+struct Frag { float4 w; float4 x[MT]; bool xp, wp; };   // xp/wp: operand already in MFMA tile order (wave-uniform)
 
 // Segment table held in registers (SGPRs): copied field-by-field from the kernel argument so that the
 // compiler never needs the argument struct in memory (address-selects on it would force a scratch copy).
@@ -37,7 +37,9 @@ struct SegTab {
     const float* x0; const float* x1; const float* x2;
     const float* w0; const float* w1; const float* w2;
     int K0, K1, K2, ldx0, ldx1, ldx2, ldw0, ldw1, ldw2;
-    int n0, n1, total;
+    int xp0, xp1, xp2, wp0, wp1, wp2;     // packed-operand flags per segment
+    int n0, n1, n2, total;
+    int cb, mt0;                          // column block / first absolute 16-row tile of this workgroup
 };
 
 // Loads are QUAD-COALESCED: lane l fetches 16 B of row (l >> 2) at k-quad (l & 3), so four consecutive lanes cover
@@ -46,9 +48,9 @@ struct SegTab {
 // requests per instruction, and the texture-address unit becomes the bottleneck: 18 us -> 12.5 us per LSTM step.)
 // The MFMA layout is restored in registers with ds_bpermute when the fragment is consumed.
 template <int MT>
-__device__ __forceinline__ void sk_load(const SegTab t, int c, const int (&rows)[MT], int wrow, int kq, Frag<MT>& f) {
+__device__ __forceinline__ void sk_load(const SegTab t, int c, const int (&rows)[MT], int wrow, int kq, int lane, Frag<MT>& f) {
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    f.w = z;
+    f.w = z; f.xp = true; f.wp = true;
 #pragma unroll
     for (int m = 0; m < MT; ++m) f.x[m] = z;
     if (c >= t.total) return;                       // wave-uniform
@@ -59,16 +61,30 @@ __device__ __forceinline__ void sk_load(const SegTab t, int c, const int (&rows)
     const int sK = in0 ? t.K0 : (in1 ? t.K1 : t.K2);
     const int ldx = in0 ? t.ldx0 : (in1 ? t.ldx1 : t.ldx2);
     const int ldw = in0 ? t.ldw0 : (in1 ? t.ldw1 : t.ldw2);
-    const int k0 = (in0 ? c : (in1 ? c - t.n0 : c - t.n0 - t.n1)) * 16;
-    const int k = k0 + kq * 4;
+    const int xp = in0 ? t.xp0 : (in1 ? t.xp1 : t.xp2);
+    const int wp = in0 ? t.wp0 : (in1 ? t.wp1 : t.wp2);
+    const int nc = in0 ? t.n0 : (in1 ? t.n1 : t.n2);
+    const int cs = in0 ? c : (in1 ? c - t.n0 : c - t.n0 - t.n1);      // chunk within its segment
+    const int k = cs * 16 + kq * 4;
     const bool ok = k < sK;
     const int kc = ok ? k : 0;
-    const float4 wv = *reinterpret_cast<const float4*>(sw + (long)wrow * ldw + kc);
-    f.w = ok ? wv : z;
+    f.xp = xp != 0; f.wp = wp != 0;
+    if (wp) {       // 1 KiB contiguous tile, already in MFMA operand order
+        f.w = *reinterpret_cast<const float4*>(sw + (((long)t.cb * nc + cs) * 64 + lane) * 4);
+    } else {
+        const float4 wv = *reinterpret_cast<const float4*>(sw + (long)wrow * ldw + kc);
+        f.w = ok ? wv : z;
+    }
+    if (xp) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const float4 xv = *reinterpret_cast<const float4*>(sx + (long)rows[m] * ldx + kc);
-        f.x[m] = ok ? xv : z;
+        for (int m = 0; m < MT; ++m)
+            f.x[m] = *reinterpret_cast<const float4*>(sx + (((long)(t.mt0 + m) * nc + cs) * 64 + lane) * 4);
+    } else {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const float4 xv = *reinterpret_cast<const float4*>(sx + (long)rows[m] * ldx + kc);
+            f.x[m] = ok ? xv : z;
+        }
     }
 }
 
@@ -78,11 +94,11 @@ __device__ __forceinline__ float4 to_mfma_layout(const float4 v, int src_lane) {
 
 template <int MT>
 __device__ __forceinline__ void sk_mma(const Frag<MT>& f, f32x4 (&acc)[MT], int src_lane) {
-    const float4 w4 = to_mfma_layout(f.w, src_lane);
+    const float4 w4 = f.wp ? f.w : to_mfma_layout(f.w, src_lane);
     const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        const float4 x4 = to_mfma_layout(f.x[m], src_lane);
+        const float4 x4 = f.xp ? f.x[m] : to_mfma_layout(f.x[m], src_lane);
         const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[s], wv[s], acc[m], 0, 0, 0);
@@ -174,6 +190,8 @@ __device__ __forceinline__ void fwd_cell(const SkinnyArgs& p, const float (&red)
     else ho = p.hmask ? (f.hm ? hn * p.hscale : 0.f) : hn;
     p.h_out[hi] = ho;
     p.c_out[hi] = co;
+    if (p.h_pack_out)      // MFMA tile order copy for the next step's X operand: lane 16*q + i, column 4*q + s of chunk u / 16
+        p.h_pack_out[((((long)(row >> 4) * (p.H >> 4) + (u >> 4)) * 64) + 4 * (u & 12) + (row & 15)) * 4 + (u & 3)] = ho;
     if (p.y_out) p.y_out[(long)row * p.ldy + u] = carried ? 0.f : ho;
 }
 
@@ -200,10 +218,15 @@ __device__ __forceinline__ void bwd_cell(const SkinnyArgs& p, const float (&red)
     const float d_o = dhn * th;
     const float dct = dcn + dhn * og * (1.f - th * th);
     float* dg = p.dgates_out + (long)row * p.ld_dgates + u;
-    dg[0] = dct * gg * ig * (1.f - ig);
-    dg[p.H] = dct * cp * fg * (1.f - fg);
-    dg[2 * p.H] = dct * ig * (1.f - gg * gg);
-    dg[3 * p.H] = d_o * og * (1.f - og);
+    const float dgv[4] = {dct * gg * ig * (1.f - ig), dct * cp * fg * (1.f - fg), dct * ig * (1.f - gg * gg), d_o * og * (1.f - og)};
+    dg[0] = dgv[0]; dg[p.H] = dgv[1]; dg[2 * p.H] = dgv[2]; dg[3 * p.H] = dgv[3];
+    if (p.dg_pack_out) {
+        const long tile = (long)(row >> 4) * (p.H >> 2);           // 4H / 16 chunks per row tile
+        const int lane_s = (4 * (u & 12) + (row & 15)) * 4 + (u & 3);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            p.dg_pack_out[(tile + ((g * p.H + u) >> 4)) * 256 + lane_s] = dgv[g];
+    }
     p.dc_out[hi] = dct * fg + dc_carry;
     if (p.dh_carry_out) p.dh_carry_out[hi] = dh_carry;
 }
@@ -257,11 +280,14 @@ __global__ __launch_bounds__(NT) void skinny_kernel(SkinnyArgs p) {
     t.K0 = p.seg[0].K; t.K1 = p.seg[1].K; t.K2 = p.seg[2].K;
     t.ldx0 = p.seg[0].ldx; t.ldx1 = p.seg[1].ldx; t.ldx2 = p.seg[2].ldx;
     t.ldw0 = p.seg[0].ldw; t.ldw1 = p.seg[1].ldw; t.ldw2 = p.seg[2].ldw;
+    t.xp0 = p.seg[0].xpack; t.xp1 = p.seg[1].xpack; t.xp2 = p.seg[2].xpack;
+    t.wp0 = p.seg[0].wpack; t.wp1 = p.seg[1].wpack; t.wp2 = p.seg[2].wpack;
+    t.cb = cb; t.mt0 = blockIdx.y * MT;
     const int nseg = p.nseg;
     t.n0 = (t.K0 + 15) >> 4;
     t.n1 = nseg > 1 ? (t.K1 + 15) >> 4 : 0;
-    const int n2 = nseg > 2 ? (t.K2 + 15) >> 4 : 0;
-    t.total = t.n0 + t.n1 + n2;
+    t.n2 = nseg > 2 ? (t.K2 + 15) >> 4 : 0;
+    t.total = t.n0 + t.n1 + t.n2;
     const int total = t.total;
 
     f32x4 acc[MT];
@@ -273,19 +299,19 @@ __global__ __launch_bounds__(NT) void skinny_kernel(SkinnyArgs p) {
     int c = ks * NW + wave;
     if (c < total) {
         Frag<MT> f0, f1, f2, f3;
-        sk_load<MT>(t, c, rows, wrow, kq4, f0);
-        sk_load<MT>(t, c + step, rows, wrow, kq4, f1);
-        sk_load<MT>(t, c + 2 * step, rows, wrow, kq4, f2);
-        sk_load<MT>(t, c + 3 * step, rows, wrow, kq4, f3);
+        sk_load<MT>(t, c, rows, wrow, kq4, lane, f0);
+        sk_load<MT>(t, c + step, rows, wrow, kq4, lane, f1);
+        sk_load<MT>(t, c + 2 * step, rows, wrow, kq4, lane, f2);
+        sk_load<MT>(t, c + 3 * step, rows, wrow, kq4, lane, f3);
         for (; c < total; c += 4 * step) {
             sk_mma<MT>(f0, acc, src_lane);
-            sk_load<MT>(t, c + 4 * step, rows, wrow, kq4, f0);
+            sk_load<MT>(t, c + 4 * step, rows, wrow, kq4, lane, f0);
             sk_mma<MT>(f1, acc, src_lane);
-            sk_load<MT>(t, c + 5 * step, rows, wrow, kq4, f1);
+            sk_load<MT>(t, c + 5 * step, rows, wrow, kq4, lane, f1);
             sk_mma<MT>(f2, acc, src_lane);
-            sk_load<MT>(t, c + 6 * step, rows, wrow, kq4, f2);
+            sk_load<MT>(t, c + 6 * step, rows, wrow, kq4, lane, f2);
             sk_mma<MT>(f3, acc, src_lane);
-            sk_load<MT>(t, c + 7 * step, rows, wrow, kq4, f3);
+            sk_load<MT>(t, c + 7 * step, rows, wrow, kq4, lane, f3);
         }
     }
 
@@ -340,7 +366,7 @@ int skinny_launch(const SkinnyArgs& p, hipStream_t s) {
     MTTS_REQUIRE(p.n_part <= MAX_PART, "skinny: at most %d partial slabs", MAX_PART);
     const int ks = p.ksplit < 1 ? 1 : p.ksplit;
     SkinnyArgs q = p; q.ksplit = ks;
-    if (p.nseg == 0) { q.seg[0] = SkSeg{p.gates, p.gates, 0, 0, 0}; q.nseg = 1; }   // pure pointwise: empty K range
+    if (p.nseg == 0) { q.seg[0] = SkSeg{p.gates, p.gates, 0, 0, 0, 0, 0}; q.nseg = 1; }   // pure pointwise: empty K range
     for (int i = q.nseg; i < 3; ++i) q.seg[i] = q.seg[0];      // keep the unused selectors dereferenceable
     if (p.lstm == 2) q.N = p.H;
     if (p.lstm == 1 && !q.h_prev) q.h_prev = q.c_prev;

@@ -36,6 +36,16 @@ class DecoderState:
         self.pre_att = e(T, B, 4 * H) if fast else None
         self.pre_gen = e(T, B, 4 * H) if fast else None
         self.q_all = e(T, B, A) if save_gates else None
+        # MFMA-tile-order copies of the recurrent operands (only when the widths are multiples of 16)
+        Bp = (B + 15) & ~15
+        hp_ok, dp_ok = H % 16 == 0, Dm % 16 == 0
+        self.h_att_p = z(T + 1, Bp * H) if hp_ok else None
+        self.h_gen_p = z(T + 1, Bp * H) if hp_ok else None
+        self.ctx_p = z(T + 1, Bp * Dm) if dp_ok else None
+        self.att_w_ctx_p = e(4 * H * Dm) if (dp_ok and H % 4 == 0) else None
+        self.att_w_hh_p = e(4 * H * H) if hp_ok else None
+        self.gen_w_hh_p = e(4 * H * H) if hp_ok else None
+        self.w_query_p = e(((A + 15) & ~15) * H) if hp_ok else None
 
 
 def fill_decoder_args(a, st, w, memory, lengths32, frames_in, teacher_host, masks, cfg):
@@ -58,7 +68,8 @@ def fill_decoder_args(a, st, w, memory, lengths32, frames_in, teacher_host, mask
     a.att_hmask, a.att_cmask = ptr(masks.get('att_h')), ptr(masks.get('att_c'))
     a.gen_hmask, a.gen_cmask = ptr(masks.get('gen_h')), ptr(masks.get('gen_c'))
     for name in ('U', 'Mt', 'PL', 'qpart', 'h_att', 'c_att', 'h_gen', 'c_gen', 'ctx', 'cum', 'align', 'gates_att', 'gates_gen',
-                 'out', 'pre_att', 'pre_gen', 'q_all'):
+                 'out', 'pre_att', 'pre_gen', 'q_all', 'h_att_p', 'h_gen_p', 'ctx_p', 'att_w_ctx_p', 'att_w_hh_p', 'gen_w_hh_p',
+                 'w_query_p'):
         setattr(a, name, ptr(getattr(st, name)))
     a.kq, a.fast = st.kq, int(st.fast)
     return a
