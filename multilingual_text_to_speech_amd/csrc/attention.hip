@@ -36,15 +36,28 @@ static inline size_t att_lds_bytes(int A, int L, int ksz) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// fast kernel: all global loads up front
+// fast kernel: all global loads up front; energies reduced with DPP; the location filter bank runs on MFMA
+//   loc[l, a] = sum_k cumwin[l][k] * U[a][k]   (rows of this workgroup x A x 32 taps  ->  v_mfma_f32_16x16x4_f32)
+// Wave w owns attention columns [16w, 16w+16) (A <= 128) for both 16-row tiles of the chunk.
 // ------------------------------------------------------------------------------------------------------------
+constexpr int UP_LD = 36;     // filter-bank row: 32 taps + 4 pad floats (conflict-free ds_read_b128)
+constexpr int NE4_MAX = 8;    // PL float4 per thread (L*A/4 <= NE4_MAX * ATT_THREADS)
+
+template <int G>              // G = A / 4 lanes cover one position's A values (16 or 32)
 __global__ __launch_bounds__(ATT_THREADS) void attn_step_kernel(AttnStepArgs p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x, ch = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int L = p.L, A = p.A, Dm = p.Dm, ksz = p.ksz, pad = (ksz - 1) / 2;
-    const AttLds s = att_carve(sm, A, L, ksz);
-    const int LA = L * A;
+    float* q = sm;                       // [A]
+    float* vv = q + A;                   // [A]
+    float* bias = vv + A;                // [A]
+    float* w = bias + A;                 // [L]
+    float* cumw = w + L;                 // [L + 64]  cum_out with zero halo / slack for the 32-tap MFMA window
+    float* Up = sm + ((3 * A + 2 * L + 64 + 3) & ~3);          // [A][UP_LD]
+    float* part = Up + A * UP_LD;        // [4 * ATT_THREADS]
+    const int LA4 = (L * A) >> 2;
 
     // ---- geometry of this workgroup's shares
     const int dc = (((Dm + p.nch - 1) / p.nch) + 3) & ~3;
@@ -54,7 +67,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_kernel(AttnStepArgs p) 
     const int cg = nc4 > 0 ? tid / nc4 : ng, c4 = nc4 > 0 ? tid % nc4 : 0;
     const int lc = (L + p.nch - 1) / p.nch;
     const int l0 = ch * lc, l1 = min(L, l0 + lc);
-    const int nlA = max(0, l1 - l0) * A;
+    const int i16 = lane & 15, q4 = lane >> 4;
 
     // ---- burst of independent loads
     const int len = min(p.lengths[b], L);
@@ -67,11 +80,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_kernel(AttnStepArgs p) 
     const float v_r = p.v[min(tid, A - 1)];
     const float bias_r = p.bias[min(tid, A - 1)];
     const float cum_r = p.cum_in[(long)b * L + min(tid, L - 1)];
-    float pl[NE_MAX];
+    float4 pl4[NE4_MAX];
     {
-        const float* PLb = p.PL + (long)b * LA;
+        const float4* PLb = reinterpret_cast<const float4*>(p.PL + (long)b * L * A);
 #pragma unroll
-        for (int j = 0; j < NE_MAX; ++j) pl[j] = PLb[min(tid + j * ATT_THREADS, LA - 1)];
+        for (int j = 0; j < NE4_MAX; ++j) pl4[j] = PLb[min(tid + j * ATT_THREADS, LA4 - 1)];
     }
     float4 mem4[NC_MAX];
     {
@@ -82,11 +95,16 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_kernel(AttnStepArgs p) 
             mem4[j] = (nc4 > 0) ? *reinterpret_cast<const float4*>(mem + (long)l * Dm) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    float mt[NM_MAX], us[NU_MAX];
+    float mtD[2][4], us[NU_MAX];
+    const int a_own = min(16 * wave + i16, A - 1);
     if (p.PL_next) {
-        const float* Mb = p.Mt + ((long)b * L + l0) * A;
 #pragma unroll
-        for (int j = 0; j < NM_MAX; ++j) mt[j] = Mb[min(tid + j * ATT_THREADS, max(nlA - 1, 0))];
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int l = min(l0 + 16 * mt + 4 * q4 + r, L - 1);
+                mtD[mt][r] = p.Mt[((long)b * L + l) * A + a_own];
+            }
 #pragma unroll
         for (int j = 0; j < NU_MAX; ++j) us[j] = p.U[min(tid + j * ATT_THREADS, A * ksz - 1)];
     }
@@ -96,31 +114,31 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_kernel(AttnStepArgs p) 
         float qs = 0.f;
 #pragma unroll
         for (int k = 0; k < KQ_MAX; ++k) qs += qp[k];
-        s.q[tid] = qs; s.vv[tid] = v_r; s.bias[tid] = bias_r;
+        q[tid] = qs; vv[tid] = v_r; bias[tid] = bias_r;
         if (ch == 0 && p.q_out) p.q_out[(long)b * A + tid] = qs;
     }
-    if (tid < L) s.w[tid] = 0.f;
     if (p.PL_next) {
 #pragma unroll
-        for (int j = 0; j < NU_MAX; ++j) { const int i = tid + j * ATT_THREADS; if (i < A * ksz) s.Us[i] = us[j]; }
+        for (int j = 0; j < NU_MAX; ++j) {
+            const int i = tid + j * ATT_THREADS;
+            if (i < A * ksz) { const int a = i / ksz, jj = i - a * ksz; Up[a * UP_LD + jj] = us[j]; }
+        }
+        for (int i = tid; i < A * (UP_LD - ksz); i += ATT_THREADS) { const int a = i / (UP_LD - ksz), jj = ksz + i % (UP_LD - ksz); Up[a * UP_LD + jj] = 0.f; }
     }
     __syncthreads();
 
-    // ---- energies
-    if ((A & 63) == 0) {
+    // ---- energies: lane holds 4 consecutive attention channels of one position; G lanes cover the position
+    {
+        const int a0 = 4 * (tid % G);
+        const float4 q4v = *reinterpret_cast<const float4*>(q + a0);
+        const float4 v4v = *reinterpret_cast<const float4*>(vv + a0);
 #pragma unroll
-        for (int j = 0; j < NE_MAX; ++j) {
-            const int i = tid + j * ATT_THREADS;          // a wave's 64 elements share one position l
-            const int l = i / A, a = i - l * A;
-            float e = (i < LA) ? s.vv[a] * tanhf_(s.q[a] + pl[j]) : 0.f;
-            e = wave_sum(e);
-            if (lane == 0 && i < LA) atomicAdd(&s.w[l], e);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < NE_MAX; ++j) {
-            const int i = tid + j * ATT_THREADS;
-            if (i < LA) { const int l = i / A, a = i - l * A; atomicAdd(&s.w[l], s.vv[a] * tanhf_(s.q[a] + pl[j])); }
+        for (int j = 0; j < NE4_MAX; ++j) {
+            const int i4 = tid + j * ATT_THREADS;
+            float e = v4v.x * tanhf_(q4v.x + pl4[j].x) + v4v.y * tanhf_(q4v.y + pl4[j].y) + v4v.z * tanhf_(q4v.z + pl4[j].z) +
+                      v4v.w * tanhf_(q4v.w + pl4[j].w);
+            e = group_sum<G>(e);
+            if ((lane % G) == 0 && i4 < LA4) w[i4 / G] = e;
         }
     }
     __syncthreads();
@@ -128,31 +146,32 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_kernel(AttnStepArgs p) 
     // ---- masked softmax (wave 0), then the cumulative-alignment window
     if (tid < 64) {
         float mx = -INFINITY;
-        for (int l = lane; l < len; l += 64) mx = fmaxf(mx, s.w[l]);
+        for (int l = lane; l < len; l += 64) mx = fmaxf(mx, w[l]);
         mx = wave_max(mx);
         float sum = 0.f;
-        for (int l = lane; l < L; l += 64) { const float ex = (l < len) ? __expf(s.w[l] - mx) : 0.f; s.w[l] = ex; sum += ex; }
+        for (int l = lane; l < L; l += 64) { const float ex = (l < len) ? __expf(w[l] - mx) : 0.f; w[l] = ex; sum += ex; }
         sum = wave_sum(sum);
         const float inv = 1.f / sum;
-        for (int l = lane; l < L; l += 64) s.w[l] *= inv;
+        for (int l = lane; l < L; l += 64) w[l] *= inv;
     }
     __syncthreads();
     if (tid < L) {
-        const float wl = s.w[tid];
+        const float wl = w[tid];
         const float cn = cum_r + wl;
-        s.cumw[pad + tid] = cn;
+        cumw[pad + tid] = cn;
         if (ch == 0) { p.w_out[(long)b * L + tid] = wl; p.cum_out[(long)b * L + tid] = cn; }
     }
-    if (tid < pad) { s.cumw[tid] = 0.f; s.cumw[pad + L + tid] = 0.f; }
+    if (tid < pad) cumw[tid] = 0.f;
+    if (tid < 64 - pad) cumw[pad + L + tid] = 0.f;
 
     // ---- context columns of this chunk (memory rows are already in registers)
-    float4* part4 = reinterpret_cast<float4*>(s.part);
+    float4* part4 = reinterpret_cast<float4*>(part);
     {
         float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int j = 0; j < NC_MAX; ++j) {
             const int l = cg + j * ng;
-            const float wl = (cg < ng && l < L) ? s.w[l] : 0.f;
+            const float wl = (cg < ng && l < L) ? w[l] : 0.f;
             s4.x += wl * mem4[j].x; s4.y += wl * mem4[j].y; s4.z += wl * mem4[j].z; s4.w += wl * mem4[j].w;
         }
         part4[tid] = s4;
@@ -168,21 +187,30 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_kernel(AttnStepArgs p) 
         }
     }
 
-    // ---- PL for the next step, rows [l0, l1)
-    if (p.PL_next) {
-        float* out = p.PL_next + ((long)b * L + l0) * A;
+    // ---- PL for the next step, rows [l0, l1): loc = cumwin x U^T on MFMA, + M + bias
+    if (p.PL_next && 16 * wave < A) {
+        f32x4 acc[2];
+        acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < NM_MAX; ++j) {
-            const int i = tid + j * ATT_THREADS;
-            if (i < nlA) {
-                const int r = i / A, a = i - r * A;
-                float acc = mt[j] + s.bias[a];
-                const float* u = s.Us + a * ksz;
-                const float* cw = s.cumw + l0 + r;
-                for (int jj = 0; jj < ksz; ++jj) acc += u[jj] * cw[jj];
-                out[i] = acc;
+        for (int c = 0; c < 2; ++c) {
+            const float4 bf = *reinterpret_cast<const float4*>(Up + (16 * wave + i16) * UP_LD + 16 * c + 4 * q4);
+            const float bv[4] = {bf.x, bf.y, bf.z, bf.w};
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const float* cw = cumw + l0 + 16 * mt + i16 + 16 * c + 4 * q4;
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cw[s2], bv[s2], acc[mt], 0, 0, 0);
             }
         }
+        const int a = 16 * wave + i16;
+        const float bb = bias[min(a, A - 1)];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int l = l0 + 16 * mt + 4 * q4 + r;
+                if (l < l1 && a < A) p.PL_next[((long)b * L + l) * A + a] = acc[mt][r] + mtD[mt][r] + bb;
+            }
     }
 }
 
@@ -299,13 +327,16 @@ int attn_step_launch(const AttnStepArgs& p, hipStream_t s) {
     const int dc = (((p.Dm + p.nch - 1) / p.nch) + 3) & ~3;
     MTTS_REQUIRE(dc / 4 <= ATT_THREADS && (p.Dm & 3) == 0, "attn_step: Dm/nch = %d too wide or Dm %% 4 != 0", dc);
     const size_t lds = att_lds_bytes(p.A, p.L, p.ksz);
+    const size_t lds_fast = sizeof(float) * ((((size_t)3 * p.A + 2 * p.L + 64 + 3) & ~(size_t)3) + (size_t)p.A * UP_LD + 4 * ATT_THREADS);
     MTTS_REQUIRE(lds <= 64 * 1024, "attn_step: LDS request %zu too large", lds);
     const int nc4 = dc / 4, ng = nc4 > 0 ? (ATT_THREADS / nc4 > 0 ? ATT_THREADS / nc4 : 1) : 1;
     const int lc = (p.L + p.nch - 1) / p.nch;
-    const bool fast = p.A <= ATT_THREADS && p.L <= ATT_THREADS && (long)p.L * p.A <= (long)NE_MAX * ATT_THREADS &&
-                      (p.L + ng - 1) / ng <= NC_MAX && (long)lc * p.A <= (long)NM_MAX * ATT_THREADS &&
-                      (long)p.A * p.ksz <= (long)NU_MAX * ATT_THREADS && p.kq <= KQ_MAX && (p.ksz - 1) / 2 <= ATT_THREADS;
-    if (fast) hipLaunchKernelGGL(attn_step_kernel, dim3(p.B, p.nch), dim3(ATT_THREADS), lds, s, p);
+    const int G = p.A / 4;
+    const bool fast = (p.A == 64 || p.A == 128) && p.L <= ATT_THREADS && (long)p.L * p.A <= 4L * NE4_MAX * ATT_THREADS &&
+                      (p.L + ng - 1) / ng <= NC_MAX && lc <= 32 && p.ksz <= 32 && lds_fast <= 64 * 1024 &&
+                      (long)p.A * p.ksz <= (long)NU_MAX * ATT_THREADS && p.kq <= KQ_MAX;
+    if (fast && G == 32) hipLaunchKernelGGL(attn_step_kernel<32>, dim3(p.B, p.nch), dim3(ATT_THREADS), lds_fast, s, p);
+    else if (fast && G == 16) hipLaunchKernelGGL(attn_step_kernel<16>, dim3(p.B, p.nch), dim3(ATT_THREADS), lds_fast, s, p);
     else hipLaunchKernelGGL(attn_step_generic_kernel, dim3(p.B, p.nch), dim3(ATT_THREADS), lds, s, p);
     MTTS_CHECK_LAUNCH("attn_step_kernel");
     return 0;

@@ -125,37 +125,46 @@ __global__ __launch_bounds__(ATB_THREADS) void attn_bwd_generic_kernel(AttnBwdAr
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// fast kernel: every global operand is requested at entry (see attention.hip for the rationale)
+// fast kernel (A = 64 or 128): every global operand is requested at entry; the three contractions over ds run on
+// v_mfma_f32_16x16x4_f32 from LDS:
+//   loc [rows x A]   = cumwin [rows x 32] * U^T          (PL recompute)
+//   dU  [A x 32]     = ds^T   [A x rows]  * cumwin       (filter-bank gradient)
+//   g   [rows x 32]  = ds     [rows x A]  * U            (cumulative-alignment gradient, then anti-diagonal sums)
+// Wave w owns attention columns [16w, 16w+16).
 // ------------------------------------------------------------------------------------------------------------
-constexpr int BNM_MAX = 8;    // own (row, a) elements per thread
 constexpr int BNU_MAX = 8;    // filter-bank elements per thread
 constexpr int BNR_MAX = 4;    // own rows per wave
 constexpr int BND_MAX = 9;    // memory floats per lane per row (Dm <= 576)
 constexpr int BNP_MAX = 8;    // partial slabs
 constexpr int BNX_MAX = 2;    // context floats per thread (Dm <= 1024)
+constexpr int BUP_LD = 36;    // U row (32 taps + pad)
+constexpr int BROWS = 32;     // padded row count of a chunk
 
 __global__ __launch_bounds__(ATB_THREADS) void attn_bwd_kernel(AttnBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x, ch = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = ATB_THREADS / 64;
+    const int tid = threadIdx.x, lane = tid & 63, nwaves = ATB_THREADS / 64;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int L = p.L, A = p.A, Dm = p.Dm, ksz = p.ksz, pad = (ksz - 1) / 2;
     const int lc = (L + p.nch - 1) / p.nch;
     const int l0 = ch * lc, l1 = min(L, l0 + lc), nl = max(0, l1 - l0);
-    const int nlA = nl * A, AK = A * ksz;
+    const int AK = A * ksz, DS_LD = A + 4;
+    const int i16 = lane & 15, q4 = lane >> 4;
     float* q = sm;                       // [A]
     float* vv = q + A;                   // [A]
     float* bias = vv + A;                // [A]
-    float* w = bias + A;                 // [L]
-    float* dex = w + L;                  // [L]   dalign + dcum_out
-    float* cumw = dex + L;               // [L + ksz - 1]
-    float* Us = cumw + L + ksz - 1;      // [A*ksz]
-    float* dctx_s = Us + AK;             // [Dm]
-    float* de = dctx_s + Dm;             // [lc]
-    float* ds = de + lc;                 // [lc*A]
-    float* dcl = ds + lc * A;            // [lc + ksz - 1]
-    float* accq = dcl + lc + ksz - 1;    // [A]
+    float* accq = bias + A;              // [A]
     float* accv = accq + A;              // [A]
-    float* red = accv + A;               // [8]
+    float* w = accv + A;                 // [L]
+    float* dex = w + L;                  // [L]
+    float* cumw = dex + L;               // [L + 64]
+    float* de = cumw + L + 64;           // [BROWS]
+    float* dcl = de + BROWS;             // [64]
+    float* red = dcl + 64;               // [16]
+    float* dctx_s = red + 16;            // [Dm]
+    float* Up = sm + ((5 * A + 3 * L + 64 + BROWS + 64 + 16 + Dm + 3) & ~3);     // [A][BUP_LD]   U[a][tap]
+    float* UT = Up + A * BUP_LD;         // [32][DS_LD]   U^T[tap][a]
+    float* dsL = UT + 32 * DS_LD;        // [BROWS][DS_LD]
     const long slab = (long)b * p.nch + ch;
 
     // ---- burst of independent loads
@@ -186,24 +195,45 @@ __global__ __launch_bounds__(ATB_THREADS) void attn_bwd_kernel(AttnBwdArgs p) {
 #pragma unroll
         for (int k = 0; k < BND_MAX; ++k) memr[j][k] = mem[min(lane + 64 * k, Dm - 1)];
     }
-    float mt[BNM_MAX], dmt[BNM_MAX], us[BNU_MAX], dus[BNU_MAX];
-    {
-        const float* Mb = p.Mt + ((long)b * L + l0) * A;
-        const float* dMb = p.dMt + ((long)b * L + l0) * A;
+    // operands in the MFMA accumulator layout: rows 16*mt + 4*q4 + r, column 16*wave + i16
+    const int a_own = min(16 * wave + i16, A - 1);
+    float mtD[2][4], dmtD[2][4];
 #pragma unroll
-        for (int j = 0; j < BNM_MAX; ++j) { const int i = min(tid + j * ATB_THREADS, max(nlA - 1, 0)); mt[j] = Mb[i]; dmt[j] = dMb[i]; }
-        const float* dUs = p.dU_slab + slab * AK;
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int j = 0; j < BNU_MAX; ++j) { const int i = min(tid + j * ATB_THREADS, AK - 1); us[j] = p.U[i]; dus[j] = dUs[i]; }
-    }
+        for (int r = 0; r < 4; ++r) {
+            const long off = ((long)b * L + min(l0 + 16 * mt + 4 * q4 + r, L - 1)) * A + a_own;
+            mtD[mt][r] = p.Mt[off]; dmtD[mt][r] = p.dMt[off];
+        }
+    float us[BNU_MAX];
+#pragma unroll
+    for (int j = 0; j < BNU_MAX; ++j) us[j] = p.U[min(tid + j * ATB_THREADS, AK - 1)];
+    // dU slab in the accumulator layout of the dU contraction: rows a = 16*wave + 4*q4 + r, columns tap = 16*nt + i16
+    float dusD[2][4];
+    const float* dUs_in = p.dU_slab + slab * AK;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int a = min(16 * wave + 4 * q4 + r, A - 1), jj = min(16 * nt + i16, ksz - 1);
+            dusD[nt][r] = dUs_in[a * ksz + jj];
+        }
 
     // ---- stage in LDS
-    if (tid < A) { q[tid] = q_r; vv[tid] = v_r; bias[tid] = bias_r; accq[tid] = 0.f; accv[tid] = 0.f; }
+    if (tid < A) { q[tid] = q_r; vv[tid] = v_r; bias[tid] = bias_r; }
     if (tid < L) { w[tid] = w_r; dex[tid] = dal_r + dco_r; cumw[pad + tid] = cum_r; }
-    if (tid < pad) { cumw[tid] = 0.f; cumw[pad + L + tid] = 0.f; }
-    for (int i = tid; i < lc + ksz - 1; i += ATB_THREADS) dcl[i] = 0.f;
+    if (tid < pad) cumw[tid] = 0.f;
+    if (tid < 64 - pad) cumw[pad + L + tid] = 0.f;
+    if (tid < 64) dcl[tid] = 0.f;
 #pragma unroll
-    for (int j = 0; j < BNU_MAX; ++j) { const int i = tid + j * ATB_THREADS; if (i < AK) Us[i] = us[j]; }
+    for (int j = 0; j < BNU_MAX; ++j) {
+        const int i = tid + j * ATB_THREADS;
+        if (i < AK) { const int a = i / ksz, jj = i - a * ksz; Up[a * BUP_LD + jj] = us[j]; UT[jj * DS_LD + a] = us[j]; }
+    }
+    for (int i = tid; i < A * (32 - ksz); i += ATB_THREADS) {      // zero taps ksz..31
+        const int a = i / (32 - ksz), jj = ksz + i % (32 - ksz);
+        Up[a * BUP_LD + jj] = 0.f; UT[jj * DS_LD + a] = 0.f;
+    }
     float sdot = 0.f;
 #pragma unroll
     for (int j = 0; j < BNX_MAX; ++j) {
@@ -218,7 +248,7 @@ __global__ __launch_bounds__(ATB_THREADS) void attn_bwd_kernel(AttnBwdArgs p) {
     __syncthreads();
     const float S = block_sum(sdot, red, tid);
 
-    // ---- dw for the own rows (wave per row, memory rows already in registers), de = w (dw - S)
+    // ---- dw for the own rows (wave per row, memory rows already in registers), de = w (dw - S); padded rows -> 0
 #pragma unroll
     for (int j = 0; j < BNR_MAX; ++j) {
         const int r = wave + j * nwaves;
@@ -226,30 +256,44 @@ __global__ __launch_bounds__(ATB_THREADS) void attn_bwd_kernel(AttnBwdArgs p) {
 #pragma unroll
         for (int k = 0; k < BND_MAX; ++k) { const int d = lane + 64 * k; acc += (d < Dm) ? dctx_s[d] * memr[j][k] : 0.f; }
         acc = wave_sum(acc);
-        if (lane == 0 && r < nl) de[r] = w[l0 + r] * (dex[l0 + r] + acc - S);
+        if (lane == 0 && r < BROWS) de[r] = (r < nl) ? w[l0 + r] * (dex[l0 + r] + acc - S) : 0.f;
     }
     __syncthreads();
 
-    // ---- ds over own rows x A; dMt accumulation; dq / dv partial sums
-    {
-        float* dMb = p.dMt + ((long)b * L + l0) * A;
+    // ---- PL recompute on MFMA, ds = de * v * (1 - tanh^2), dMt accumulation, dq / dv column sums
+    if (16 * wave < A) {
+        f32x4 acc[2];
+        acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < BNM_MAX; ++j) {
-            const int i = tid + j * ATB_THREADS;
-            if (i < nlA) {
-                const int r = i / A, a = i - r * A;
-                float sacc = q[a] + mt[j] + bias[a];
-                const float* u = Us + a * ksz;
-                const float* cw = cumw + l0 + r;
-                for (int jj = 0; jj < ksz; ++jj) sacc += u[jj] * cw[jj];
-                const float th = tanhf_(sacc);
-                const float dsv = de[r] * vv[a] * (1.f - th * th);
-                ds[i] = dsv;
-                dMb[i] = dmt[j] + dsv;
-                atomicAdd(&accq[a], dsv);
-                atomicAdd(&accv[a], de[r] * th);
+        for (int c = 0; c < 2; ++c) {
+            const float4 bf = *reinterpret_cast<const float4*>(Up + (16 * wave + i16) * BUP_LD + 16 * c + 4 * q4);
+            const float bv[4] = {bf.x, bf.y, bf.z, bf.w};
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const float* cw = cumw + l0 + 16 * mt + i16 + 16 * c + 4 * q4;
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cw[s2], bv[s2], acc[mt], 0, 0, 0);
             }
         }
+        const int a = 16 * wave + i16;
+        const float qa = q[a_own], va = vv[a_own], ba = bias[a_own];
+        float sq = 0.f, sv = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = 16 * mt + 4 * q4 + r;
+                const float th = tanhf_(qa + mtD[mt][r] + ba + acc[mt][r]);
+                const float der = de[rr];                         // 0 for padded rows
+                const float dsv = der * va * (1.f - th * th);
+                dsL[rr * DS_LD + a_own] = dsv;
+                if (rr < nl && a < A) p.dMt[((long)b * L + l0 + rr) * A + a] = dmtD[mt][r] + dsv;
+                sq += dsv; sv += der * th;
+            }
+        // column sums over the 4 row groups of this lane column (lanes i16, i16+16, i16+32, i16+48)
+        sq += __shfl_xor(sq, 16, 64); sq += __shfl_xor(sq, 32, 64);
+        sv += __shfl_xor(sv, 16, 64); sv += __shfl_xor(sv, 32, 64);
+        if (q4 == 0 && a < A) { accq[a] = sq; accv[a] = sv; }
     }
     __syncthreads();
     if (tid < A) {
@@ -257,23 +301,50 @@ __global__ __launch_bounds__(ATB_THREADS) void attn_bwd_kernel(AttnBwdArgs p) {
         p.dbias_slab[slab * A + tid] = dbs_r + accq[tid];
         p.dv_slab[slab * A + tid] = dvs_r + accv[tid];
     }
-    {
-        float* dUs = p.dU_slab + slab * AK;
+
+    // ---- dU[a, tap] += sum_rows ds[row, a] * cumwin[row][tap]      (A operand ds^T, B operand Toeplitz window)
+    if (16 * wave < A) {
+        f32x4 acc[2];
+        acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < BNU_MAX; ++j) {           // dU[a,jj] += sum_r ds[r,a] cum_in[l0 + r + jj - pad]
-            const int i = tid + j * ATB_THREADS;
-            if (i < AK) {
-                const int a = i / ksz, jj = i - a * ksz;
-                float sacc = 0.f;
-                for (int r = 0; r < nl; ++r) sacc += ds[r * A + a] * cumw[l0 + r + jj];
-                dUs[i] = dus[j] + sacc;
+        for (int c = 0; c < 2; ++c) {
+            float av[4];
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) av[s2] = dsL[(16 * c + 4 * q4 + s2) * DS_LD + 16 * wave + i16];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const float* cw = cumw + l0 + 16 * c + 4 * q4 + 16 * nt + i16;       // cumwin[row][tap] = cumw[l0 + row + tap]
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], cw[s2], acc[nt], 0, 0, 0);
             }
         }
-        for (int i = tid; i < nl * ksz; i += ATB_THREADS) {   // dcum window: sum_a ds[r,a] U[a,jj]
-            const int r = i / ksz, jj = i - r * ksz;
-            float g = 0.f;
-            for (int a = 0; a < A; ++a) g += ds[r * A + a] * Us[a * ksz + jj];
-            atomicAdd(&dcl[r + jj], g);
+        float* dUs = p.dU_slab + slab * AK;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a = 16 * wave + 4 * q4 + r, jj = 16 * nt + i16;
+                if (a < A && jj < ksz) dUs[a * ksz + jj] = dusD[nt][r] + acc[nt][r];
+            }
+    }
+
+    // ---- g[row, tap] = sum_a ds[row, a] * U[a][tap]; dcum window: dcl[row + tap] += g.  4 tiles x 2 K-halves over 8 waves
+    {
+        const int tile = wave & 3, mt = tile >> 1, nt = tile & 1, kh = wave >> 2;
+        const int nchunk = A >> 4, c_lo = kh * (nchunk >> 1), c_hi = kh ? nchunk : (nchunk >> 1);
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int c = c_lo; c < c_hi; ++c) {
+            const float4 af = *reinterpret_cast<const float4*>(dsL + (16 * mt + i16) * DS_LD + 16 * c + 4 * q4);
+            const float4 bf = *reinterpret_cast<const float4*>(UT + (16 * nt + i16) * DS_LD + 16 * c + 4 * q4);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bf.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bf.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bf.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bf.w, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rr = 16 * mt + 4 * q4 + r, jj = 16 * nt + i16;
+            if (rr < nl && jj < ksz) atomicAdd(&dcl[rr + jj], acc[r]);
         }
     }
     __syncthreads();
@@ -290,12 +361,13 @@ MTTS_API int mtts_attn_step_bwd(const AttnBwdArgs* args, void* stream) {
     const int lc = (p.L + p.nch - 1) / p.nch;
     const size_t lds = sizeof(float) * ((size_t)5 * p.A + 2 * p.L + (p.L + p.ksz - 1) + (size_t)p.A * p.ksz + p.Dm + lc +
                                         (size_t)lc * p.A + (lc + p.ksz - 1) + 16);
-    MTTS_REQUIRE(lds <= 64 * 1024, "attn_bwd: LDS request %zu too large (raise nch)", lds);
-    const bool fast = p.A <= ATB_THREADS && p.L <= ATB_THREADS && (long)lc * p.A <= (long)BNM_MAX * ATB_THREADS &&
-                      (long)p.A * p.ksz <= (long)BNU_MAX * ATB_THREADS && lc <= BNR_MAX * (ATB_THREADS / 64) &&
-                      p.Dm <= 64 * BND_MAX && p.Dm <= BNX_MAX * ATB_THREADS && p.n_part <= BNP_MAX &&
-                      (p.ksz - 1) / 2 <= ATB_THREADS;
-    if (fast) hipLaunchKernelGGL(attn_bwd_kernel, dim3(p.B, p.nch), dim3(ATB_THREADS), lds, (hipStream_t)stream, p);
+    const size_t lds_fast = sizeof(float) * ((((size_t)5 * p.A + 3 * p.L + 64 + BROWS + 64 + 16 + p.Dm + 3) & ~(size_t)3) +
+                                             (size_t)p.A * BUP_LD + (size_t)(32 + BROWS) * (p.A + 4));
+    const bool fast = (p.A == 64 || p.A == 128) && p.L <= ATB_THREADS && lc <= BROWS && lc <= BNR_MAX * (ATB_THREADS / 64) &&
+                      p.ksz <= 32 && (long)p.A * p.ksz <= (long)BNU_MAX * ATB_THREADS && p.Dm <= 64 * BND_MAX &&
+                      p.Dm <= BNX_MAX * ATB_THREADS && p.n_part <= BNP_MAX && lds_fast <= 64 * 1024;
+    MTTS_REQUIRE(fast || lds <= 64 * 1024, "attn_bwd: LDS request %zu too large (raise nch)", lds);
+    if (fast) hipLaunchKernelGGL(attn_bwd_kernel, dim3(p.B, p.nch), dim3(ATB_THREADS), lds_fast, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(attn_bwd_generic_kernel, dim3(p.B, p.nch), dim3(ATB_THREADS), lds, (hipStream_t)stream, p);
     MTTS_CHECK_LAUNCH("attn_bwd_kernel");
     return 0;

@@ -84,3 +84,25 @@ int relu_mask_bwd(const float* dy, const float* y, float* dz, long n, float scal
 bool prof_sample(int t, hipStream_t s, int phase);
 hipStream_t side_stream();
 hipEvent_t pool_event();
+
+// ---- DPP (no LDS traffic) reductions inside 16-lane rows, then across rows -----------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+// every lane of a 16-lane row ends up with the row's sum
+__device__ __forceinline__ float row16_sum(float x) {
+    x += dpp_f<0xB1>(x);      // quad_perm [1,0,3,2]
+    x += dpp_f<0x4E>(x);      // quad_perm [2,3,0,1]
+    x += dpp_f<0x141>(x);     // row_half_mirror
+    x += dpp_f<0x140>(x);     // row_mirror
+    return x;
+}
+// sum over groups of G consecutive lanes (G = 16, 32 or 64); every lane gets its group's sum
+template <int G>
+__device__ __forceinline__ float group_sum(float x) {
+    x = row16_sum(x);
+    if (G >= 32) x += __shfl_xor(x, 16, 64);
+    if (G >= 64) x += __shfl_xor(x, 32, 64);
+    return x;
+}

@@ -126,3 +126,74 @@ def test_full_size_properties_and_schedule_equivalence():
             outs.append(D.decode_train(memory, tgt, tl, [True] * Ts, masks, cfg, w))
     for a, b in zip(*outs):
         assert (a - b).abs().max().item() <= 2e-4
+
+
+@pytest.mark.parametrize('preset,B', [('shared_training', 4), ('generated_switching', 5)])
+def test_train_step_gradients_match_oracle_at_real_widths(preset, B):
+    """Full train step (loss + backward) at the real layer widths against the CPU oracle's autograd: exercises the
+    MFMA attention kernels, the packed-operand step kernels and the two-stream schedules that the small fixtures bypass."""
+    from multilingual_text_to_speech_amd.params import presets, Params as hp
+    from multilingual_text_to_speech_amd.modules.tacotron2 import Tacotron, TacotronLoss
+    from multilingual_text_to_speech_amd.masks import provider
+    presets.apply(preset, speaker_number=7)
+    torch.manual_seed(1)
+    model = Tacotron().train()
+    L, T = 20, 9
+    text, tl, target, tgl, spk, lang = _random_batch(hp, B, L, T, seed=9)
+    stop_t = torch.zeros(B, T)
+    for b in range(B):
+        stop_t[b, max(int(tgl[b]) - hp.stop_frames, 0):] = 1.0
+    g = torch.Generator().manual_seed(21)
+    keep = lambda *shape, p: (torch.rand(*shape, generator=g) >= p).to(torch.uint8)
+    H, P = hp.decoder_dimension, hp.prenet_dimension
+    inj = {'teacher': [True] * T, 'dec.att_lstm': keep(T, B, H, p=hp.dropout_hidden), 'dec.gen_lstm': keep(T, B, H, p=hp.dropout_hidden)}
+    inj.update({f'dec.prenet.{i}': keep(T, B, P, p=hp.dropout) for i in range(2)})
+    G = hp.language_number if hp.encoder_type == 'generated' else 1
+    if hp.encoder_type == 'generated':
+        from multilingual_text_to_speech_amd.modules.encoder import _LAYERS
+        for i, (k, d, hw) in enumerate(_LAYERS):
+            inj[f'enc.{i}'] = keep(B // G, L, G * hp.encoder_dimension * (2 if hw else 1), p=0.05)
+    else:
+        inj.update({f'enc.{i}': keep(B, L, hp.encoder_dimension, p=hp.dropout) for i in range(hp.encoder_blocks)})
+    nb = hp.postnet_blocks
+    inj.update({f'post.{i}': keep(B, T, hp.postnet_dimension if i < nb - 1 else hp.num_mels, p=hp.dropout) for i in range(nb)})
+
+    # ---- oracle (CPU autograd)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and not k.endswith(('running_mean', 'running_var')):
+            v.requires_grad_(True)
+    cfg = O.cfg_from_params(hp)
+    mult = lambda m, p: m.float() / (1 - p)
+    om = {'att_lstm': mult(inj['dec.att_lstm'], hp.dropout_hidden), 'gen_lstm': mult(inj['dec.gen_lstm'], hp.dropout_hidden)}
+    for i in range(2):
+        om[f'prenet.{i}'] = torch.cat((mult(inj[f'dec.prenet.{i}'], hp.dropout).transpose(0, 1), torch.ones(B, 1, P)), 1)
+    for k, v in inj.items():
+        if k.startswith('enc.'):
+            om[k] = mult(v, 0.05 if hp.encoder_type == 'generated' else hp.dropout).permute(0, 2, 1)
+        if k.startswith('post.'):
+            om[k] = mult(v, hp.dropout).permute(0, 2, 1)
+    ref = O.tacotron_forward(sd, cfg, text, tl, target, tgl, spk, lang, torch.ones(T, dtype=torch.bool), om, True)
+    rloss, _ = O.tacotron_loss(cfg, ref, tl, tgl, target, stop_t, spk, hp.guided_attention_toleration)
+    rloss.backward()
+
+    # ---- HIP
+    model.cuda()
+    provider.injected = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in inj.items()}
+    try:
+        to = lambda t: None if t is None else t.cuda()
+        post, pre, stop, align, spk_pred, enc = model(to(text), tl, to(target), tgl, to(spk), to(lang), 1.0)
+    finally:
+        provider.injected = None
+    crit = TacotronLoss(hp.guided_attention_steps, hp.guided_attention_toleration, hp.guided_attention_gain)
+    loss, _ = crit(tl.cuda(), tgl.cuda(), pre, target.cuda(), post, target.cuda(), stop, stop_t.cuda(), align, to(spk), spk_pred, enc, None)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert (post.cpu() - ref['post']).abs().max().item() <= 1e-3
+    assert abs(loss.item() - rloss.item()) <= 1e-4 * max(1.0, abs(rloss.item()))
+    for k, p in model.named_parameters():
+        r = sd[k].grad
+        assert r is not None and p.grad is not None, k
+        err = (p.grad.cpu() - r).abs().max().item()
+        tol = 1e-3 * r.abs().max().item() + 2e-5
+        assert err <= tol, f'{preset}/{k}: max |delta| {err:.3e} > {tol:.3e}'
