@@ -393,6 +393,8 @@ typedef struct DecoderGradArgs {
     int ksb;
     float* dc_att;         /* [2,B,H] zero-initialised */
     float* dc_gen;         /* [2,B,H] zero-initialised */
+    float* dh_carry_att;   /* [2,B,H] zero-initialised: part of dh that bypasses the cell (zoneout) */
+    float* dh_carry_gen;   /* [2,B,H] zero-initialised */
     float* dMt;            /* [B,L,A] zero-initialised */
     float* dU_slab;        /* [B*nch,A*ksz] zero-initialised */
     float* dv_slab;        /* [B*nch,A] zero-initialised */

@@ -72,6 +72,8 @@ def decoder_bwd(ctx, dspec, dstop, dalign):
     g.ksb, g.nch = ksb, nch
     buf('dc_att', _z(2, B, H, device=dev))
     buf('dc_gen', _z(2, B, H, device=dev))
+    buf('dh_carry_att', _z(2, B, H, device=dev))
+    buf('dh_carry_gen', _z(2, B, H, device=dev))
     buf('dMt', _z(B, L, A, device=dev))
     buf('dU_slab', _z(B * nch, A * ksz, device=dev))
     buf('dv_slab', _z(B * nch, A, device=dev))

@@ -31,7 +31,7 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
     const int Mo = round4(M + 1), TB = T * B;
     const long BH = (long)B * H, BD = (long)B * Dm, BL = (long)B * L, B4H = 4 * BH, BP = (long)B * P, BA = (long)B * A;
     MTTS_REQUIRE(a.fast, "decoder backward: only the fully teacher-forced schedule is implemented (teacher forcing ratio 1.0)");
-    MTTS_REQUIRE(!a.zone, "decoder backward: zoneout regularisation is forward-only in this build");
+    MTTS_REQUIRE(!a.zone || (a.training && g.dh_carry_att && g.dh_carry_gen), "decoder backward with zoneout needs training mode and the carry buffers");
     MTTS_REQUIRE(a.q_all && a.gates_att && a.gates_gen, "decoder backward needs q_all and the saved gates");
     MTTS_REQUIRE((A & 3) == 0, "attention dimension must be a multiple of 4");
     const int ksb = g.ksb;
@@ -71,6 +71,7 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
             if (t < T - 1) { k.part = g.part_gen; k.n_part = ksb; k.part_ks = BH; k.part_ld = H; k.part_col0 = 0; }
             k.gates = a.gates_gen + t * B4H; k.c_prev = a.c_gen + t * BH;
             k.dc_in = g.dc_gen + ((t + 1) & 1) * BH; k.dc_out = g.dc_gen + (t & 1) * BH;
+            if (a.zone) { k.dh_b = g.dh_carry_gen + ((t + 1) & 1) * BH; k.dh_carry_out = g.dh_carry_gen + (t & 1) * BH; }
             k.dgates_out = g.dG_gen + t * B4H; k.ld_dgates = 4 * H;
             k.dg_pack_out = g.dG_gen_p ? g.dG_gen_p + t * Bp4H : nullptr;
             bwd_reg(a, k, a.gen_hmask, a.gen_cmask, t);
@@ -131,6 +132,7 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
             if (t < T - 1) { k.part = g.part_att; k.n_part = ksb; k.part_ks = (long)B * (Dm + H); k.part_ld = Dm + H; k.part_col0 = Dm; }
             k.gates = a.gates_att + t * B4H; k.c_prev = a.c_att + t * BH;
             k.dc_in = g.dc_att + ((t + 1) & 1) * BH; k.dc_out = g.dc_att + (t & 1) * BH;
+            if (a.zone) { k.dh_b = g.dh_carry_att + ((t + 1) & 1) * BH; k.dh_carry_out = g.dh_carry_att + (t & 1) * BH; }
             k.dgates_out = g.dG_att + t * B4H; k.ld_dgates = 4 * H;
             k.dg_pack_out = g.dG_att_p ? g.dG_att_p + t * Bp4H : nullptr;
             bwd_reg(a, k, a.att_hmask, a.att_cmask, t);

@@ -8,8 +8,8 @@ from tests.helpers import build_hip_model, golden_names, hip_forward, load_golde
 
 pytestmark = pytest.mark.gpu
 
-# schedules the backward implements: every step teacher forced, dropout regularisation
-CASES = [n for n in golden_names('train') if n not in ('simple_eval', 'simple_mixed_tf', 'simple_zoneout')]
+# schedules the backward implements: every step teacher forced (dropout or zoneout regularisation)
+CASES = [n for n in golden_names('train') if n not in ('simple_eval', 'simple_mixed_tf')]
 
 
 def run_step(fx, device='cuda'):
