@@ -372,9 +372,13 @@ typedef struct DecoderGradArgs {
     const float* dalign;   /* [T,B,L] or NULL */
     /* workspaces */
     float* att_w_rec_T;    /* [Dm+H,4H] */
-    float* att_w_ih_T;     /* [P+Dm,4H] (general path) */
+    float* att_w_ih_T;     /* general schedule: [P+Dm+H,4H] = [W_ih | W_hh]^T of the attention LSTM */
     float* gen_w_hh_T;     /* [H,4H] */
-    float* gen_w_ih_T;     /* [H+Dm,4H] (general path) */
+    float* gen_w_ih_T;     /* general schedule: [H+Dm+H,4H] = [W_ih | W_hh]^T of the generator LSTM */
+    float* w_out_T;        /* general schedule: [H+Dm,Mo] transposed frame/stop projection (zero padded columns) */
+    float* prenet_w_T[4];  /* general schedule: transposed prenet weights [in_i, P] */
+    float* step_ws;        /* general schedule: B*(P+Dm+H + 2H+Dm + H+Dm + M) floats of per-step scratch */
+    float* frames_fed;     /* general schedule: [T,B,M] frame actually fed to the prenet at each step */
     float* w_query_T;      /* [H,A] */
     float* dG_att;         /* [T,B,4H] */
     float* dG_gen;         /* [T,B,4H] */

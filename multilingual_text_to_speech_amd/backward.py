@@ -21,8 +21,6 @@ def decoder_bwd(ctx, dspec, dstop, dalign):
     M, P, H, A, Dm, ksz, C = st.dims
     B, L, T, Mo, n = st.B, st.L, st.T, st.Mo, ctx.n_prenet
     dev = ctx.memory.device
-    if not st.fast:
-        raise NotImplementedError('decoder backward is implemented for teacher_forcing_ratio == 1.0 (all reference configs)')
 
     # gradient of (frame, stop) per step, time-major with the forward's row stride
     dout = _z(T + 1, B, Mo, device=dev)
@@ -61,6 +59,16 @@ def decoder_bwd(ctx, dspec, dstop, dalign):
         buf('dG_gen_p', _z(T, Bp * 4 * H, device=dev))
         buf('att_w_rec_Tp', _e(((Dm + H + 15) & ~15) * 4 * H, device=dev))
         buf('gen_w_hh_Tp', _e(H * 4 * H, device=dev))
+    if not st.fast:      # general schedule (teacher forcing < 1): per-step chain with transposed full weights
+        buf('att_w_ih_T', _e(P + Dm + H, 4 * H, device=dev))
+        buf('gen_w_ih_T', _e(2 * H + Dm, 4 * H, device=dev))
+        buf('w_out_T', _e(H + Dm, Mo, device=dev))
+        pwt = [_e(M if i == 0 else P, P, device=dev) for i in range(n)]
+        keep.extend(pwt)
+        for i in range(n):
+            g.prenet_w_T[i] = pwt[i].data_ptr()
+        buf('step_ws', _z(B * ((P + Dm + H) + (2 * H + Dm) + (H + Dm) + M), device=dev))
+        buf('frames_fed', _e(T, B, M, device=dev))
     buf('dHG', _e(T, B, H, device=dev))
     buf('dHA', _e(T, B, H, device=dev))
     buf('dctx_all', _z(T + 1, B, Dm, device=dev))

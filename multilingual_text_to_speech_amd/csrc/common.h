@@ -106,3 +106,5 @@ __device__ __forceinline__ float group_sum(float x) {
     if (G >= 64) x += __shfl_xor(x, 32, 64);
     return x;
 }
+int add3(float* out, int ldo, const float* a, int lda, const float* b, int ldb, const float* c3, int ldc, int rows, int cols,
+         bool accumulate, hipStream_t s);

@@ -23,6 +23,185 @@ static void bwd_reg(const DecoderArgs& a, SkinnyArgs& k, const uint8_t* hmask, c
     else if (a.training && hmask && a.p_hidden > 0.f) { k.zone = 0; k.hmask = hmask + off; k.hscale = 1.f / (1.f - a.p_hidden); }
 }
 
+// Batched part after the sequential sweeps: prenet, every weight gradient, memory gradient, attention parameters.
+// `prenet_chain_done`: the general schedule already pushed the gradient through the prenet step by step (dpren holds dz).
+static int bwd_post(const DecoderArgs& a, const DecoderGradArgs& g, bool prenet_chain_done, bool gen_wgrad_done, hipStream_t s) {
+    const int B = a.B, L = a.L, T = a.T, M = a.M, P = a.P, H = a.H, A = a.A, Dm = a.Dm;
+    const int Mo = round4(M + 1), TB = T * B;
+    const long BH = (long)B * H, BD = (long)B * Dm, BP = (long)B * P;
+    const float* dout1 = g.dout + (long)B * Mo;
+    // ---- prenet backward (batched over all frames)
+    const int n = a.n_prenet;
+    const float pscale = a.p_prenet > 0.f ? 1.f / (1.f - a.p_prenet) : 1.f;
+    float* dp_last = g.dpren + (long)(n - 1) * T * BP;
+    if (!prenet_chain_done) MTTS_TRY(gm(g.dG_att, a.att_w_ih, dp_last, TB, P, 4 * H, 4 * H, P + Dm, P, false, true, 0.f, s));
+    for (int i = n - 1; i >= 0; --i) {
+        float* dz = g.dpren + (long)i * T * BP;
+        if (!prenet_chain_done) MTTS_TRY(relu_mask_bwd(dz, a.prenet_act[i], dz, (long)T * BP, a.prenet_mask[i] ? pscale : 1.f, s));
+        const float* xin = i == 0 ? (prenet_chain_done ? g.frames_fed : a.frames_in) : a.prenet_act[i - 1];
+        const int Kin = i == 0 ? M : P;
+        MTTS_TRY(gm(dz, xin, g.d_prenet_w[i], P, Kin, TB, P, Kin, Kin, true, true, 0.f, s));
+        MTTS_TRY(colsum(dz, g.d_prenet_b[i], TB, P, P, g.colsum_ws, s));
+        if (i > 0 && !prenet_chain_done) MTTS_TRY(gm(dz, a.prenet_w[i], g.dpren + (long)(i - 1) * T * BP, TB, P, P, P, P, P, false, true, 0.f, s));
+    }
+    const float* pren = a.prenet_act[n - 1];
+
+    // ---- LSTM weight gradients
+    MTTS_TRY(gm(g.dG_att, pren, g.d_att_w_ih, 4 * H, P, TB, 4 * H, P, P + Dm, true, true, 0.f, s));
+    MTTS_TRY(gm(g.dG_att, a.ctx, g.d_att_w_ih + P, 4 * H, Dm, TB, 4 * H, Dm, P + Dm, true, true, 0.f, s));
+    MTTS_TRY(gm(g.dG_att, a.h_att, g.d_att_w_hh, 4 * H, H, TB, 4 * H, H, H, true, true, 0.f, s));
+    MTTS_TRY(colsum(g.dG_att, g.d_att_b_ih, TB, 4 * H, 4 * H, g.colsum_ws, s));
+    MTTS_TRY(colsum(g.dG_att, g.d_att_b_hh, TB, 4 * H, 4 * H, g.colsum_ws, s));
+    if (!gen_wgrad_done) {
+        MTTS_TRY(gm(g.dG_gen, a.h_att + BH, g.d_gen_w_ih, 4 * H, H, TB, 4 * H, H, H + Dm, true, true, 0.f, s));
+        MTTS_TRY(gm(g.dG_gen, a.ctx + BD, g.d_gen_w_ih + H, 4 * H, Dm, TB, 4 * H, Dm, H + Dm, true, true, 0.f, s));
+        MTTS_TRY(gm(g.dG_gen, a.h_gen, g.d_gen_w_hh, 4 * H, H, TB, 4 * H, H, H, true, true, 0.f, s));
+    }
+    MTTS_TRY(colsum(g.dG_gen, g.d_gen_b_ih, TB, 4 * H, 4 * H, g.colsum_ws, s));
+    MTTS_TRY(colsum(g.dG_gen, g.d_gen_b_hh, TB, 4 * H, 4 * H, g.colsum_ws, s));
+
+    // ---- frame/stop projection and query weights
+    MTTS_TRY(gm(dout1, a.h_gen + BH, g.d_w_out, M + 1, H, TB, Mo, H, H + Dm, true, true, 0.f, s));
+    MTTS_TRY(gm(dout1, a.ctx + BD, g.d_w_out + H, M + 1, Dm, TB, Mo, Dm, H + Dm, true, true, 0.f, s));
+    MTTS_TRY(colsum(dout1, g.d_b_out, TB, M + 1, Mo, g.colsum_ws, s));
+    MTTS_TRY(gm(g.dq_all, a.h_att + BH, g.d_w_query, A, H, TB, A, H, H, true, true, 0.f, s));
+
+    // ---- memory gradient: context path (per-sample align^T dctx), memory-transform path, and W_memory
+    {
+        GemmArgs q; memset(&q, 0, sizeof(q));
+        q.A = a.align; q.B = g.dctx_tot + BD; q.C = g.dmemory;
+        q.M = L; q.N = Dm; q.K = T; q.lda = B * L; q.ldb = B * Dm; q.ldc = Dm;
+        q.transA = 1; q.transB = 1; q.taps = 1; q.Kc = T; q.batch = B; q.zt = 1;
+        q.a_z = L; q.b_z = Dm; q.c_z = (long)L * Dm; q.alpha = 1.f; q.mask_scale = 1.f;
+        MTTS_TRY(mtts_gemm_ex(&q, s));
+    }
+    MTTS_TRY(gm(g.dMt, a.w_memory, g.dmemory, B * L, Dm, A, A, Dm, Dm, false, true, 1.f, s));
+    MTTS_TRY(gm(g.dMt, a.memory, g.d_w_memory, A, Dm, B * L, A, Dm, Dm, true, true, 0.f, s));
+
+    // ---- small attention parameters from the per-workgroup slabs
+    const int nslab = B * g.nch;
+    MTTS_TRY(colsum(g.dU_slab, g.dU, nslab, A * a.ksz, A * a.ksz, g.colsum_ws, s));
+    MTTS_TRY(gm(g.dU, a.w_conv, g.d_w_loc, A, a.C, a.ksz, a.ksz, a.ksz, a.C, false, false, 0.f, s));
+    MTTS_TRY(gm(a.w_loc, g.dU, g.d_w_conv, a.C, a.ksz, A, a.C, a.ksz, a.ksz, true, true, 0.f, s));
+    MTTS_TRY(colsum(g.dv_slab, g.d_w_energy, nslab, A, A, g.colsum_ws, s));
+    MTTS_TRY(colsum(g.dbias_slab, g.d_att_bias, nslab, A, A, g.colsum_ws, s));
+    return 0;
+}
+
+// General schedule (some steps fed with the model's own prediction): one dependent chain per step, last step first.
+//   projection bwd -> generator cell bwd -> generator input gradient -> attention bwd -> query+attention cell bwd
+//   -> attention-LSTM input gradient -> prenet bwd (-> gradient of the previous frame when that step was free running)
+static int bwd_general(const DecoderArgs& a, const DecoderGradArgs& g, hipStream_t s) {
+    const int B = a.B, L = a.L, T = a.T, M = a.M, P = a.P, H = a.H, A = a.A, Dm = a.Dm, n = a.n_prenet;
+    const int Mo = round4(M + 1);
+    const long BH = (long)B * H, BD = (long)B * Dm, BL = (long)B * L, B4H = 4 * BH, BP = (long)B * P, BA = (long)B * A;
+    MTTS_REQUIRE(g.att_w_ih_T && g.gen_w_ih_T && g.w_out_T && g.step_ws && g.frames_fed && (Mo & 3) == 0,
+                 "decoder backward (general schedule) needs the transposed-weight and per-step workspaces");
+    const int Fa = P + Dm + H, Fg = 2 * H + Dm, Fp = H + Dm;
+    float* dfeat = g.step_ws;                    // [B, P+Dm+H]  gradient w.r.t. the attention-LSTM input of the LATER step
+    float* dgen_in = dfeat + (long)B * Fa;       // [B, H+Dm+H]
+    float* dproj = dgen_in + (long)B * Fg;       // [B, H+Dm]
+    float* dframe = dproj + (long)B * Fp;        // [B, M]
+    float* dout = const_cast<float*>(g.dout);
+    const float pscale = a.p_prenet > 0.f ? 1.f / (1.f - a.p_prenet) : 1.f;
+
+    // transposed weights
+    MTTS_TRY(transpose2d(a.att_w_ih, g.att_w_ih_T, 4 * H, P + Dm, s));
+    MTTS_TRY(transpose2d(a.att_w_hh, g.att_w_ih_T + (long)(P + Dm) * 4 * H, 4 * H, H, s));
+    MTTS_TRY(transpose2d(a.gen_w_ih, g.gen_w_ih_T, 4 * H, H + Dm, s));
+    MTTS_TRY(transpose2d(a.gen_w_hh, g.gen_w_ih_T + (long)(H + Dm) * 4 * H, 4 * H, H, s));
+    MTTS_TRY(transpose2d(a.w_query, g.w_query_T, A, H, s));
+    MTTS_CHECK_HIP(hipMemsetAsync(g.w_out_T, 0, (size_t)Fp * Mo * sizeof(float), s));
+    MTTS_TRY(transpose2d_ld(a.w_out, g.w_out_T, M + 1, Fp, Fp, Mo, s));
+    for (int i = 0; i < n; ++i) MTTS_TRY(transpose2d(a.prenet_w[i], g.prenet_w_T[i], P, i == 0 ? M : P, s));
+    // frames actually fed: teacher frame or the model's previous output (slot t of `out` holds frame t-1)
+    for (int t = 0; t < T; ++t) {
+        const bool teach = a.frames_in && a.teacher && a.teacher[t];
+        if (teach) MTTS_TRY(copy2d(a.frames_in + (long)t * B * M, g.frames_fed + (long)t * B * M, B, M, M, M, s));
+        else MTTS_TRY(copy2d(a.out + (long)t * B * Mo, g.frames_fed + (long)t * B * M, B, M, Mo, M, s));
+    }
+
+    for (int t = T - 1; t >= 0; --t) {
+        const bool last = t == T - 1;
+        {   // projection backward: dproj = dout[t] W_out
+            SkinnyArgs k; memset(&k, 0, sizeof(k));
+            k.nseg = 1; k.B = B; k.N = Fp; k.ksplit = 1;
+            k.seg[0] = SkSeg{dout + (long)(t + 1) * B * Mo, g.w_out_T, Mo, Mo, Mo, 0, 0};
+            k.out = dproj; k.ldo = Fp;
+            MTTS_TRY(skinny_launch(k, s));
+        }
+        {   // generator cell backward
+            SkinnyArgs k; memset(&k, 0, sizeof(k));
+            k.B = B; k.H = H; k.lstm = 2; k.nseg = 0; k.ksplit = 1;
+            k.dh_a = dproj; k.ld_dh_a = Fp;
+            if (!last) { k.part = dgen_in; k.n_part = 1; k.part_ks = 0; k.part_ld = Fg; k.part_col0 = H + Dm; }
+            k.gates = a.gates_gen + t * B4H; k.c_prev = a.c_gen + t * BH;
+            k.dc_in = g.dc_gen + ((t + 1) & 1) * BH; k.dc_out = g.dc_gen + (t & 1) * BH;
+            if (a.zone) { k.dh_b = g.dh_carry_gen + ((t + 1) & 1) * BH; k.dh_carry_out = g.dh_carry_gen + (t & 1) * BH; }
+            k.dgates_out = g.dG_gen + t * B4H; k.ld_dgates = 4 * H;
+            bwd_reg(a, k, a.gen_hmask, a.gen_cmask, t);
+            MTTS_TRY(skinny_launch(k, s));
+        }
+        {   // d[h_att_t, ctx_t, h_gen_{t-1}] = dG_gen [W_ih | W_hh]
+            SkinnyArgs k; memset(&k, 0, sizeof(k));
+            k.nseg = 1; k.B = B; k.N = Fg; k.ksplit = 1;
+            k.seg[0] = SkSeg{g.dG_gen + t * B4H, g.gen_w_ih_T, 4 * H, 4 * H, 4 * H, 0, 0};
+            k.out = dgen_in; k.ldo = Fg;
+            MTTS_TRY(skinny_launch(k, s));
+        }
+        // total context gradient of this step: projection + generator input + attention-LSTM input of step t+1
+        MTTS_TRY(add3(g.dctx_all + (t + 1) * BD, Dm, dproj + H, Fp, dgen_in + H, Fg, last ? nullptr : dfeat + P, Fa, B, Dm, false, s));
+        {
+            AttnBwdArgs q; memset(&q, 0, sizeof(q));
+            q.q = a.q_all + t * BA; q.Mt = a.Mt; q.U = a.U; q.bias = a.att_bias; q.v = a.w_energy; q.memory = a.memory;
+            q.ctx = a.ctx + (t + 1) * BD; q.lengths = a.lengths; q.w = a.align + t * BL; q.cum_in = a.cum + t * BL;
+            q.dalign = g.dalign ? g.dalign + t * BL : nullptr;
+            q.dcum_out = g.dcum_all + (t + 1) * BL; q.dcum_in = g.dcum_all + t * BL;
+            q.dctx = g.dctx_all + (t + 1) * BD; q.dctx_total = g.dctx_tot + (t + 1) * BD;
+            q.dq = g.dq_all + t * BA; q.dMt = g.dMt; q.dU_slab = g.dU_slab; q.dv_slab = g.dv_slab; q.dbias_slab = g.dbias_slab;
+            q.B = B; q.L = L; q.A = A; q.Dm = Dm; q.ksz = a.ksz; q.nch = g.nch;
+            MTTS_TRY(mtts_attn_step_bwd(&q, s));
+        }
+        {   // dh_att_t = dq W_q + (generator input part) + (recurrent part of step t+1) -> attention cell backward
+            SkinnyArgs k; memset(&k, 0, sizeof(k));
+            k.B = B; k.H = H; k.lstm = 2; k.nseg = 1; k.ksplit = 1;
+            k.seg[0] = SkSeg{g.dq_all + t * BA, g.w_query_T, A, A, A, 0, 0};
+            k.dh_a = dgen_in; k.ld_dh_a = Fg;
+            if (!last) { k.part = dfeat; k.n_part = 1; k.part_ks = 0; k.part_ld = Fa; k.part_col0 = P + Dm; }
+            k.gates = a.gates_att + t * B4H; k.c_prev = a.c_att + t * BH;
+            k.dc_in = g.dc_att + ((t + 1) & 1) * BH; k.dc_out = g.dc_att + (t & 1) * BH;
+            if (a.zone) { k.dh_b = g.dh_carry_att + ((t + 1) & 1) * BH; k.dh_carry_out = g.dh_carry_att + (t & 1) * BH; }
+            k.dgates_out = g.dG_att + t * B4H; k.ld_dgates = 4 * H;
+            bwd_reg(a, k, a.att_hmask, a.att_cmask, t);
+            MTTS_TRY(skinny_launch(k, s));
+        }
+        {   // d[prenet_t, ctx_{t-1}, h_att_{t-1}] = dG_att [W_ih | W_hh]
+            SkinnyArgs k; memset(&k, 0, sizeof(k));
+            k.nseg = 1; k.B = B; k.N = Fa; k.ksplit = 1;
+            k.seg[0] = SkSeg{g.dG_att + t * B4H, g.att_w_ih_T, 4 * H, 4 * H, 4 * H, 0, 0};
+            k.out = dfeat; k.ldo = Fa;
+            MTTS_TRY(skinny_launch(k, s));
+        }
+        // prenet backward for this step; the gradient reaches frame t-1 only when step t was free running
+        const bool teach = a.frames_in && a.teacher && a.teacher[t];
+        MTTS_TRY(copy2d(dfeat, g.dpren + ((long)(n - 1) * T + t) * BP, B, P, Fa, P, s));
+        for (int i = n - 1; i >= 0; --i) {
+            float* dz = g.dpren + ((long)i * T + t) * BP;
+            MTTS_TRY(relu_mask_bwd(dz, a.prenet_act[i] + t * BP, dz, BP, a.prenet_mask[i] ? pscale : 1.f, s));
+            if (i > 0 || (!teach && t > 0)) {
+                SkinnyArgs k; memset(&k, 0, sizeof(k));
+                k.nseg = 1; k.B = B; k.ksplit = 1;
+                k.seg[0] = SkSeg{dz, g.prenet_w_T[i], P, P, P, 0, 0};
+                if (i > 0) { k.N = P; k.out = g.dpren + ((long)(i - 1) * T + t) * BP; k.ldo = P; }
+                else { k.N = M; k.out = dframe; k.ldo = M; }
+                MTTS_TRY(skinny_launch(k, s));
+            }
+        }
+        if (!teach && t > 0) MTTS_TRY(add3(dout + (long)t * B * Mo, Mo, dframe, M, nullptr, 0, nullptr, 0, B, M, true, s));
+    }
+    return bwd_post(a, g, true, false, s);
+}
+
 MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* grad, void* stream) {
     const DecoderArgs& a = *fwd;
     const DecoderGradArgs& g = *grad;
@@ -30,7 +209,7 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
     const int B = a.B, L = a.L, T = a.T, M = a.M, P = a.P, H = a.H, A = a.A, Dm = a.Dm;
     const int Mo = round4(M + 1), TB = T * B;
     const long BH = (long)B * H, BD = (long)B * Dm, BL = (long)B * L, B4H = 4 * BH, BP = (long)B * P, BA = (long)B * A;
-    MTTS_REQUIRE(a.fast, "decoder backward: only the fully teacher-forced schedule is implemented (teacher forcing ratio 1.0)");
+    if (!a.fast) return bwd_general(a, g, s);
     MTTS_REQUIRE(!a.zone || (a.training && g.dh_carry_att && g.dh_carry_gen), "decoder backward with zoneout needs training mode and the carry buffers");
     MTTS_REQUIRE(a.q_all && a.gates_att && a.gates_gen, "decoder backward needs q_all and the saved gates");
     MTTS_REQUIRE((A & 3) == 0, "attention dimension must be a multiple of 4");
@@ -150,57 +329,7 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
     }
     MTTS_CHECK_HIP(hipStreamWaitEvent(s, ev_b_done, 0));     // join before the split-K weight-gradient GEMMs
 
-    // ---- prenet backward (batched over all frames)
-    const int n = a.n_prenet;
-    const float pscale = a.p_prenet > 0.f ? 1.f / (1.f - a.p_prenet) : 1.f;
-    float* dp_last = g.dpren + (long)(n - 1) * T * BP;
-    MTTS_TRY(gm(g.dG_att, a.att_w_ih, dp_last, TB, P, 4 * H, 4 * H, P + Dm, P, false, true, 0.f, s));
-    for (int i = n - 1; i >= 0; --i) {
-        float* dz = g.dpren + (long)i * T * BP;
-        MTTS_TRY(relu_mask_bwd(dz, a.prenet_act[i], dz, (long)T * BP, a.prenet_mask[i] ? pscale : 1.f, s));
-        const float* xin = i == 0 ? a.frames_in : a.prenet_act[i - 1];
-        const int Kin = i == 0 ? M : P;
-        MTTS_TRY(gm(dz, xin, g.d_prenet_w[i], P, Kin, TB, P, Kin, Kin, true, true, 0.f, s));
-        MTTS_TRY(colsum(dz, g.d_prenet_b[i], TB, P, P, g.colsum_ws, s));
-        if (i > 0) MTTS_TRY(gm(dz, a.prenet_w[i], g.dpren + (long)(i - 1) * T * BP, TB, P, P, P, P, P, false, true, 0.f, s));
-    }
-    const float* pren = a.prenet_act[n - 1];
-
-    // ---- LSTM weight gradients
-    MTTS_TRY(gm(g.dG_att, pren, g.d_att_w_ih, 4 * H, P, TB, 4 * H, P, P + Dm, true, true, 0.f, s));
-    MTTS_TRY(gm(g.dG_att, a.ctx, g.d_att_w_ih + P, 4 * H, Dm, TB, 4 * H, Dm, P + Dm, true, true, 0.f, s));
-    MTTS_TRY(gm(g.dG_att, a.h_att, g.d_att_w_hh, 4 * H, H, TB, 4 * H, H, H, true, true, 0.f, s));
-    MTTS_TRY(colsum(g.dG_att, g.d_att_b_ih, TB, 4 * H, 4 * H, g.colsum_ws, s));
-    MTTS_TRY(colsum(g.dG_att, g.d_att_b_hh, TB, 4 * H, 4 * H, g.colsum_ws, s));
-    MTTS_TRY(colsum(g.dG_gen, g.d_gen_b_ih, TB, 4 * H, 4 * H, g.colsum_ws, s));
-    MTTS_TRY(colsum(g.dG_gen, g.d_gen_b_hh, TB, 4 * H, 4 * H, g.colsum_ws, s));
-
-    // ---- frame/stop projection and query weights
-    MTTS_TRY(gm(dout1, a.h_gen + BH, g.d_w_out, M + 1, H, TB, Mo, H, H + Dm, true, true, 0.f, s));
-    MTTS_TRY(gm(dout1, a.ctx + BD, g.d_w_out + H, M + 1, Dm, TB, Mo, Dm, H + Dm, true, true, 0.f, s));
-    MTTS_TRY(colsum(dout1, g.d_b_out, TB, M + 1, Mo, g.colsum_ws, s));
-    MTTS_TRY(gm(g.dq_all, a.h_att + BH, g.d_w_query, A, H, TB, A, H, H, true, true, 0.f, s));
-
-    // ---- memory gradient: context path (per-sample align^T dctx), memory-transform path, and W_memory
-    {
-        GemmArgs q; memset(&q, 0, sizeof(q));
-        q.A = a.align; q.B = g.dctx_tot + BD; q.C = g.dmemory;
-        q.M = L; q.N = Dm; q.K = T; q.lda = B * L; q.ldb = B * Dm; q.ldc = Dm;
-        q.transA = 1; q.transB = 1; q.taps = 1; q.Kc = T; q.batch = B; q.zt = 1;
-        q.a_z = L; q.b_z = Dm; q.c_z = (long)L * Dm; q.alpha = 1.f; q.mask_scale = 1.f;
-        MTTS_TRY(mtts_gemm_ex(&q, s));
-    }
-    MTTS_TRY(gm(g.dMt, a.w_memory, g.dmemory, B * L, Dm, A, A, Dm, Dm, false, true, 1.f, s));
-    MTTS_TRY(gm(g.dMt, a.memory, g.d_w_memory, A, Dm, B * L, A, Dm, Dm, true, true, 0.f, s));
-
-    // ---- small attention parameters from the per-workgroup slabs
-    const int nslab = B * g.nch;
-    MTTS_TRY(colsum(g.dU_slab, g.dU, nslab, A * a.ksz, A * a.ksz, g.colsum_ws, s));
-    MTTS_TRY(gm(g.dU, a.w_conv, g.d_w_loc, A, a.C, a.ksz, a.ksz, a.ksz, a.C, false, false, 0.f, s));
-    MTTS_TRY(gm(a.w_loc, g.dU, g.d_w_conv, a.C, a.ksz, A, a.C, a.ksz, a.ksz, true, true, 0.f, s));
-    MTTS_TRY(colsum(g.dv_slab, g.d_w_energy, nslab, A, A, g.colsum_ws, s));
-    MTTS_TRY(colsum(g.dbias_slab, g.d_att_bias, nslab, A, A, g.colsum_ws, s));
-    return 0;
+    return bwd_post(a, g, false, true, s);
 }
 
 MTTS_API int mtts_bilstm_bwd(const BiLstmArgs* fwd, const BiLstmGradArgs* grad, void* stream) {

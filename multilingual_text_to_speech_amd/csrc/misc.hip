@@ -210,3 +210,25 @@ MTTS_API int mtts_pack_rows(const float* src, int ld, int rows, int K, float* ds
     MTTS_CHECK_LAUNCH("pack_rows");
     return 0;
 }
+
+// out[r, c] (+)= a[r, c] + b[r, c] + c3[r, c]  with independent leading dimensions (NULL operands are skipped)
+__global__ void add3_kernel(float* __restrict__ out, int ldo, const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+                            const float* __restrict__ c3, int ldc, int rows, int cols, int accumulate) {
+    const long total = (long)rows * cols;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / cols; const int c = (int)(i - r * cols);
+        float v = accumulate ? out[r * ldo + c] : 0.f;
+        if (a) v += a[r * lda + c];
+        if (b) v += b[r * ldb + c];
+        if (c3) v += c3[r * ldc + c];
+        out[r * ldo + c] = v;
+    }
+}
+
+int add3(float* out, int ldo, const float* a, int lda, const float* b, int ldb, const float* c3, int ldc, int rows, int cols,
+         bool accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(add3_kernel, dim3(nblocks((long)rows * cols)), dim3(256), 0, s, out, ldo, a, lda, b, ldb, c3, ldc, rows, cols,
+                       accumulate ? 1 : 0);
+    MTTS_CHECK_LAUNCH("add3");
+    return 0;
+}

@@ -101,12 +101,12 @@ def injected_masks(fx, device='cuda'):
     return out
 
 
-def hip_forward(fx, model, device='cuda'):
+def hip_forward(fx, model, device='cuda', tf=1.0):
     from multilingual_text_to_speech_amd.masks import provider
     provider.injected = injected_masks(fx, device)
     try:
         to = lambda t: None if t is None else t.to(device)
         return model(to(fx['text']), fx['text_length'], to(fx['target']), fx['target_length'], to(fx['speakers']),
-                     to(fx['languages']), 1.0)
+                     to(fx['languages']), tf)
     finally:
         provider.injected = None
