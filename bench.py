@@ -181,7 +181,7 @@ def main():
             'value': round(frames / dt, 1), 'unit': 'mel-frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * dt / args.steps, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'params/{args.preset} (BASELINE configs[1]) train step, per-GPU batch {B}, L={L} -> T={T}, '
+            'config': {'workload': f'params/{args.preset}' + (' (BASELINE configs[1])' if args.preset == PRESET else '') + f' train step, per-GPU batch {B}, L={L} -> T={T}, '
                                    f'fp32, random-init weights', 'global_batch': B * world, 'parallelism': f'dp{world}',
                        'loss': float(loss.item())},
             'roofline': {'bound': 'mfma', 'kernel': 'skinny_kernel<4> (attention-LSTM step: [B,Dm+H]x[4H,Dm+H]^T + LSTM cell)',

@@ -53,7 +53,7 @@ def decoder_bwd(ctx, dspec, dstop, dalign):
     buf('w_query_T', _e(H, A, device=dev))
     buf('dG_att', _e(T, B, 4 * H, device=dev))
     buf('dG_gen', _e(T, B, 4 * H, device=dev))
-    if H % 16 == 0:      # MFMA-tile-order copies for the per-step input-gradient GEMMs
+    if H % 16 == 0 and st.h_att_p is not None:      # MFMA-tile-order copies for the per-step input-gradient GEMMs
         Bp = (B + 15) & ~15
         buf('dG_att_p', _z(T, Bp * 4 * H, device=dev))
         buf('dG_gen_p', _z(T, Bp * 4 * H, device=dev))

@@ -241,7 +241,7 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
     }
     const int nchunks = (T + CH - 1) / CH;
     std::vector<hipEvent_t> chunk_ev(nchunks);
-    for (int c = nchunks - 1; c >= 0; --c) {
+    auto submit_B = [&](int c) -> int {
         const int c0 = c * CH, c1 = std::min(T, c0 + CH), n = c1 - c0;
         for (int t = c1 - 1; t >= c0; --t) {
             SkinnyArgs k; memset(&k, 0, sizeof(k));
@@ -275,6 +275,56 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
         MTTS_TRY(mtts_gemm_ex(&q, sb));
         chunk_ev[c] = pool_event();
         MTTS_CHECK_HIP(hipEventRecord(chunk_ev[c], sb));
+        return 0;
+    };
+    auto submit_A = [&](int c) -> int {
+        const int c0 = c * CH, c1 = std::min(T, c0 + CH);
+        MTTS_CHECK_HIP(hipStreamWaitEvent(s, chunk_ev[c], 0));
+        for (int t = c1 - 1; t >= c0; --t) {
+            {
+                AttnBwdArgs q; memset(&q, 0, sizeof(q));
+                q.q = a.q_all + t * BA; q.Mt = a.Mt; q.U = a.U; q.bias = a.att_bias; q.v = a.w_energy; q.memory = a.memory;
+                q.ctx = a.ctx + (t + 1) * BD; q.lengths = a.lengths; q.w = a.align + t * BL; q.cum_in = a.cum + t * BL;
+                q.dalign = g.dalign ? g.dalign + t * BL : nullptr;
+                q.dcum_out = g.dcum_all + (t + 1) * BL; q.dcum_in = g.dcum_all + t * BL;
+                q.dctx = g.dctx_all + (t + 1) * BD; q.dctx_total = g.dctx_tot + (t + 1) * BD;
+                if (t < T - 1) { q.part = g.part_att; q.n_part = ksb; q.part_ks = (long)B * (Dm + H); q.part_ld = Dm + H; }
+                q.dq = g.dq_all + t * BA; q.dMt = g.dMt; q.dU_slab = g.dU_slab; q.dv_slab = g.dv_slab; q.dbias_slab = g.dbias_slab;
+                q.B = B; q.L = L; q.A = A; q.Dm = Dm; q.ksz = a.ksz; q.nch = g.nch;
+                MTTS_TRY(mtts_attn_step_bwd(&q, s));
+            }
+            {   // dh_att_t = dq W_q + dHA[t] + (recurrent part of step t+1) -> cell backward
+                SkinnyArgs k; memset(&k, 0, sizeof(k));
+                k.B = B; k.H = H; k.lstm = 2; k.nseg = 1; k.ksplit = 1;
+                k.seg[0] = SkSeg{g.dq_all + t * BA, g.w_query_T, A, A, A, 0, 0};
+                k.dh_a = g.dHA + t * BH; k.ld_dh_a = H;
+                if (t < T - 1) { k.part = g.part_att; k.n_part = ksb; k.part_ks = (long)B * (Dm + H); k.part_ld = Dm + H; k.part_col0 = Dm; }
+                k.gates = a.gates_att + t * B4H; k.c_prev = a.c_att + t * BH;
+                k.dc_in = g.dc_att + ((t + 1) & 1) * BH; k.dc_out = g.dc_att + (t & 1) * BH;
+                if (a.zone) { k.dh_b = g.dh_carry_att + ((t + 1) & 1) * BH; k.dh_carry_out = g.dh_carry_att + (t & 1) * BH; }
+                k.dgates_out = g.dG_att + t * B4H; k.ld_dgates = 4 * H;
+                k.dg_pack_out = g.dG_att_p ? g.dG_att_p + t * Bp4H : nullptr;
+                bwd_reg(a, k, a.att_hmask, a.att_cmask, t);
+                MTTS_TRY(skinny_launch(k, s));
+            }
+            if (t > 0) {   // d[ctx_{t-1}, h_att_{t-1}] = dG_att_t [W_ih[:, P:] | W_hh]
+                SkinnyArgs q; memset(&q, 0, sizeof(q));
+                q.nseg = 1; q.B = B; q.N = Dm + H; q.ksplit = ksb;
+                q.seg[0] = SkSeg{g.dG_att + t * B4H, g.att_w_rec_T, 4 * H, 4 * H, 4 * H, 0, 0};
+                if (g.dG_att_p) { q.seg[0].x = g.dG_att_p + t * Bp4H; q.seg[0].xpack = 1; }
+                if (g.att_w_rec_Tp) { q.seg[0].w = g.att_w_rec_Tp; q.seg[0].wpack = 1; }
+                q.out = g.part_att; q.ldo = Dm + H; q.out_ks = (long)B * (Dm + H);
+                MTTS_TRY(skinny_launch(q, s));
+            }
+
+        }
+        return 0;
+    };
+    // host submission order keeps chain B one chunk ahead of chain A so that neither stream starves
+    MTTS_TRY(submit_B(nchunks - 1));
+    for (int c = nchunks - 1; c >= 0; --c) {
+        if (c > 0) MTTS_TRY(submit_B(c - 1));
+        MTTS_TRY(submit_A(c));
     }
     // generator-side weight gradients also go to the side stream (they only need dG_gen); no split-K there (shared scratch)
     {
@@ -288,45 +338,6 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
     hipEvent_t ev_b_done = pool_event();
     MTTS_CHECK_HIP(hipEventRecord(ev_b_done, sb));
 
-    // ---- chain A: attention + attention LSTM, t = T-1 .. 0
-    for (int t = T - 1; t >= 0; --t) {
-        if (t == T - 1 || ((t + 1) % CH) == 0) MTTS_CHECK_HIP(hipStreamWaitEvent(s, chunk_ev[t / CH], 0));
-        {
-            AttnBwdArgs q; memset(&q, 0, sizeof(q));
-            q.q = a.q_all + t * BA; q.Mt = a.Mt; q.U = a.U; q.bias = a.att_bias; q.v = a.w_energy; q.memory = a.memory;
-            q.ctx = a.ctx + (t + 1) * BD; q.lengths = a.lengths; q.w = a.align + t * BL; q.cum_in = a.cum + t * BL;
-            q.dalign = g.dalign ? g.dalign + t * BL : nullptr;
-            q.dcum_out = g.dcum_all + (t + 1) * BL; q.dcum_in = g.dcum_all + t * BL;
-            q.dctx = g.dctx_all + (t + 1) * BD; q.dctx_total = g.dctx_tot + (t + 1) * BD;
-            if (t < T - 1) { q.part = g.part_att; q.n_part = ksb; q.part_ks = (long)B * (Dm + H); q.part_ld = Dm + H; }
-            q.dq = g.dq_all + t * BA; q.dMt = g.dMt; q.dU_slab = g.dU_slab; q.dv_slab = g.dv_slab; q.dbias_slab = g.dbias_slab;
-            q.B = B; q.L = L; q.A = A; q.Dm = Dm; q.ksz = a.ksz; q.nch = g.nch;
-            MTTS_TRY(mtts_attn_step_bwd(&q, s));
-        }
-        {   // dh_att_t = dq W_q + dHA[t] + (recurrent part of step t+1) -> cell backward
-            SkinnyArgs k; memset(&k, 0, sizeof(k));
-            k.B = B; k.H = H; k.lstm = 2; k.nseg = 1; k.ksplit = 1;
-            k.seg[0] = SkSeg{g.dq_all + t * BA, g.w_query_T, A, A, A, 0, 0};
-            k.dh_a = g.dHA + t * BH; k.ld_dh_a = H;
-            if (t < T - 1) { k.part = g.part_att; k.n_part = ksb; k.part_ks = (long)B * (Dm + H); k.part_ld = Dm + H; k.part_col0 = Dm; }
-            k.gates = a.gates_att + t * B4H; k.c_prev = a.c_att + t * BH;
-            k.dc_in = g.dc_att + ((t + 1) & 1) * BH; k.dc_out = g.dc_att + (t & 1) * BH;
-            if (a.zone) { k.dh_b = g.dh_carry_att + ((t + 1) & 1) * BH; k.dh_carry_out = g.dh_carry_att + (t & 1) * BH; }
-            k.dgates_out = g.dG_att + t * B4H; k.ld_dgates = 4 * H;
-            k.dg_pack_out = g.dG_att_p ? g.dG_att_p + t * Bp4H : nullptr;
-            bwd_reg(a, k, a.att_hmask, a.att_cmask, t);
-            MTTS_TRY(skinny_launch(k, s));
-        }
-        if (t > 0) {   // d[ctx_{t-1}, h_att_{t-1}] = dG_att_t [W_ih[:, P:] | W_hh]
-            SkinnyArgs q; memset(&q, 0, sizeof(q));
-            q.nseg = 1; q.B = B; q.N = Dm + H; q.ksplit = ksb;
-            q.seg[0] = SkSeg{g.dG_att + t * B4H, g.att_w_rec_T, 4 * H, 4 * H, 4 * H, 0, 0};
-            if (g.dG_att_p) { q.seg[0].x = g.dG_att_p + t * Bp4H; q.seg[0].xpack = 1; }
-            if (g.att_w_rec_Tp) { q.seg[0].w = g.att_w_rec_Tp; q.seg[0].wpack = 1; }
-            q.out = g.part_att; q.ldo = Dm + H; q.out_ks = (long)B * (Dm + H);
-            MTTS_TRY(skinny_launch(q, s));
-        }
-    }
     MTTS_CHECK_HIP(hipStreamWaitEvent(s, ev_b_done, 0));     // join before the split-K weight-gradient GEMMs
 
     return bwd_post(a, g, false, true, s);

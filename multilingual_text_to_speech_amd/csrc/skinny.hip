@@ -39,7 +39,7 @@ struct SegTab {
     int K0, K1, K2, ldx0, ldx1, ldx2, ldw0, ldw1, ldw2;
     int xp0, xp1, xp2, wp0, wp1, wp2;     // packed-operand flags per segment
     int n0, n1, n2, total;
-    int cb, mt0;                          // column block / first absolute 16-row tile of this workgroup
+    int cb, mt0, mt_last;                 // column block / first absolute 16-row tile of this workgroup / last existing tile
 };
 
 // Loads are QUAD-COALESCED: lane l fetches 16 B of row (l >> 2) at k-quad (l & 3), so four consecutive lanes cover
@@ -78,7 +78,7 @@ __device__ __forceinline__ void sk_load(const SegTab t, int c, const int (&rows)
     if (xp) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
-            f.x[m] = *reinterpret_cast<const float4*>(sx + (((long)(t.mt0 + m) * nc + cs) * 64 + lane) * 4);
+            f.x[m] = *reinterpret_cast<const float4*>(sx + (((long)min(t.mt0 + m, t.mt_last) * nc + cs) * 64 + lane) * 4);
     } else {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(NT) void skinny_kernel(SkinnyArgs p) {
     t.ldw0 = p.seg[0].ldw; t.ldw1 = p.seg[1].ldw; t.ldw2 = p.seg[2].ldw;
     t.xp0 = p.seg[0].xpack; t.xp1 = p.seg[1].xpack; t.xp2 = p.seg[2].xpack;
     t.wp0 = p.seg[0].wpack; t.wp1 = p.seg[1].wpack; t.wp2 = p.seg[2].wpack;
-    t.cb = cb; t.mt0 = blockIdx.y * MT;
+    t.cb = cb; t.mt0 = blockIdx.y * MT; t.mt_last = ((p.B + 15) >> 4) - 1;
     const int nseg = p.nseg;
     t.n0 = (t.K0 + 15) >> 4;
     t.n1 = nseg > 1 ? (t.K1 + 15) >> 4 : 0;

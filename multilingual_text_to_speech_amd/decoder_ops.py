@@ -3,6 +3,7 @@
 reference: Decoder._decode, modules/tacotron2.py:148-209.
 """
 import ctypes
+import os
 
 import torch
 
@@ -38,7 +39,8 @@ class DecoderState:
         self.q_all = e(T, B, A) if save_gates else None
         # MFMA-tile-order copies of the recurrent operands (only when the widths are multiples of 16)
         Bp = (B + 15) & ~15
-        hp_ok, dp_ok = H % 16 == 0, Dm % 16 == 0
+        use_pack = os.environ.get('MTTS_NO_PACK', '0') != '1'      # debugging / A-B switch: row-major operands only
+        hp_ok, dp_ok = use_pack and H % 16 == 0, use_pack and Dm % 16 == 0
         self.h_att_p = z(T + 1, Bp * H) if hp_ok else None
         self.h_gen_p = z(T + 1, Bp * H) if hp_ok else None
         self.ctx_p = z(T + 1, Bp * Dm) if dp_ok else None

@@ -54,6 +54,13 @@ __global__ __launch_bounds__(NW * 64) void k(const float* __restrict__ X, const 
             for (int s = 0; s < 4; ++s) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[s], wv[s], acc[m], 0, 0, 0);
         }
     };
+    // VAR 7: operands pre-packed in MFMA tile order: [tile][chunk][64 lanes][4]
+    auto load_p = [&](int c, int slot) {
+        if (c < total) {
+            fw[slot] = *reinterpret_cast<const float4*>(W + (((long)cb * total + c) * 64 + lane) * 4);
+            for (int m = 0; m < 4; ++m) fx[slot][m] = *reinterpret_cast<const float4*>(X + (((long)m * total + c) * 64 + lane) * 4);
+        } else { fw[slot] = make_float4(0, 0, 0, 0); for (int m = 0; m < 4; ++m) fx[slot][m] = make_float4(0, 0, 0, 0); }
+    };
     auto mma = [&](int slot) {
         const float wv[4] = {fw[slot].x, fw[slot].y, fw[slot].z, fw[slot].w};
         for (int m = 0; m < 4; ++m) {
@@ -65,12 +72,12 @@ __global__ __launch_bounds__(NW * 64) void k(const float* __restrict__ X, const 
     for (int d = 0; d < DEPTH; ++d) { fw[d] = make_float4(1, 1, 1, 1); for (int m = 0; m < 4; ++m) fx[d][m] = make_float4(1, 1, 1, 1); }
     int c = wave;
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) { if (VAR == 6) load_c(c + d * NW, d); else if (VAR == 5) load_b(c + d * NW, d); else load(c + d * NW, d); }
+    for (int d = 0; d < DEPTH; ++d) { if (VAR == 7) load_p(c + d * NW, d); else if (VAR == 6) load_c(c + d * NW, d); else if (VAR == 5) load_b(c + d * NW, d); else load(c + d * NW, d); }
     for (; c < total; c += DEPTH * NW) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             if (VAR == 6) mma_c(d); else mma(d);
-            if (VAR == 6) load_c(c + (DEPTH + d) * NW, d); else if (VAR == 5) load_b(c + (DEPTH + d) * NW, d); else load(c + (DEPTH + d) * NW, d);
+            if (VAR == 7) load_p(c + (DEPTH + d) * NW, d); else if (VAR == 6) load_c(c + (DEPTH + d) * NW, d); else if (VAR == 5) load_b(c + (DEPTH + d) * NW, d); else load(c + (DEPTH + d) * NW, d);
         }
     }
     for (int m = 0; m < 4; ++m)
@@ -116,6 +123,11 @@ int main() {
     printf("NW4 mfma only    %.2f\n", run<4, 2, 4>(X, W, out, B, K, N, iters));
     printf("NW4 loads only   %.2f\n", run<4, 1, 4>(X, W, out, B, K, N, iters));
     printf("NW16 branch d2   %.2f\n", run<16, 5, 2>(X, W, out, B, K, N, iters));
+    printf("NW8 packed d4 %.2f\n", run<8, 7, 4>(X, W, out, B, K, N, iters));
+    printf("NW8 packed d2 %.2f\n", run<8, 7, 2>(X, W, out, B, K, N, iters));
+    printf("NW8 packed d6 %.2f\n", run<8, 7, 6>(X, W, out, B, K, N, iters));
+    printf("NW4 packed d4 %.2f\n", run<4, 7, 4>(X, W, out, B, K, N, iters));
+    printf("NW16 packed d2 %.2f\n", run<16, 7, 2>(X, W, out, B, K, N, iters));
     printf("NW8 coalesced+perm d4 %.2f\n", run<8, 6, 4>(X, W, out, B, K, N, iters));
     printf("NW4 coalesced+perm d4 %.2f\n", run<4, 6, 4>(X, W, out, B, K, N, iters));
     printf("NW8 coalesced+perm d2 %.2f\n", run<8, 6, 2>(X, W, out, B, K, N, iters));

@@ -197,3 +197,32 @@ def test_train_step_gradients_match_oracle_at_real_widths(preset, B):
         err = (p.grad.cpu() - r).abs().max().item()
         tol = 1e-3 * r.abs().max().item() + 2e-5
         assert err <= tol, f'{preset}/{k}: max |delta| {err:.3e} > {tol:.3e}'
+
+
+@pytest.mark.parametrize('preset,B', [('generated_switching', 40), ('shared_training', 72)])
+def test_packed_operands_equal_row_major_for_odd_batches(preset, B, monkeypatch):
+    """Batches that are not multiples of 16 / exceed one 64-row tile: the MFMA-tile-order ('packed') operand path must give
+    the same outputs and gradients as the plain row-major path (regression test for an out-of-range row tile)."""
+    from multilingual_text_to_speech_amd.params import presets, Params as hp
+    from multilingual_text_to_speech_amd.modules.tacotron2 import Tacotron
+    from multilingual_text_to_speech_amd.masks import provider
+    presets.apply(preset, speaker_number=7)
+    torch.manual_seed(3)
+    model = Tacotron().cuda().train()
+    L, T = 30, 12
+    text, tl, target, tgl, spk, lang = _random_batch(hp, B, L, T, seed=4)
+    results = []
+    for no_pack in ('0', '1'):
+        monkeypatch.setenv('MTTS_NO_PACK', no_pack)
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(100)                      # identical dropout draws
+        to = lambda t: None if t is None else t.cuda()
+        post, pre, stop, align, _, enc = model(to(text), tl, to(target), tgl, to(spk), to(lang), 1.0)
+        (post.square().mean() + align.square().sum() * 1e-3 + stop.clamp(-5, 5).mean()).backward()
+        torch.cuda.synchronize()
+        results.append((post.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}))
+    (p0, g0), (p1, g1) = results
+    assert torch.isfinite(p0).all()
+    assert (p0 - p1).abs().max().item() <= 1e-5
+    for k in g0:
+        assert (g0[k] - g1[k]).abs().max().item() <= 1e-4 * g0[k].abs().max().item() + 1e-6, k
