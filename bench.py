@@ -60,6 +60,16 @@ def train_step(model, crit, opt, buckets, batch, hp):
     return loss
 
 
+def pmc_traffic(preset, B):
+    """HBM bytes per launch of the roofline kernel from the committed PMC measurement (rocprofv3 --pmc cannot run inside the
+    timed process); None when this workload was not measured."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
+            return json.load(f).get(f'{preset}/B{B}', {}).get('traffic_bytes')
+    except OSError:
+        return None
+
+
 def cpu_baseline(seconds_budget=25.0):
     """Time the CPU oracle (port of the reference) on a bounded sample: same config, batch 8, 40 frames."""
     from oracle import tacotron_oracle as O
@@ -188,7 +198,7 @@ def main():
                          'achieved': round(achieved, 2), 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': round(achieved / 157.3, 4),
                          'flop_per_launch': flop, 'bytes_per_launch': bytes_alg, 'avg_launch_us': round(avg_s * 1e6, 2),
                          'hbm_frac_of_8TBps': round(bytes_alg / avg_s / 8e12, 4) if avg_s > 0 else 0.0, 'samples': cnt.value,
-                         'traffic': None},
+                         'traffic': pmc_traffic(args.preset, B)},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:      # separate process + hard timeout: the baseline is reporting only, never lose the GPU number over it

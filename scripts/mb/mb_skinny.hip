@@ -7,7 +7,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 template <int NW, int VAR, int DEPTH>
 __global__ __launch_bounds__(NW * 64) void k(const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ out,
-                                              int B, int K, int N) {
+                                              int B, int K, int N, float* __restrict__ qacc, const float* __restrict__ Wq) {
     __shared__ float red[NW][64][17];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -72,12 +72,12 @@ __global__ __launch_bounds__(NW * 64) void k(const float* __restrict__ X, const 
     for (int d = 0; d < DEPTH; ++d) { fw[d] = make_float4(1, 1, 1, 1); for (int m = 0; m < 4; ++m) fx[d][m] = make_float4(1, 1, 1, 1); }
     int c = wave;
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) { if (VAR == 7) load_p(c + d * NW, d); else if (VAR == 6) load_c(c + d * NW, d); else if (VAR == 5) load_b(c + d * NW, d); else load(c + d * NW, d); }
+    for (int d = 0; d < DEPTH; ++d) { if (VAR == 7 || VAR == 8) load_p(c + d * NW, d); else if (VAR == 6) load_c(c + d * NW, d); else if (VAR == 5) load_b(c + d * NW, d); else load(c + d * NW, d); }
     for (; c < total; c += DEPTH * NW) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             if (VAR == 6) mma_c(d); else mma(d);
-            if (VAR == 7) load_p(c + (DEPTH + d) * NW, d); else if (VAR == 6) load_c(c + (DEPTH + d) * NW, d); else if (VAR == 5) load_b(c + (DEPTH + d) * NW, d); else load(c + (DEPTH + d) * NW, d);
+            if (VAR == 7 || VAR == 8) load_p(c + (DEPTH + d) * NW, d); else if (VAR == 6) load_c(c + (DEPTH + d) * NW, d); else if (VAR == 5) load_b(c + (DEPTH + d) * NW, d); else load(c + (DEPTH + d) * NW, d);
         }
     }
     for (int m = 0; m < 4; ++m)
@@ -88,15 +88,27 @@ __global__ __launch_bounds__(NW * 64) void k(const float* __restrict__ X, const 
         float v = 0.f;
         for (int w = 0; w < NW; ++w) v += red[w][rr][cc];
         out[(long)rr * N + cb * 16 + cc] = v;
+        if (VAR == 8) red[0][rr][cc] = v;
+    }
+    if (VAR == 8) {     // q[b, a] += sum over this block's 4 'units' of Wq[a][u] * h[b][u]  (8192 atomics per workgroup)
+        __syncthreads();
+        for (int e = tid; e < 64 * 128; e += NW * 64) {
+            const int b = e >> 7, a = e & 127;
+            const float4 wq = *reinterpret_cast<const float4*>(Wq + (long)a * 1024 + cb * 4);
+            const float v = wq.x * red[0][b][0] + wq.y * red[0][b][1] + wq.z * red[0][b][2] + wq.w * red[0][b][3];
+            atomicAdd(qacc + b * 128 + a, v);
+        }
     }
 }
 
 template <int NW, int VAR, int DEPTH>
 float run(const float* X, const float* W, float* out, int B, int K, int N, int iters) {
+    static float* qacc = nullptr; static float* Wq = nullptr;
+    if (!qacc) { hipMalloc(&qacc, 64 * 128 * 4); hipMalloc(&Wq, 128 * 1024 * 4); hipMemset(qacc, 0, 64 * 128 * 4); hipMemset(Wq, 0, 128 * 1024 * 4); }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((k<NW, VAR, DEPTH>), dim3(N / 16), dim3(NW * 64), 0, 0, X, W, out, B, K, N);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((k<NW, VAR, DEPTH>), dim3(N / 16), dim3(NW * 64), 0, 0, X, W, out, B, K, N, qacc, Wq);
     hipEventRecord(e0, 0);
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((k<NW, VAR, DEPTH>), dim3(N / 16), dim3(NW * 64), 0, 0, X, W, out, B, K, N);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((k<NW, VAR, DEPTH>), dim3(N / 16), dim3(NW * 64), 0, 0, X, W, out, B, K, N, qacc, Wq);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     return ms * 1000.f / iters;
@@ -125,6 +137,7 @@ int main() {
     printf("NW16 branch d2   %.2f\n", run<16, 5, 2>(X, W, out, B, K, N, iters));
     printf("NW8 packed d4 %.2f\n", run<8, 7, 4>(X, W, out, B, K, N, iters));
     printf("NW8 packed d2 %.2f\n", run<8, 7, 2>(X, W, out, B, K, N, iters));
+    printf("NW8 packed d2 + q atomics %.2f\n", run<8, 8, 2>(X, W, out, B, K, N, iters));
     printf("NW8 packed d6 %.2f\n", run<8, 7, 6>(X, W, out, B, K, N, iters));
     printf("NW4 packed d4 %.2f\n", run<4, 7, 4>(X, W, out, B, K, N, iters));
     printf("NW16 packed d2 %.2f\n", run<16, 7, 2>(X, W, out, B, K, N, iters));
