@@ -450,6 +450,59 @@ typedef struct BiLstmGradArgs {
 
 int mtts_bilstm_bwd(const BiLstmArgs* fwd, const BiLstmGradArgs* grad, void* stream);
 
+/* ---- training loss and optimizer step -----------------------------------------------------
+ * mtts_tacotron_loss: TacotronLoss.forward (modules/tacotron2.py:443-485) without the classifier term: values in out[0..4]
+ * (mel_pre, mel_pos, stop_token, guided_att, total) and the gradients w.r.t. pre/post/stop/alignment scaled by gscale. */
+typedef struct TacoLossArgs {
+    const float* pre;          /* [B,M,T] */
+    const float* post;         /* [B,M,T] */
+    const float* target;       /* [B,M,T] */
+    const float* stop;         /* [B,T] logits */
+    const float* stop_target;  /* [B,T] */
+    const float* align;        /* [B,T,L] or NULL */
+    const int* text_len;       /* [B] */
+    const int* target_len;     /* [B] */
+    float* d_pre;
+    float* d_post;
+    float* d_stop;
+    float* d_align;
+    float* partials;           /* [nblk*4] */
+    float* out;                /* [5] */
+    int B;
+    int M;
+    int T;
+    int L;
+    int nblk;
+    int ga_on;                 /* guided attention active (guided_att_steps > 0) */
+    float g;                   /* guided attention tolerance */
+    float pos_weight;          /* 100 in the reference */
+    float gscale;              /* upstream gradient of the total loss (1 for loss.backward()) */
+} TacoLossArgs;
+
+int mtts_tacotron_loss(const TacoLossArgs* args, void* stream);
+
+/* mtts_clip_adam_step: torch.nn.utils.clip_grad_norm_(params, max_norm) followed by torch.optim.Adam.step() with L2-coupled
+ * weight decay (train.py:84-85,260).  ptrs: device array of 4 pointers per tensor {param, grad, exp_avg, exp_avg_sq};
+ * chunks partition every tensor into blocks of work. */
+typedef struct AdamArgs {
+    const int64_t* ptrs;
+    const int* chunk_tensor;
+    const int64_t* chunk_off;
+    const int* chunk_len;
+    float* norm_partials;      /* [nchunks] */
+    float* norm_out;           /* [2]: total gradient norm, clip coefficient */
+    int nchunks;
+    float max_norm;            /* <= 0: no clipping */
+    float weight_decay;
+    float beta1;
+    float beta2;
+    float eps;
+    float step_size;           /* lr / (1 - beta1^t) */
+    float inv_sqrt_bc2;        /* 1 / sqrt(1 - beta2^t) */
+} AdamArgs;
+
+int mtts_clip_adam_step(const AdamArgs* args, void* stream);
+
 /* ---- small data-movement kernels --------------------------------------------------------------------------- */
 /* Embedding lookup (modules/tacotron2.py:363, :122 speaker/language tables): out[r, col0:col0+D] = table[ids[r]] */
 int mtts_embedding_fwd(const float* table, const int64_t* ids, float* out, int rows, int D, int ldo, int col0, void* stream);
@@ -480,7 +533,7 @@ int mtts_prof_end(float* total_ms, int* count);
 
 const char* mtts_last_error(void);
 int mtts_version(void);
-/* sizeof() of the structs above in declaration order (0 = GemmArgs ... 6 = BiLstmArgs, 7 = AttnBwdArgs, 8 = DecoderGradArgs, 9 = BiLstmGradArgs); -1 when out of range */
+/* sizeof() of the structs above in declaration order (0 = GemmArgs ... 6 = BiLstmArgs, 7 = AttnBwdArgs, 8 = DecoderGradArgs, 9 = BiLstmGradArgs, 10 = TacoLossArgs, 11 = AdamArgs); -1 when out of range */
 int mtts_sizeof_struct(int which);
 
 #ifdef __cplusplus

@@ -28,6 +28,8 @@ MTTS_API int mtts_sizeof_struct(int which) {
         case 7: return (int)sizeof(AttnBwdArgs);
         case 8: return (int)sizeof(DecoderGradArgs);
         case 9: return (int)sizeof(BiLstmGradArgs);
+        case 10: return (int)sizeof(TacoLossArgs);
+        case 11: return (int)sizeof(AdamArgs);
         default: return -1;
     }
 }

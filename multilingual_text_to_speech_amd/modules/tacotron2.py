@@ -274,15 +274,28 @@ class TacotronLoss(Module):
         pre_target.requires_grad = False
         post_target.requires_grad = False
         target_stop.requires_grad = False
-        stop_balance = torch.tensor([100], device=stop.device, dtype=torch.float32)
-        losses = {
-            'mel_pre': 2 * F.mse_loss(pre_prediction, pre_target),
-            'mel_pos': F.mse_loss(post_prediction, post_target),
-            'stop_token': F.binary_cross_entropy_with_logits(stop, target_stop, pos_weight=stop_balance) / (hp.num_mels + 2),
-        }
+        if pre_prediction.is_cuda and pre_target is post_target:
+            # fused HIP path: all four terms and their gradients in one pass (mtts_tacotron_loss)
+            from ..optim import TacotronLossFn
+            ga_on = bool(hp.guided_attention_loss) and self._g_steps > 0
+            v = TacotronLossFn.apply(pre_prediction, post_prediction, stop, alignment if hp.guided_attention_loss else None,
+                                     pre_target, target_stop, source_length, target_length, self._g, ga_on, 100.0)
+            losses = {'mel_pre': v[0], 'mel_pos': v[1], 'stop_token': v[2]}
+            total = v[4]
+            if hp.guided_attention_loss:
+                losses['guided_att'] = v[3] if ga_on else 0
+        else:
+            stop_balance = torch.tensor([100], device=stop.device, dtype=torch.float32)
+            losses = {
+                'mel_pre': 2 * F.mse_loss(pre_prediction, pre_target),
+                'mel_pos': F.mse_loss(post_prediction, post_target),
+                'stop_token': F.binary_cross_entropy_with_logits(stop, target_stop, pos_weight=stop_balance) / (hp.num_mels + 2),
+            }
+            if hp.guided_attention_loss:
+                losses['guided_att'] = self._guided_attention(alignment, source_length, target_length)
+            total = sum(losses.values())
         if hp.reversal_classifier:
-            losses['lang_class'] = ReversalClassifier.loss(source_length, speaker, speaker_prediction)
-            losses['lang_class'] *= hp.reversal_classifier_w / (hp.num_mels + 2)
-        if hp.guided_attention_loss:
-            losses['guided_att'] = self._guided_attention(alignment, source_length, target_length)
-        return sum(losses.values()), losses
+            losses['lang_class'] = ReversalClassifier.loss(source_length, speaker, speaker_prediction) * \
+                (hp.reversal_classifier_w / (hp.num_mels + 2))
+            total = total + losses['lang_class']
+        return total, losses

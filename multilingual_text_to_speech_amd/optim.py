@@ -1,0 +1,109 @@
+"""Fused loss and optimizer step on top of mtts_tacotron_loss / mtts_clip_adam_step."""
+import ctypes
+import math
+
+import torch
+
+from . import _C
+from ._C import check, lib, ptr, require_gpu, stream_ptr
+
+
+class TacotronLossFn(torch.autograd.Function):
+    """2*MSE(pre) + MSE(post) + BCE(stop, pos_weight 100)/(M+2) + guided attention, values and gradients in one pass
+    (reference modules/tacotron2.py:443-485).  Returns the five-vector (mel_pre, mel_pos, stop_token, guided_att, total)."""
+
+    @staticmethod
+    def forward(ctx, pre, post, stop, align, target, stop_target, text_len, target_len, g, ga_on, pos_weight):
+        require_gpu(pre, post, stop, target)
+        pre, post, stop, target, stop_target = (t.contiguous() for t in (pre, post, stop, target, stop_target))
+        align = align.contiguous() if align is not None else None
+        B, M, T = pre.shape
+        dev = pre.device
+        a = _C.TacoLossArgs()
+        d_pre, d_post, d_stop = torch.empty_like(pre), torch.empty_like(post), torch.empty_like(stop)
+        d_align = torch.empty_like(align) if align is not None else None
+        nblk = 1024
+        partials = torch.empty(nblk * 4, dtype=torch.float32, device=dev)
+        out = torch.empty(5, dtype=torch.float32, device=dev)
+        tl = text_len.to(device=dev, dtype=torch.int32).contiguous()
+        fl = target_len.to(device=dev, dtype=torch.int32).contiguous()
+        a.pre, a.post, a.target, a.stop, a.stop_target, a.align = ptr(pre), ptr(post), ptr(target), ptr(stop), ptr(stop_target), ptr(align)
+        a.text_len, a.target_len = ptr(tl), ptr(fl)
+        a.d_pre, a.d_post, a.d_stop, a.d_align, a.partials, a.out = ptr(d_pre), ptr(d_post), ptr(d_stop), ptr(d_align), ptr(partials), ptr(out)
+        a.B, a.M, a.T, a.L, a.nblk = B, M, T, (align.shape[2] if align is not None else 0), nblk
+        a.ga_on, a.g, a.pos_weight, a.gscale = int(ga_on), float(g), float(pos_weight), 1.0
+        check(lib().mtts_tacotron_loss(ctypes.byref(a), stream_ptr()), 'mtts_tacotron_loss')
+        ctx.save_for_backward(d_pre, d_post, d_stop, d_align)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        d_pre, d_post, d_stop, d_align = ctx.saved_tensors
+        # d(total)/d(x): every term enters `total` with weight 1, so the upstream scale is dout[4] plus the per-term entries
+        s = dout[4]
+        return ((dout[0] + s) * d_pre, (dout[1] + s) * d_post, (dout[2] + s) * d_stop,
+                None if d_align is None else (dout[3] + s) * d_align, None, None, None, None, None, None, None)
+
+
+class FusedAdam(torch.optim.Adam):
+    """torch.optim.Adam (same hyper-parameters, same state_dict layout: step / exp_avg / exp_avg_sq) whose `step` runs
+    clip_grad_norm_ + the Adam update in three kernel launches over a device-side tensor table
+    (reference train.py:84-85: clip_grad_norm_(0.25) then Adam(lr, weight_decay=L2-coupled))."""
+
+    CHUNK = 1 << 16
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        self._tables = {}
+
+    def _table(self, gi, plist):
+        key = (gi, tuple((p.data_ptr(), p.grad.data_ptr()) for p in plist))
+        t = self._tables.get(gi)
+        if t is not None and t['key'] == key:
+            return t
+        dev = plist[0].device
+        ptrs, ct, co, cl = [], [], [], []
+        for i, p in enumerate(plist):
+            st = self.state[p]
+            ptrs += [p.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr()]
+            n = p.numel()
+            for off in range(0, n, self.CHUNK):
+                ct.append(i); co.append(off); cl.append(min(self.CHUNK, n - off))
+        t = dict(key=key, n=len(ct),
+                 ptrs=torch.tensor(ptrs, dtype=torch.int64, device=dev), ct=torch.tensor(ct, dtype=torch.int32, device=dev),
+                 co=torch.tensor(co, dtype=torch.int64, device=dev), cl=torch.tensor(cl, dtype=torch.int32, device=dev),
+                 partials=torch.empty(len(ct), dtype=torch.float32, device=dev), norm=torch.zeros(2, dtype=torch.float32, device=dev))
+        self._tables[gi] = t
+        return t
+
+    @torch.no_grad()
+    def step(self, closure=None, max_norm=0.0):
+        """One update; `max_norm > 0` applies clip_grad_norm_ over this optimizer's parameters first.  Returns the device
+        tensor [grad_norm, clip_coefficient] of the (last) parameter group."""
+        norm = None
+        for gi, group in enumerate(self.param_groups):
+            plist = [p for p in group['params'] if p.grad is not None]
+            if not plist:
+                continue
+            require_gpu(*plist)
+            for p in plist:
+                st = self.state[p]
+                if len(st) == 0:
+                    st['step'] = torch.tensor(0.0)
+                    st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                assert p.is_contiguous() and p.grad.is_contiguous()
+            step = int(self.state[plist[0]]['step']) + 1
+            for p in plist:
+                self.state[p]['step'] += 1
+            t = self._table(gi, plist)
+            b1, b2 = group['betas']
+            a = _C.AdamArgs()
+            a.ptrs, a.chunk_tensor, a.chunk_off, a.chunk_len = ptr(t['ptrs']), ptr(t['ct']), ptr(t['co']), ptr(t['cl'])
+            a.norm_partials, a.norm_out, a.nchunks = ptr(t['partials']), ptr(t['norm']), t['n']
+            a.max_norm, a.weight_decay, a.beta1, a.beta2, a.eps = float(max_norm), group['weight_decay'], b1, b2, group['eps']
+            a.step_size = group['lr'] / (1 - b1 ** step)
+            a.inv_sqrt_bc2 = 1.0 / math.sqrt(1 - b2 ** step)
+            check(lib().mtts_clip_adam_step(ctypes.byref(a), stream_ptr()), 'mtts_clip_adam_step')
+            norm = t['norm']
+        return norm
