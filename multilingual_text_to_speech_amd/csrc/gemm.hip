@@ -310,14 +310,17 @@ MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
         }
     }
     dim3 grid(ntx * nty, S, p.batch * p.zt);
-    const size_t lds = 4 * LDS_A * sizeof(float);
+    // side-stream launches (nosplit) ask for > half of the CU's LDS so that only ONE GEMM workgroup sits on a CU and the
+    // latency-critical step kernels of the main stream always find room next to it
+    const size_t lds_base = 4 * LDS_A * sizeof(float);
+    const size_t lds = p.nosplit ? (size_t)96 * 1024 : lds_base;
     hipStream_t s = (hipStream_t)stream;
     static bool attr_done = false;
     if (!attr_done) {   // > 64 KiB of dynamic LDS needs the opt-in attribute
-        hipFuncSetAttribute((const void*)gemm_mfma_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute((const void*)gemm_mfma_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute((const void*)gemm_mfma_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute((const void*)gemm_mfma_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)gemm_mfma_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute((const void*)gemm_mfma_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute((const void*)gemm_mfma_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute((const void*)gemm_mfma_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr_done = true;
     }
     float* ws = g_ws_host;
