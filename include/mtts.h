@@ -393,8 +393,9 @@ typedef struct DecoderGradArgs {
     float* dcum_all;       /* [T+1,B,L] zero-initialised */
     float* dq_all;         /* [T,B,A] zero-initialised */
     float* part_gen;       /* [ksb,B,H] */
-    float* part_att;       /* [ksb,B,Dm+H] */
+    float* part_att;       /* [ksb_ctx,B,Dm] followed by [ksb,B,H] */
     int ksb;
+    int ksb_ctx;           /* K-splits of the context-column input-gradient GEMM (0: same as ksb) */
     float* dc_att;         /* [2,B,H] zero-initialised */
     float* dc_gen;         /* [2,B,H] zero-initialised */
     float* dh_carry_att;   /* [2,B,H] zero-initialised: part of dh that bypasses the cell (zoneout) */

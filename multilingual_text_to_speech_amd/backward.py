@@ -76,8 +76,9 @@ def decoder_bwd(ctx, dspec, dstop, dalign):
     buf('dcum_all', _z(T + 1, B, L, device=dev))
     buf('dq_all', _z(T, B, A, device=dev))
     buf('part_gen', _z(ksb, B, H, device=dev))
-    buf('part_att', _z(ksb, B, Dm + H, device=dev))
-    g.ksb, g.nch = ksb, nch
+    ksc = cfg.get('ksb_ctx', 8)
+    buf('part_att', _z(ksc * B * Dm + ksb * B * H, device=dev))
+    g.ksb, g.nch, g.ksb_ctx = ksb, nch, ksc
     buf('dc_att', _z(2, B, H, device=dev))
     buf('dc_gen', _z(2, B, H, device=dev))
     buf('dh_carry_att', _z(2, B, H, device=dev))

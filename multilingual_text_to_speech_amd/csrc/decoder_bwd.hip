@@ -277,6 +277,19 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
         MTTS_CHECK_HIP(hipEventRecord(chunk_ev[c], sb));
         return 0;
     };
+    // Chain A per step t:  { attention backward(t)  ||  dG_att(t+1) W_hh^T }  ->  dq W_q + cell backward(t)  ->  dG_att(t) W_ih[:, P:]^T
+    // The h-columns of the input gradient are only needed by the cell backward, so they share the attention backward's launch
+    // ("fat launch"); the ctx-columns sit on the critical path and get their own, smaller launch.
+    const int ksc = g.ksb_ctx > 0 ? g.ksb_ctx : ksb;
+    float* part_ctx = g.part_att;                               // [ksc][B][Dm]
+    float* part_h = g.part_att + (long)ksc * B * Dm;            // [ksb][B][H]
+    const int cb_ctx = Dm >> 4;                                 // packed tiles of the ctx rows of [W_ih[:, P:] | W_hh]^T
+    auto gemm_seg = [&](int t, bool h_part) {
+        SkSeg sg = SkSeg{g.dG_att + t * B4H, g.att_w_rec_T + (h_part ? (long)Dm * 4 * H : 0), 4 * H, 4 * H, 4 * H, 0, 0};
+        if (g.dG_att_p) { sg.x = g.dG_att_p + t * Bp4H; sg.xpack = 1; }
+        if (g.att_w_rec_Tp && (Dm & 15) == 0) { sg.w = g.att_w_rec_Tp + (h_part ? (long)cb_ctx * (4 * H / 16) * 256 : 0); sg.wpack = 1; }
+        return sg;
+    };
     auto submit_A = [&](int c) -> int {
         const int c0 = c * CH, c1 = std::min(T, c0 + CH);
         MTTS_CHECK_HIP(hipStreamWaitEvent(s, chunk_ev[c], 0));
@@ -288,17 +301,25 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
                 q.dalign = g.dalign ? g.dalign + t * BL : nullptr;
                 q.dcum_out = g.dcum_all + (t + 1) * BL; q.dcum_in = g.dcum_all + t * BL;
                 q.dctx = g.dctx_all + (t + 1) * BD; q.dctx_total = g.dctx_tot + (t + 1) * BD;
-                if (t < T - 1) { q.part = g.part_att; q.n_part = ksb; q.part_ks = (long)B * (Dm + H); q.part_ld = Dm + H; }
+                if (t < T - 1) { q.part = part_ctx; q.n_part = ksc; q.part_ks = BD; q.part_ld = Dm; }
                 q.dq = g.dq_all + t * BA; q.dMt = g.dMt; q.dU_slab = g.dU_slab; q.dv_slab = g.dv_slab; q.dbias_slab = g.dbias_slab;
                 q.B = B; q.L = L; q.A = A; q.Dm = Dm; q.ksz = a.ksz; q.nch = g.nch;
-                MTTS_TRY(mtts_attn_step_bwd(&q, s));
+                if (t < T - 1) {     // fat launch with the h-columns of step t+1's input gradient
+                    SkinnyArgs k; memset(&k, 0, sizeof(k));
+                    k.nseg = 1; k.B = B; k.N = H; k.ksplit = ksb;
+                    k.seg[0] = gemm_seg(t + 1, true);
+                    k.out = part_h; k.ldo = H; k.out_ks = BH;
+                    MTTS_TRY(attn_bwd_plus_skinny(q, k, s));
+                } else {
+                    MTTS_TRY(mtts_attn_step_bwd(&q, s));
+                }
             }
             {   // dh_att_t = dq W_q + dHA[t] + (recurrent part of step t+1) -> cell backward
                 SkinnyArgs k; memset(&k, 0, sizeof(k));
                 k.B = B; k.H = H; k.lstm = 2; k.nseg = 1; k.ksplit = 1;
                 k.seg[0] = SkSeg{g.dq_all + t * BA, g.w_query_T, A, A, A, 0, 0};
                 k.dh_a = g.dHA + t * BH; k.ld_dh_a = H;
-                if (t < T - 1) { k.part = g.part_att; k.n_part = ksb; k.part_ks = (long)B * (Dm + H); k.part_ld = Dm + H; k.part_col0 = Dm; }
+                if (t < T - 1) { k.part = part_h; k.n_part = ksb; k.part_ks = BH; k.part_ld = H; k.part_col0 = 0; }
                 k.gates = a.gates_att + t * B4H; k.c_prev = a.c_att + t * BH;
                 k.dc_in = g.dc_att + ((t + 1) & 1) * BH; k.dc_out = g.dc_att + (t & 1) * BH;
                 if (a.zone) { k.dh_b = g.dh_carry_att + ((t + 1) & 1) * BH; k.dh_carry_out = g.dh_carry_att + (t & 1) * BH; }
@@ -307,16 +328,13 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
                 bwd_reg(a, k, a.att_hmask, a.att_cmask, t);
                 MTTS_TRY(skinny_launch(k, s));
             }
-            if (t > 0) {   // d[ctx_{t-1}, h_att_{t-1}] = dG_att_t [W_ih[:, P:] | W_hh]
+            if (t > 0) {   // d ctx_{t-1} = dG_att_t W_ih[:, P:]  (critical path of the next attention backward)
                 SkinnyArgs q; memset(&q, 0, sizeof(q));
-                q.nseg = 1; q.B = B; q.N = Dm + H; q.ksplit = ksb;
-                q.seg[0] = SkSeg{g.dG_att + t * B4H, g.att_w_rec_T, 4 * H, 4 * H, 4 * H, 0, 0};
-                if (g.dG_att_p) { q.seg[0].x = g.dG_att_p + t * Bp4H; q.seg[0].xpack = 1; }
-                if (g.att_w_rec_Tp) { q.seg[0].w = g.att_w_rec_Tp; q.seg[0].wpack = 1; }
-                q.out = g.part_att; q.ldo = Dm + H; q.out_ks = (long)B * (Dm + H);
+                q.nseg = 1; q.B = B; q.N = Dm; q.ksplit = ksc;
+                q.seg[0] = gemm_seg(t, false);
+                q.out = part_ctx; q.ldo = Dm; q.out_ks = BD;
                 MTTS_TRY(skinny_launch(q, s));
             }
-
         }
         return 0;
     };

@@ -1,0 +1,368 @@
+// Skinny (small-M) fp32 MFMA GEMM for the autoregressive steps:  Y[B,N] = sum_s X_s[B,K_s] * W_s[N,K_s]^T
+// with B = batch rows (<= 64 per row tile), N = thousands of weight rows streamed once per step.
+//
+// This is the recurrent hot loop of the decoder (reference modules/layers.py:18-47 LSTMCell call sites
+// modules/tacotron2.py:185,188; attention query modules/attention.py:68; frame/stop projection
+// modules/tacotron2.py:192-193) and of the encoder BiLSTM (modules/encoder.py:41-44), forward and backward.
+//
+// Decomposition (gfx950): one workgroup owns 16 output columns for all rows of its row tile; its 8 waves
+// (two per SIMD) take the 16-wide K chunks round-robin and reduce through LDS.  Weights go L2/HBM -> VGPR
+// directly (each weight row is consumed by exactly one workgroup: LDS staging would be pure overhead),
+// 16 B per lane along K; the MFMA k-slot trick (slot q <-> k = k0 + 4q + s for instruction s) turns one
+// float4 per lane into four v_mfma_f32_16x16x4_f32.  Inputs may be given as up to 3 K-segments so the
+// concatenations [prenet, context, h] / [h_att, context, h_gen] are never materialised.
+//
+// These kernels are memory-LATENCY bound (a step is a few microseconds of MFMA work behind ~1-2 us round
+// trips), so the structure is about bytes in flight:
+//   * the chunk index is wave-uniform (readfirstlane) -> scalar segment selection, branch-free loads
+//     (clamped addresses, zero-select on the K tail), 4 chunks per wave in flight, 8 waves per CU;
+//   * every operand of the epilogue (precomputed gate addends, biases, previous cell state, masks,
+//     saved gates, partial sums of the later step) is requested BEFORE the main loop, so the epilogue
+//     adds no further round trip.
+//
+// Epilogues: raw (optionally K-split partials), bias+activation+dropout, the fused LSTM cell
+// (gate nonlinearities, cell update, dropout / zoneout on h, packed-sequence carry, saved gates) and the
+// LSTM cell backward.
+#pragma once
+#include "common.h"
+
+constexpr int NW = 8;                 // waves per workgroup
+constexpr int NT = NW * 64;
+
+template <int MT>
+struct Frag { float4 w; float4 x[MT]; bool xp, wp; };   // xp/wp: operand already in MFMA tile order (wave-uniform)
+
+// Segment table held in registers (SGPRs): copied field-by-field from the kernel argument so that the
+// compiler never needs the argument struct in memory (address-selects on it would force a scratch copy).
+struct SegTab {
+    const float* x0; const float* x1; const float* x2;
+    const float* w0; const float* w1; const float* w2;
+    int K0, K1, K2, ldx0, ldx1, ldx2, ldw0, ldw1, ldw2;
+    int xp0, xp1, xp2, wp0, wp1, wp2;     // packed-operand flags per segment
+    int n0, n1, n2, total;
+    int cb, mt0, mt_last;                 // column block / first absolute 16-row tile of this workgroup / last existing tile
+};
+
+// Loads are QUAD-COALESCED: lane l fetches 16 B of row (l >> 2) at k-quad (l & 3), so four consecutive lanes cover
+// 64 contiguous bytes and one wave instruction covers a 16-row x 16-k tile in 16 requests.  (Fetching directly in the
+// MFMA operand layout - row = l & 15, k-quad = l >> 4 - puts consecutive lanes on different rows: 64 separate 16-B
+// requests per instruction, and the texture-address unit becomes the bottleneck: 18 us -> 12.5 us per LSTM step.)
+// The MFMA layout is restored in registers with ds_bpermute when the fragment is consumed.
+template <int MT>
+__device__ __forceinline__ void sk_load(const SegTab t, int c, const int (&rows)[MT], int wrow, int kq, int lane, Frag<MT>& f) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    f.w = z; f.xp = true; f.wp = true;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) f.x[m] = z;
+    if (c >= t.total) return;                       // wave-uniform
+    // chunk index (global over the segments) -> segment parameters; everything here is wave-uniform
+    const bool in0 = c < t.n0, in1 = c < t.n0 + t.n1;
+    const float* sx = in0 ? t.x0 : (in1 ? t.x1 : t.x2);
+    const float* sw = in0 ? t.w0 : (in1 ? t.w1 : t.w2);
+    const int sK = in0 ? t.K0 : (in1 ? t.K1 : t.K2);
+    const int ldx = in0 ? t.ldx0 : (in1 ? t.ldx1 : t.ldx2);
+    const int ldw = in0 ? t.ldw0 : (in1 ? t.ldw1 : t.ldw2);
+    const int xp = in0 ? t.xp0 : (in1 ? t.xp1 : t.xp2);
+    const int wp = in0 ? t.wp0 : (in1 ? t.wp1 : t.wp2);
+    const int nc = in0 ? t.n0 : (in1 ? t.n1 : t.n2);
+    const int cs = in0 ? c : (in1 ? c - t.n0 : c - t.n0 - t.n1);      // chunk within its segment
+    const int k = cs * 16 + kq * 4;
+    const bool ok = k < sK;
+    const int kc = ok ? k : 0;
+    f.xp = xp != 0; f.wp = wp != 0;
+    if (wp) {       // 1 KiB contiguous tile, already in MFMA operand order
+        f.w = *reinterpret_cast<const float4*>(sw + (((long)t.cb * nc + cs) * 64 + lane) * 4);
+    } else {
+        const float4 wv = *reinterpret_cast<const float4*>(sw + (long)wrow * ldw + kc);
+        f.w = ok ? wv : z;
+    }
+    if (xp) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+            f.x[m] = *reinterpret_cast<const float4*>(sx + (((long)min(t.mt0 + m, t.mt_last) * nc + cs) * 64 + lane) * 4);
+    } else {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const float4 xv = *reinterpret_cast<const float4*>(sx + (long)rows[m] * ldx + kc);
+            f.x[m] = ok ? xv : z;
+        }
+    }
+}
+
+__device__ __forceinline__ float4 to_mfma_layout(const float4 v, int src_lane) {
+    return make_float4(__shfl(v.x, src_lane, 64), __shfl(v.y, src_lane, 64), __shfl(v.z, src_lane, 64), __shfl(v.w, src_lane, 64));
+}
+
+template <int MT>
+__device__ __forceinline__ void sk_mma(const Frag<MT>& f, f32x4 (&acc)[MT], int src_lane) {
+    const float4 w4 = f.wp ? f.w : to_mfma_layout(f.w, src_lane);
+    const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const float4 x4 = f.xp ? f.x[m] : to_mfma_layout(f.x[m], src_lane);
+        const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[s], wv[s], acc[m], 0, 0, 0);
+    }
+}
+
+// ---- epilogue operands, fetched ahead of the main loop ------------------------------------------------------
+struct FwdPre {            // LSTM cell forward, one (row, unit) per thread
+    float pre[4], bi[4], bh[4], cp, hp;
+    int hm, cm, len;
+    bool valid;
+};
+struct BwdPre {            // LSTM cell backward, one (row, unit)
+    float dh_extra, dc, g[4], cp;
+    int hm, cm, len;
+    bool valid;
+};
+constexpr int MAX_PART = 8;
+
+__device__ __forceinline__ void fwd_prefetch(const SkinnyArgs& p, int row, int u, bool valid, FwdPre& f) {
+    f.valid = valid;
+    const int r = valid ? row : 0, uu = valid ? u : 0;
+    const long hi = (long)r * p.H + uu;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int gc = g * p.H + uu;
+        f.pre[g] = p.pre ? p.pre[(long)r * p.ldpre + gc] : 0.f;
+        f.bi[g] = p.b_ih ? p.b_ih[gc] : 0.f;
+        f.bh[g] = p.b_hh ? p.b_hh[gc] : 0.f;
+    }
+    f.cp = p.c_prev[hi];
+    f.hp = p.h_prev ? p.h_prev[hi] : 0.f;
+    f.hm = p.hmask ? (int)p.hmask[hi] : 1;
+    f.cm = p.cmask ? (int)p.cmask[hi] : 1;
+    f.len = p.lengths ? p.lengths[r] : 0x7fffffff;
+}
+
+__device__ __forceinline__ void bwd_prefetch(const SkinnyArgs& p, int row, int u, bool valid, BwdPre& f) {
+    f.valid = valid;
+    const int r = valid ? row : 0, uu = valid ? u : 0;
+    const long hi = (long)r * p.H + uu;
+    float e = p.dh_a ? p.dh_a[(long)r * p.ld_dh_a + uu] : 0.f;
+    if (p.dh_b) e += p.dh_b[hi];
+    float parts[MAX_PART];
+#pragma unroll
+    for (int k = 0; k < MAX_PART; ++k)
+        parts[k] = (k < p.n_part) ? p.part[(long)k * p.part_ks + (long)r * p.part_ld + p.part_col0 + uu] : 0.f;
+#pragma unroll
+    for (int k = 0; k < MAX_PART; ++k) e += parts[k];
+    f.dh_extra = e;
+    f.dc = p.dc_in[hi];
+    const float* gp = p.gates + (long)r * 4 * p.H + uu;
+    f.g[0] = gp[0]; f.g[1] = gp[p.H]; f.g[2] = gp[2 * p.H]; f.g[3] = gp[3 * p.H];
+    f.cp = p.c_prev[hi];
+    f.hm = p.hmask ? (int)p.hmask[hi] : 1;
+    f.cm = p.cmask ? (int)p.cmask[hi] : 1;
+    f.len = p.lengths ? p.lengths[r] : 0x7fffffff;
+}
+
+template <int MT>
+__device__ __forceinline__ float red_sum(const float (&red)[NW][MT * 16][17], int rr, int cc) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v += red[w][rr][cc];
+    return v;
+}
+
+template <int MT>
+__device__ __forceinline__ void fwd_cell(const SkinnyArgs& p, const float (&red)[NW][MT * 16][17], int rr, int uu, int row,
+                                         int u, const FwdPre& f) {
+    if (!f.valid) return;
+    float g4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) g4[g] = red_sum<MT>(red, rr, g * 4 + uu) + f.pre[g] + f.bi[g] + f.bh[g];
+    const long hi = (long)row * p.H + u;
+    const float cp = f.cp;
+    const float ig = sigmoidf_(g4[0]), fg = sigmoidf_(g4[1]), gg = tanhf_(g4[2]), og = sigmoidf_(g4[3]);
+    const float cn = fg * cp + ig * gg;
+    const float hn = og * tanhf_(cn);
+    const bool carried = p.t >= f.len;
+    if (p.gates_out) {
+        float* go = p.gates_out + (long)row * 4 * p.H + u;
+        go[0] = carried ? 0.f : ig; go[p.H] = carried ? 0.f : fg; go[2 * p.H] = carried ? 0.f : gg; go[3 * p.H] = carried ? 0.f : og;
+    }
+    float ho, co = cn;
+    if (carried) { ho = f.hp; co = cp; }
+    else if (p.zone == 1) { ho = f.hm ? hn : f.hp; co = f.cm ? cn : cp; }          // keep flag set -> take the new value
+    else if (p.zone == 2) { ho = p.zh * f.hp + (1.f - p.zh) * hn; co = p.zc * cp + (1.f - p.zc) * cn; }
+    else ho = p.hmask ? (f.hm ? hn * p.hscale : 0.f) : hn;
+    p.h_out[hi] = ho;
+    p.c_out[hi] = co;
+    if (p.h_pack_out)      // MFMA tile order copy for the next step's X operand: lane 16*q + i, column 4*q + s of chunk u / 16
+        p.h_pack_out[((((long)(row >> 4) * (p.H >> 4) + (u >> 4)) * 64) + 4 * (u & 12) + (row & 15)) * 4 + (u & 3)] = ho;
+    if (p.y_out) p.y_out[(long)row * p.ldy + u] = carried ? 0.f : ho;
+}
+
+template <int MT>
+__device__ __forceinline__ void bwd_cell(const SkinnyArgs& p, const float (&red)[NW][MT * 16][17], int rr, int cc, int row,
+                                         int u, const BwdPre& f) {
+    if (!f.valid) return;
+    const long hi = (long)row * p.H + u;
+    const float dh = red_sum<MT>(red, rr, cc) + f.dh_extra;
+    const float dc = f.dc;
+    const float ig = f.g[0], fg = f.g[1], gg = f.g[2], og = f.g[3];
+    const float cp = f.cp;
+    const bool carried = p.t >= f.len;
+    float dh_carry = 0.f, dc_carry = 0.f, dhn = dh, dcn = dc;
+    if (carried) { dh_carry = dh; dc_carry = dc; dhn = 0.f; dcn = 0.f; }
+    else if (p.zone == 1) {
+        if (!f.hm) { dh_carry = dh; dhn = 0.f; }
+        if (!f.cm) { dc_carry = dc; dcn = 0.f; }
+    } else if (p.hmask) {
+        dhn = f.hm ? dh * p.hscale : 0.f;
+    }
+    const float cn = fg * cp + ig * gg;
+    const float th = tanhf_(cn);
+    const float d_o = dhn * th;
+    const float dct = dcn + dhn * og * (1.f - th * th);
+    float* dg = p.dgates_out + (long)row * p.ld_dgates + u;
+    const float dgv[4] = {dct * gg * ig * (1.f - ig), dct * cp * fg * (1.f - fg), dct * ig * (1.f - gg * gg), d_o * og * (1.f - og)};
+    dg[0] = dgv[0]; dg[p.H] = dgv[1]; dg[2 * p.H] = dgv[2]; dg[3 * p.H] = dgv[3];
+    if (p.dg_pack_out) {
+        const long tile = (long)(row >> 4) * (p.H >> 2);           // 4H / 16 chunks per row tile
+        const int lane_s = (4 * (u & 12) + (row & 15)) * 4 + (u & 3);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            p.dg_pack_out[(tile + ((g * p.H + u) >> 4)) * 256 + lane_s] = dgv[g];
+    }
+    p.dc_out[hi] = dct * fg + dc_carry;
+    if (p.dh_carry_out) p.dh_carry_out[hi] = dh_carry;
+}
+
+// Body of the skinny kernel for workgroup (column block cb, row tile, K split ks); `red` is the workgroup's LDS reduction buffer.
+template <int MT, int DEPTH = 4>
+__device__ __forceinline__ void skinny_body(const SkinnyArgs& p, float (&red)[NW][MT * 16][17], const int cb, const int row_tile,
+                                            const int ks) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    const int row0 = row_tile * (MT * 16);
+
+    // ---- epilogue operands first (independent of the GEMM): one memory round trip, overlapped with the main loop
+    FwdPre fp; BwdPre bp0, bp1;
+    fp.valid = false; bp0.valid = false; bp1.valid = false;
+    if (p.lstm == 1) {
+        const int rr = tid >> 2, uu = tid & 3;
+        const int row = row0 + rr, u = cb * 4 + uu;
+        fwd_prefetch(p, row, u, tid < MT * 64 && row < p.B && u < p.H, fp);
+    } else if (p.lstm == 2) {
+        {
+            const int rr = tid >> 4, cc = tid & 15;
+            const int row = row0 + rr, u = cb * 16 + cc;
+            bwd_prefetch(p, row, u, tid < MT * 256 && row < p.B && u < p.H, bp0);
+        }
+        if (MT * 256 > NT) {
+            const int e = tid + NT;
+            const int rr = e >> 4, cc = e & 15;
+            const int row = row0 + rr, u = cb * 16 + cc;
+            bwd_prefetch(p, row, u, e < MT * 256 && row < p.B && u < p.H, bp1);
+        }
+    }
+
+    // load geometry (quad-coalesced): this lane fetches tile row r4, k-quad kq4; dest lane l takes its MFMA operand
+    // from source lane 4*(l & 15) + (l >> 4).  Out-of-range rows/columns are clamped (their results are never stored).
+    const int r4 = lane >> 2, kq4 = lane & 3;
+    const int src_lane = 4 * (lane & 15) + (lane >> 4);
+    int wrow;
+    if (p.lstm == 1) { const int u = min(cb * 4 + (r4 & 3), p.H - 1); wrow = (r4 >> 2) * p.H + u; }
+    else wrow = min(cb * 16 + r4, p.N - 1);
+    int rows[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) rows[m] = min(row0 + m * 16 + r4, p.B - 1);
+
+    SegTab t;
+    t.x0 = p.seg[0].x; t.x1 = p.seg[1].x; t.x2 = p.seg[2].x;
+    t.w0 = p.seg[0].w; t.w1 = p.seg[1].w; t.w2 = p.seg[2].w;
+    t.K0 = p.seg[0].K; t.K1 = p.seg[1].K; t.K2 = p.seg[2].K;
+    t.ldx0 = p.seg[0].ldx; t.ldx1 = p.seg[1].ldx; t.ldx2 = p.seg[2].ldx;
+    t.ldw0 = p.seg[0].ldw; t.ldw1 = p.seg[1].ldw; t.ldw2 = p.seg[2].ldw;
+    t.xp0 = p.seg[0].xpack; t.xp1 = p.seg[1].xpack; t.xp2 = p.seg[2].xpack;
+    t.wp0 = p.seg[0].wpack; t.wp1 = p.seg[1].wpack; t.wp2 = p.seg[2].wpack;
+    t.cb = cb; t.mt0 = row_tile * MT; t.mt_last = ((p.B + 15) >> 4) - 1;
+    const int nseg = p.nseg;
+    t.n0 = (t.K0 + 15) >> 4;
+    t.n1 = nseg > 1 ? (t.K1 + 15) >> 4 : 0;
+    t.n2 = nseg > 2 ? (t.K2 + 15) >> 4 : 0;
+    t.total = t.n0 + t.n1 + t.n2;
+    const int total = t.total;
+
+    f32x4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // chunk c is served by wave (c % NW) of K-split ((c / NW) % ksplit); 4-deep software pipeline per wave
+    const int step = NW * p.ksplit;
+    int c = ks * NW + wave;
+    if (c < total) {
+        if (DEPTH == 4) {
+            Frag<MT> f0, f1, f2, f3;
+            sk_load<MT>(t, c, rows, wrow, kq4, lane, f0);
+            sk_load<MT>(t, c + step, rows, wrow, kq4, lane, f1);
+            sk_load<MT>(t, c + 2 * step, rows, wrow, kq4, lane, f2);
+            sk_load<MT>(t, c + 3 * step, rows, wrow, kq4, lane, f3);
+            for (; c < total; c += 4 * step) {
+                sk_mma<MT>(f0, acc, src_lane);
+                sk_load<MT>(t, c + 4 * step, rows, wrow, kq4, lane, f0);
+                sk_mma<MT>(f1, acc, src_lane);
+                sk_load<MT>(t, c + 5 * step, rows, wrow, kq4, lane, f1);
+                sk_mma<MT>(f2, acc, src_lane);
+                sk_load<MT>(t, c + 6 * step, rows, wrow, kq4, lane, f2);
+                sk_mma<MT>(f3, acc, src_lane);
+                sk_load<MT>(t, c + 7 * step, rows, wrow, kq4, lane, f3);
+            }
+        } else {      // 2-deep variant: fewer registers, used where the workgroup shares a CU with another one
+            Frag<MT> f0, f1;
+            sk_load<MT>(t, c, rows, wrow, kq4, lane, f0);
+            sk_load<MT>(t, c + step, rows, wrow, kq4, lane, f1);
+            for (; c < total; c += 2 * step) {
+                sk_mma<MT>(f0, acc, src_lane);
+                sk_load<MT>(t, c + 2 * step, rows, wrow, kq4, lane, f0);
+                sk_mma<MT>(f1, acc, src_lane);
+                sk_load<MT>(t, c + 3 * step, rows, wrow, kq4, lane, f1);
+            }
+        }
+    }
+
+    // C/D layout 16x16: col = lane&15, row = (lane>>4)*4 + r
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][m * 16 + lq * 4 + r][li] = acc[m][r];
+    __syncthreads();
+
+    if (p.lstm == 0) {
+        for (int e = tid; e < MT * 16 * 16; e += NT) {
+            const int rr = e >> 4, cc = e & 15;
+            const int row = row0 + rr, col = cb * 16 + cc;
+            if (row >= p.B || col >= p.N) continue;
+            float v = red_sum<MT>(red, rr, cc);
+            if (p.ksplit > 1) { p.out[(long)ks * p.out_ks + (long)row * p.ldo + col] = v; continue; }
+            if (p.bias) v += p.bias[col];
+            v = apply_act(p.act, v);
+            if (p.mask) v = p.mask[(long)row * p.ldmask + col] ? v * p.mask_scale : 0.f;
+            p.out[(long)row * p.ldo + col] = v;
+        }
+        return;
+    }
+    if (p.lstm == 2) {
+        {
+            const int rr = tid >> 4, cc = tid & 15;
+            bwd_cell<MT>(p, red, rr, cc, row0 + rr, cb * 16 + cc, bp0);
+        }
+        if (MT * 256 > NT) {
+            const int e = tid + NT;
+            const int rr = e >> 4, cc = e & 15;
+            bwd_cell<MT>(p, red, rr, cc, row0 + rr, cb * 16 + cc, bp1);
+        }
+        return;
+    }
+    {
+        const int rr = tid >> 2, uu = tid & 3;
+        fwd_cell<MT>(p, red, rr, uu, row0 + rr, cb * 4 + uu, fp);
+    }
+}
+
