@@ -1,4 +1,11 @@
-// fp32 MFMA GEMM for gfx950 (v_mfma_f32_32x32x2_f32: exact f32, 157 TF peak).
+// fp32 GEMM for gfx950, two interchangeable cores behind one argument block:
+//   * gemm_split_kernel (default): every fp32 operand element is split EXACTLY into three bf16 values
+//     x = h1 + h2 + h3 (+ < 2^-24 |x|) while its tile is written to LDS, and the product is evaluated on the bf16 matrix
+//     cores as a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1 with fp32 accumulation (v_mfma_f32_32x32x16_bf16).  The dropped
+//     terms are <= 2^-23 |ab|, i.e. below one fp32 rounding of the product; measured error against fp64 is at or below
+//     that of an fp32 fma chain (scripts/mb/mb_gemm_split.hip, tests/test_gpu_more.py).  Six bf16 MFMAs cost 6/16 of
+//     the matrix-pipe cycles of the fp32 MFMA they replace: 150-185 TFLOP/s-equivalent sustained vs 101-112.
+//   * gemm_mfma_kernel (MTTS_GEMM_EXACT_F32=1): v_mfma_f32_32x32x2_f32, exact f32 products, 157 TF peak.
 //
 //   C[M,N] = epilogue( alpha * sum_k A(m,k) * B(n,k) )
 //
@@ -18,6 +25,7 @@
 // The k-slot trick: instruction s of group g uses slot q (=lane>>5) as k = 8g + 4q + s for BOTH
 // operands, so a lane's float4 along k supplies four consecutive instructions.
 #include "common.h"
+#include <stdlib.h>
 
 
 constexpr int BM = 128, BN = 128, BK = 32;
@@ -30,7 +38,7 @@ struct Tile {                      // registers holding one thread's share of a 
 };
 
 // Load one float4 of operand X (rows = BM-tile rows, kk along K).  Generic + slow-path safe.
-template <bool TRANS, bool IS_A>
+template <bool TRANS, bool IS_A, bool SPLIT = false>
 __device__ __forceinline__ void load_tile(const GemmArgs& p, const float* __restrict__ base, int row0, int k0,
                                           int rows_total, int ld, bool vec_ok, int shift_z, Tile<TRANS>& t) {
     const int tid = threadIdx.x;
@@ -72,8 +80,10 @@ __device__ __forceinline__ void load_tile(const GemmArgs& p, const float* __rest
             }
         } else {
             // transposed source: element (row, kk) at base[kk*ld + row] (+ tap offset); float4 along rows
-            const int kk = k0 + it * 8 + (tid >> 5);
-            const int r = row0 + (tid & 31) * 4;
+            // exact-f32 core: k = it*8 + tid/32, rows 4*(tid%32)..+3;  split core: k = 4*(tid%8) + it, rows 4*(tid/8)..+3
+            // (four consecutive k per thread, so that one row's 4 k-values form an 8-byte bf16 store)
+            const int kk = k0 + (SPLIT ? (tid & 7) * 4 + it : it * 8 + (tid >> 5));
+            const int r = row0 + (SPLIT ? (tid >> 3) * 4 : (tid & 31) * 4);
             if (kk < p.K && r < rows_total) {
                 long koff; bool valid = true;
                 if (!IS_A && p.shift_mode == 2) {          // wgrad: k index is an activation row, shifted
@@ -149,6 +159,177 @@ __global__ void gemm_splitk_reduce(GemmArgs p, const float* __restrict__ ws, int
         if (p.mask) v = p.mask[row * p.ldmask + col] ? v * p.mask_scale : 0.f;
         *cp = v;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// split-bf16 core.  LDS image per operand: 3 planes x [128 rows][32 k] bf16 (64 B rows, no padding); the 16-byte
+// chunk c of row r sits at chunk c ^ ((r >> 2) & 3): conflict-free for ds_read_b128 (lane groups of the 32x32x16
+// fragment read) and at most 2-way for the 8-byte stores of both the k-contiguous and the transposed fill.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+constexpr int SP_ROW_B = BK * 2;
+constexpr int SP_PLANE_B = BM * SP_ROW_B;        // 8 KiB
+constexpr int SP_LDS_B = 6 * SP_PLANE_B;         // A planes 0..2, B planes 3..5: 48 KiB
+
+__device__ __forceinline__ void split_pair(float x, float y, unsigned& p1, unsigned& p2, unsigned& p3) {
+    const unsigned ux = __float_as_uint(x), uy = __float_as_uint(y);
+    const float rx = x - __uint_as_float(ux & 0xffff0000u), ry = y - __uint_as_float(uy & 0xffff0000u);   // exact
+    const unsigned vx = __float_as_uint(rx), vy = __float_as_uint(ry);
+    const float sx = rx - __uint_as_float(vx & 0xffff0000u), sy = ry - __uint_as_float(vy & 0xffff0000u);   // exact
+    p1 = __builtin_amdgcn_perm(uy, ux, 0x07060302u);       // {hi16(x), hi16(y)}: truncation to bf16
+    p2 = __builtin_amdgcn_perm(vy, vx, 0x07060302u);
+    p3 = __builtin_amdgcn_perm(__float_as_uint(sy), __float_as_uint(sx), 0x07060302u);
+}
+
+__device__ __forceinline__ void store_split4(char* lds, int row, int k4, float4 v) {
+    unsigned a1, a2, a3, b1, b2, b3;
+    split_pair(v.x, v.y, a1, a2, a3);
+    split_pair(v.z, v.w, b1, b2, b3);
+    char* p = lds + row * SP_ROW_B + (((k4 >> 1) ^ ((row >> 2) & 3)) * 16) + (k4 & 1) * 8;
+    *reinterpret_cast<uint2*>(p) = make_uint2(a1, b1);
+    *reinterpret_cast<uint2*>(p + SP_PLANE_B) = make_uint2(a2, b2);
+    *reinterpret_cast<uint2*>(p + 2 * SP_PLANE_B) = make_uint2(a3, b3);
+}
+
+template <bool TRANS>
+__device__ __forceinline__ void store_tile_split(char* lds, const Tile<TRANS>& t) {
+    const int tid = threadIdx.x;
+    if (!TRANS) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) store_split4(lds, it * 32 + (tid >> 3), tid & 7, t.v[it]);
+    } else {      // thread holds k = 4*(tid%8) + it (it = 0..3) of rows 4*(tid/8) + {x,y,z,w}
+        store_split4(lds, (tid >> 3) * 4 + 0, tid & 7, make_float4(t.v[0].x, t.v[1].x, t.v[2].x, t.v[3].x));
+        store_split4(lds, (tid >> 3) * 4 + 1, tid & 7, make_float4(t.v[0].y, t.v[1].y, t.v[2].y, t.v[3].y));
+        store_split4(lds, (tid >> 3) * 4 + 2, tid & 7, make_float4(t.v[0].z, t.v[1].z, t.v[2].z, t.v[3].z));
+        store_split4(lds, (tid >> 3) * 4 + 3, tid & 7, make_float4(t.v[0].w, t.v[1].w, t.v[2].w, t.v[3].w));
+    }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p, float* g_ws) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* sa = reinterpret_cast<char*>(smem);
+    char* sb = sa + 3 * SP_PLANE_B;
+
+    const int ntx = (p.N + BN - 1) / BN, nty = (p.M + BM - 1) / BM;
+    const int nt = ntx * nty;
+    int id = blockIdx.x;
+    {   // XCD-aware tile order (see gemm_mfma_kernel)
+        const int q = nt / 8, r = nt % 8, xcd = id % 8, idx = id / 8;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = id / ntx, tile_n = id % ntx;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int z = blockIdx.z;
+    const int zb = z / p.zt, ztap = z % p.zt;
+    const float* A = p.A + (long)zb * p.a_z;
+    const float* B = p.B + (long)zb * p.b_z;
+    float* C = p.C + (long)zb * p.c_z + (long)ztap * p.c_ztap;
+    const float* bias = p.bias ? p.bias + (long)zb * p.bias_z : nullptr;
+    const int shift_z = p.shift0 + ztap * p.dshift;
+
+    const bool vecA = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && (p.shift_mode == 0 || (p.Kc & 3) == 0) &&
+                      ((p.a_z & 3) == 0);
+    const bool vecB = ((p.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && (p.shift_mode == 0 || (p.Kc & 3) == 0) &&
+                      ((p.b_z & 3) == 0) && ((p.b_tap & 3) == 0);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int li = lane & 31, lq = lane >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    Tile<TA> ta; Tile<TB> tb;
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int per_split = (nk_all + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int kb0 = blockIdx.y * per_split;
+    const int nk = min(nk_all, kb0 + per_split);
+    load_tile<TA, true, true>(p, A, m0, kb0 * BK, p.M, p.lda, vecA, shift_z, ta);
+    load_tile<TB, false, true>(p, B, n0, kb0 * BK, p.N, p.ldb, vecB, shift_z, tb);
+    store_tile_split<TA>(sa, ta);
+    store_tile_split<TB>(sb, tb);
+    __syncthreads();
+
+    // fragment addresses: lane reads row (l & 31), k-chunk 2*ks + (l >> 5) of each plane
+    int offa[2], offb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ra = wm + i * 32 + li, rb = wn + i * 32 + li;
+        offa[i] = ra * SP_ROW_B + ((lq ^ ((ra >> 2) & 3)) * 16);
+        offb[i] = rb * SP_ROW_B + ((lq ^ ((rb >> 2) & 3)) * 16);
+    }
+
+    for (int kb = kb0; kb < nk; ++kb) {
+        if (kb + 1 < nk) {
+            load_tile<TA, true, true>(p, A, m0, (kb + 1) * BK, p.M, p.lda, vecA, shift_z, ta);
+            load_tile<TB, false, true>(p, B, n0, (kb + 1) * BK, p.N, p.ldb, vecB, shift_z, tb);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[2][3], b[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {      // chunk (2*ks + lq) ^ s == (lq ^ s) ^ 2*ks
+                    a[i][pl] = *reinterpret_cast<const bf16x8*>(sa + pl * SP_PLANE_B + (offa[i] ^ (ks * 32)));
+                    b[i][pl] = *reinterpret_cast<const bf16x8*>(sb + pl * SP_PLANE_B + (offb[i] ^ (ks * 32)));
+                }
+#define MTTS_MM(PA, PB)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] =      \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA], b[j][PB], acc[i][j], 0, 0, 0);
+            MTTS_MM(2, 0) MTTS_MM(0, 2) MTTS_MM(1, 1) MTTS_MM(1, 0) MTTS_MM(0, 1) MTTS_MM(0, 0)
+#undef MTTS_MM
+        }
+        __syncthreads();
+        if (kb + 1 < nk) {
+            store_tile_split<TA>(sa, ta);
+            store_tile_split<TB>(sb, tb);
+        }
+        __syncthreads();
+    }
+
+    // C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (gridDim.y > 1) {
+        float* W = g_ws + ((long)z * gridDim.y + blockIdx.y) * (long)p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wn + j * 32 + li;
+                if (col >= p.N) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lq;
+                    if (row < p.M) W[(long)row * p.N + col] = acc[i][j][r];
+                }
+            }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn + j * 32 + li;
+            if (col >= p.N) continue;
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lq;
+                if (row >= p.M) continue;
+                float v = p.alpha * acc[i][j][r] + bv;
+                float* cp = C + (long)row * p.ldc + col;
+                if (p.beta != 0.f) v += p.beta * (*cp);
+                v = apply_act(p.act, v);
+                if (p.mask) v = p.mask[(long)row * p.ldmask + col] ? v * p.mask_scale : 0.f;
+                *cp = v;
+            }
+        }
 }
 
 template <bool TA, bool TB>
@@ -312,7 +493,8 @@ MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
     dim3 grid(ntx * nty, S, p.batch * p.zt);
     // side-stream launches (nosplit) ask for > half of the CU's LDS so that only ONE GEMM workgroup sits on a CU and the
     // latency-critical step kernels of the main stream always find room next to it
-    const size_t lds_base = 4 * LDS_A * sizeof(float);
+    static const bool exact_f32 = [] { const char* e = getenv("MTTS_GEMM_EXACT_F32"); return e && e[0] == '1'; }();
+    const size_t lds_base = exact_f32 ? 4 * LDS_A * sizeof(float) : (size_t)SP_LDS_B;
     const size_t lds = p.nosplit ? (size_t)96 * 1024 : lds_base;
     hipStream_t s = (hipStream_t)stream;
     static bool attr_done = false;
@@ -321,13 +503,24 @@ MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
         hipFuncSetAttribute((const void*)gemm_mfma_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         hipFuncSetAttribute((const void*)gemm_mfma_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         hipFuncSetAttribute((const void*)gemm_mfma_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute((const void*)gemm_split_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute((const void*)gemm_split_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute((const void*)gemm_split_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute((const void*)gemm_split_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr_done = true;
     }
     float* ws = g_ws_host;
-    if (!p.transA && !p.transB) hipLaunchKernelGGL((gemm_mfma_kernel<false, false>), grid, dim3(256), lds, s, p, ws);
-    else if (!p.transA && p.transB) hipLaunchKernelGGL((gemm_mfma_kernel<false, true>), grid, dim3(256), lds, s, p, ws);
-    else if (p.transA && !p.transB) hipLaunchKernelGGL((gemm_mfma_kernel<true, false>), grid, dim3(256), lds, s, p, ws);
-    else hipLaunchKernelGGL((gemm_mfma_kernel<true, true>), grid, dim3(256), lds, s, p, ws);
+    if (exact_f32) {
+        if (!p.transA && !p.transB) hipLaunchKernelGGL((gemm_mfma_kernel<false, false>), grid, dim3(256), lds, s, p, ws);
+        else if (!p.transA && p.transB) hipLaunchKernelGGL((gemm_mfma_kernel<false, true>), grid, dim3(256), lds, s, p, ws);
+        else if (p.transA && !p.transB) hipLaunchKernelGGL((gemm_mfma_kernel<true, false>), grid, dim3(256), lds, s, p, ws);
+        else hipLaunchKernelGGL((gemm_mfma_kernel<true, true>), grid, dim3(256), lds, s, p, ws);
+    } else {
+        if (!p.transA && !p.transB) hipLaunchKernelGGL((gemm_split_kernel<false, false>), grid, dim3(256), lds, s, p, ws);
+        else if (!p.transA && p.transB) hipLaunchKernelGGL((gemm_split_kernel<false, true>), grid, dim3(256), lds, s, p, ws);
+        else if (p.transA && !p.transB) hipLaunchKernelGGL((gemm_split_kernel<true, false>), grid, dim3(256), lds, s, p, ws);
+        else hipLaunchKernelGGL((gemm_split_kernel<true, true>), grid, dim3(256), lds, s, p, ws);
+    }
     MTTS_CHECK_LAUNCH("gemm_mfma_kernel");
     if (S > 1) {
         const long MN = (long)p.M * p.N;
