@@ -48,6 +48,17 @@ hipStream_t side_stream() {
     return g_side;
 }
 
+// second helper stream (least priority): weight-gradient GEMMs of finished chunks, off both decoder chains
+static hipStream_t g_wgrad = nullptr;
+hipStream_t wgrad_stream() {
+    if (!g_wgrad) {
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&g_wgrad, hipStreamNonBlocking, lo) != hipSuccess) g_wgrad = nullptr;
+    }
+    return g_wgrad;
+}
+
 hipEvent_t pool_event() {
     if (g_event_count < 256) {
         hipEventCreateWithFlags(&g_events[g_event_count], hipEventDisableTiming);

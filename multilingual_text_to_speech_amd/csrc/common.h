@@ -83,6 +83,7 @@ int colsum(const float* x, float* out, int rows, int cols, int ld, float* ws, hi
 int relu_mask_bwd(const float* dy, const float* y, float* dz, long n, float scale, hipStream_t s);
 bool prof_sample(int t, hipStream_t s, int phase);
 hipStream_t side_stream();
+hipStream_t wgrad_stream();
 hipEvent_t pool_event();
 
 // ---- DPP (no LDS traffic) reductions inside 16-lane rows, then across rows -----------------------------------

@@ -25,7 +25,8 @@ static void bwd_reg(const DecoderArgs& a, SkinnyArgs& k, const uint8_t* hmask, c
 
 // Batched part after the sequential sweeps: prenet, every weight gradient, memory gradient, attention parameters.
 // `prenet_chain_done`: the general schedule already pushed the gradient through the prenet step by step (dpren holds dz).
-static int bwd_post(const DecoderArgs& a, const DecoderGradArgs& g, bool prenet_chain_done, bool gen_wgrad_done, hipStream_t s) {
+static int bwd_post(const DecoderArgs& a, const DecoderGradArgs& g, bool prenet_chain_done, bool gen_wgrad_done, bool att_wgrad_done,
+                    hipStream_t s) {
     const int B = a.B, L = a.L, T = a.T, M = a.M, P = a.P, H = a.H, A = a.A, Dm = a.Dm;
     const int Mo = round4(M + 1), TB = T * B;
     const long BH = (long)B * H, BD = (long)B * Dm, BP = (long)B * P;
@@ -47,9 +48,11 @@ static int bwd_post(const DecoderArgs& a, const DecoderGradArgs& g, bool prenet_
     const float* pren = a.prenet_act[n - 1];
 
     // ---- LSTM weight gradients
-    MTTS_TRY(gm(g.dG_att, pren, g.d_att_w_ih, 4 * H, P, TB, 4 * H, P, P + Dm, true, true, 0.f, s));
-    MTTS_TRY(gm(g.dG_att, a.ctx, g.d_att_w_ih + P, 4 * H, Dm, TB, 4 * H, Dm, P + Dm, true, true, 0.f, s));
-    MTTS_TRY(gm(g.dG_att, a.h_att, g.d_att_w_hh, 4 * H, H, TB, 4 * H, H, H, true, true, 0.f, s));
+    if (!att_wgrad_done) {
+        MTTS_TRY(gm(g.dG_att, pren, g.d_att_w_ih, 4 * H, P, TB, 4 * H, P, P + Dm, true, true, 0.f, s));
+        MTTS_TRY(gm(g.dG_att, a.ctx, g.d_att_w_ih + P, 4 * H, Dm, TB, 4 * H, Dm, P + Dm, true, true, 0.f, s));
+        MTTS_TRY(gm(g.dG_att, a.h_att, g.d_att_w_hh, 4 * H, H, TB, 4 * H, H, H, true, true, 0.f, s));
+    }
     MTTS_TRY(colsum(g.dG_att, g.d_att_b_ih, TB, 4 * H, 4 * H, g.colsum_ws, s));
     MTTS_TRY(colsum(g.dG_att, g.d_att_b_hh, TB, 4 * H, 4 * H, g.colsum_ws, s));
     if (!gen_wgrad_done) {
@@ -61,10 +64,12 @@ static int bwd_post(const DecoderArgs& a, const DecoderGradArgs& g, bool prenet_
     MTTS_TRY(colsum(g.dG_gen, g.d_gen_b_hh, TB, 4 * H, 4 * H, g.colsum_ws, s));
 
     // ---- frame/stop projection and query weights
-    MTTS_TRY(gm(dout1, a.h_gen + BH, g.d_w_out, M + 1, H, TB, Mo, H, H + Dm, true, true, 0.f, s));
-    MTTS_TRY(gm(dout1, a.ctx + BD, g.d_w_out + H, M + 1, Dm, TB, Mo, Dm, H + Dm, true, true, 0.f, s));
+    if (!att_wgrad_done) {
+        MTTS_TRY(gm(dout1, a.h_gen + BH, g.d_w_out, M + 1, H, TB, Mo, H, H + Dm, true, true, 0.f, s));
+        MTTS_TRY(gm(dout1, a.ctx + BD, g.d_w_out + H, M + 1, Dm, TB, Mo, Dm, H + Dm, true, true, 0.f, s));
+        MTTS_TRY(gm(g.dq_all, a.h_att + BH, g.d_w_query, A, H, TB, A, H, H, true, true, 0.f, s));
+    }
     MTTS_TRY(colsum(dout1, g.d_b_out, TB, M + 1, Mo, g.colsum_ws, s));
-    MTTS_TRY(gm(g.dq_all, a.h_att + BH, g.d_w_query, A, H, TB, A, H, H, true, true, 0.f, s));
 
     // ---- memory gradient: context path (per-sample align^T dctx), memory-transform path, and W_memory
     {
@@ -199,7 +204,7 @@ static int bwd_general(const DecoderArgs& a, const DecoderGradArgs& g, hipStream
         }
         if (!teach && t > 0) MTTS_TRY(add3(dout + (long)t * B * Mo, Mo, dframe, M, nullptr, 0, nullptr, 0, B, M, true, s));
     }
-    return bwd_post(a, g, true, false, s);
+    return bwd_post(a, g, true, false, false, s);
 }
 
 MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* grad, void* stream) {
@@ -241,6 +246,25 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
     }
     const int nchunks = (T + CH - 1) / CH;
     std::vector<hipEvent_t> chunk_ev(nchunks);
+    // ---- weight gradients ride a third, least-priority stream: every chunk's dG^T x product is queued as soon as its chain
+    //      has produced the chunk's dG, and accumulates (beta = 1) into the gradient; one workgroup per CU (nosplit) so that
+    //      the step kernels of both chains always find room.  The frame-projection gradient needs no chain at all.
+    hipStream_t sw = wgrad_stream();
+    if (!sw) return mtts_fail("decoder backward: cannot create the weight-gradient stream");
+    auto wgrad = [&](const float* dY, int ldy, int Mw, const float* X, int ldx, int Nw, float* dW, int ldw, int rows, float beta) -> int {
+        GemmArgs q; memset(&q, 0, sizeof(q));
+        q.taps = 1; q.batch = 1; q.zt = 1; q.alpha = 1.f; q.mask_scale = 1.f; q.nosplit = 1; q.transA = 1; q.transB = 1;
+        q.A = dY; q.lda = ldy; q.M = Mw; q.B = X; q.ldb = ldx; q.N = Nw; q.C = dW; q.ldc = ldw; q.K = rows; q.Kc = rows; q.beta = beta;
+        return mtts_gemm_ex(&q, sw);
+    };
+    {
+        hipEvent_t ev = pool_event();
+        MTTS_CHECK_HIP(hipEventRecord(ev, s));
+        MTTS_CHECK_HIP(hipStreamWaitEvent(sw, ev, 0));
+        MTTS_TRY(wgrad(dout1, Mo, M + 1, a.h_gen + BH, H, H, g.d_w_out, H + Dm, TB, 0.f));
+        MTTS_TRY(wgrad(dout1, Mo, M + 1, a.ctx + BD, Dm, Dm, g.d_w_out + H, H + Dm, TB, 0.f));
+    }
+    const float* pren = a.prenet_act[a.n_prenet - 1];
     auto submit_B = [&](int c) -> int {
         const int c0 = c * CH, c1 = std::min(T, c0 + CH), n = c1 - c0;
         for (int t = c1 - 1; t >= c0; --t) {
@@ -275,6 +299,12 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
         MTTS_TRY(mtts_gemm_ex(&q, sb));
         chunk_ev[c] = pool_event();
         MTTS_CHECK_HIP(hipEventRecord(chunk_ev[c], sb));
+        // generator-LSTM weight gradients of this chunk
+        MTTS_CHECK_HIP(hipStreamWaitEvent(sw, chunk_ev[c], 0));
+        const float beta = c == nchunks - 1 ? 0.f : 1.f;
+        MTTS_TRY(wgrad(g.dG_gen + c0 * B4H, 4 * H, 4 * H, a.h_att + (c0 + 1) * BH, H, H, g.d_gen_w_ih, H + Dm, n * B, beta));
+        MTTS_TRY(wgrad(g.dG_gen + c0 * B4H, 4 * H, 4 * H, a.ctx + (c0 + 1) * BD, Dm, Dm, g.d_gen_w_ih + H, H + Dm, n * B, beta));
+        MTTS_TRY(wgrad(g.dG_gen + c0 * B4H, 4 * H, 4 * H, a.h_gen + c0 * BH, H, H, g.d_gen_w_hh, H, n * B, beta));
         return 0;
     };
     // Chain A per step t:  { attention backward(t)  ||  dG_att(t+1) W_hh^T }  ->  dq W_q + cell backward(t)  ->  dG_att(t) W_ih[:, P:]^T
@@ -336,6 +366,18 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
                 MTTS_TRY(skinny_launch(q, s));
             }
         }
+        {   // attention-LSTM and query weight gradients of this chunk
+            hipEvent_t ev = pool_event();
+            MTTS_CHECK_HIP(hipEventRecord(ev, s));
+            MTTS_CHECK_HIP(hipStreamWaitEvent(sw, ev, 0));
+            const int n = c1 - c0;
+            const float beta = c == nchunks - 1 ? 0.f : 1.f;
+            const float* dG = g.dG_att + c0 * B4H;
+            MTTS_TRY(wgrad(dG, 4 * H, 4 * H, pren + c0 * BP, P, P, g.d_att_w_ih, P + Dm, n * B, beta));
+            MTTS_TRY(wgrad(dG, 4 * H, 4 * H, a.ctx + c0 * BD, Dm, Dm, g.d_att_w_ih + P, P + Dm, n * B, beta));
+            MTTS_TRY(wgrad(dG, 4 * H, 4 * H, a.h_att + c0 * BH, H, H, g.d_att_w_hh, H, n * B, beta));
+            MTTS_TRY(wgrad(g.dq_all + c0 * BA, A, A, a.h_att + (c0 + 1) * BH, H, H, g.d_w_query, H, n * B, beta));
+        }
         return 0;
     };
     // host submission order keeps chain B one chunk ahead of chain A so that neither stream starves
@@ -344,21 +386,13 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
         if (c > 0) MTTS_TRY(submit_B(c - 1));
         MTTS_TRY(submit_A(c));
     }
-    // generator-side weight gradients also go to the side stream (they only need dG_gen); no split-K there (shared scratch)
-    {
-        GemmArgs q; memset(&q, 0, sizeof(q));
-        q.taps = 1; q.batch = 1; q.zt = 1; q.alpha = 1.f; q.mask_scale = 1.f; q.nosplit = 1; q.transA = 1; q.transB = 1;
-        q.A = g.dG_gen; q.M = 4 * H; q.K = TB; q.Kc = TB; q.lda = 4 * H;
-        q.B = a.h_att + BH; q.C = g.d_gen_w_ih; q.N = H; q.ldb = H; q.ldc = H + Dm; MTTS_TRY(mtts_gemm_ex(&q, sb));
-        q.B = a.ctx + BD; q.C = g.d_gen_w_ih + H; q.N = Dm; q.ldb = Dm; MTTS_TRY(mtts_gemm_ex(&q, sb));
-        q.B = a.h_gen; q.C = g.d_gen_w_hh; q.N = H; q.ldb = H; q.ldc = H; MTTS_TRY(mtts_gemm_ex(&q, sb));
-    }
-    hipEvent_t ev_b_done = pool_event();
+    hipEvent_t ev_b_done = pool_event(), ev_w_done = pool_event();
     MTTS_CHECK_HIP(hipEventRecord(ev_b_done, sb));
+    MTTS_CHECK_HIP(hipEventRecord(ev_w_done, sw));
+    MTTS_CHECK_HIP(hipStreamWaitEvent(s, ev_b_done, 0));
+    MTTS_CHECK_HIP(hipStreamWaitEvent(s, ev_w_done, 0));     // join before the split-K GEMMs of the batched part (shared scratch)
 
-    MTTS_CHECK_HIP(hipStreamWaitEvent(s, ev_b_done, 0));     // join before the split-K weight-gradient GEMMs
-
-    return bwd_post(a, g, false, true, s);
+    return bwd_post(a, g, false, true, true, s);
 }
 
 MTTS_API int mtts_bilstm_bwd(const BiLstmArgs* fwd, const BiLstmGradArgs* grad, void* stream) {
