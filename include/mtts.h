@@ -437,10 +437,10 @@ typedef struct BiLstmGradArgs {
     const float* dy;       /* [B,L,2H] */
     float* w_hh_T[2];      /* [H,4H] workspace */
     float* dxproj[2];      /* [L,B,4H] gate gradients */
-    float* part;           /* [ksb,B,H] */
+    float* part;           /* [2 directions][ksb,B,H] (the two directions run concurrently on two streams) */
     int ksb;
-    float* dc;             /* [2,B,H] zero-initialised */
-    float* dh_carry;       /* [2,B,H] zero-initialised */
+    float* dc;             /* [2 directions][2,B,H] */
+    float* dh_carry;       /* [2 directions][2,B,H] */
     float* colsum_ws;
     float* dx;             /* [L,B,Cin] time-major */
     float* d_w_ih[2];

@@ -124,7 +124,7 @@ def bilstm_bwd(ctx, dy):
     ksb = 4
     whT = [_e(H, 4 * H, device=dev) for _ in range(2)]
     dxp = [_e(L, B, 4 * H, device=dev) for _ in range(2)]
-    part, dc, dhc = _z(ksb, B, H, device=dev), _z(2, B, H, device=dev), _z(2, B, H, device=dev)
+    part, dc, dhc = _z(2, ksb, B, H, device=dev), _z(2, 2, B, H, device=dev), _z(2, 2, B, H, device=dev)
     cws = _e(int(lib().mtts_colsum_workspace_floats(4 * H)), device=dev)
     dx = _e(L, B, Cin, device=dev)
     dw = [[_e(*t.shape, device=dev) for t in ws[d]] for d in range(2)]

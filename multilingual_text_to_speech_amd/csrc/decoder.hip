@@ -253,8 +253,19 @@ MTTS_API int mtts_bilstm_fwd(const BiLstmArgs* args, void* stream) {
     const int B = a.B, L = a.L, H = a.H;
     MTTS_REQUIRE((H & 3) == 0 && (a.Cin & 3) == 0, "bilstm: H and Cin must be multiples of 4");
     const long BH = (long)B * H;
-    for (int d = 0; d < 2; ++d) {
-        MTTS_TRY(gemm_plain(a.x, a.w_ih[d], a.xproj[d], B * L, 4 * H, a.Cin, a.Cin, a.Cin, 4 * H, false, false, 1.f, 0.f, nullptr, 0, s));
+    // the two directions are independent (disjoint state, gate and output-column arrays): the reverse one runs on the side stream
+    hipStream_t sd[2] = {s, side_stream()};
+    if (!sd[1]) return mtts_fail("bilstm: cannot create the side stream");
+    hipEvent_t ev_fork = pool_event(), ev_join = pool_event();
+    MTTS_CHECK_HIP(hipEventRecord(ev_fork, s));
+    MTTS_CHECK_HIP(hipStreamWaitEvent(sd[1], ev_fork, 0));
+    for (int d = 1; d >= 0; --d) {
+        {   // input projection for all steps (K = Cin is short: never split-K, so no shared scratch between the streams)
+            GemmArgs q; memset(&q, 0, sizeof(q));
+            q.A = a.x; q.B = a.w_ih[d]; q.C = a.xproj[d]; q.M = B * L; q.N = 4 * H; q.K = a.Cin; q.Kc = a.Cin;
+            q.lda = a.Cin; q.ldb = a.Cin; q.ldc = 4 * H; q.taps = 1; q.batch = 1; q.zt = 1; q.alpha = 1.f; q.mask_scale = 1.f; q.nosplit = d;
+            MTTS_TRY(mtts_gemm_ex(&q, sd[d]));
+        }
         for (int st = 0; st < L; ++st) {
             const int t = d == 0 ? st : L - 1 - st;
             const int s_in = d == 0 ? t : t + 1, s_out = d == 0 ? t + 1 : t;
@@ -268,8 +279,10 @@ MTTS_API int mtts_bilstm_fwd(const BiLstmArgs* args, void* stream) {
             k.gates_out = a.gates[d] ? a.gates[d] + (long)t * 4 * BH : nullptr;
             k.lengths = a.lengths; k.t = t;
             k.y_out = a.y + (long)t * 2 * H + d * H; k.ldy = L * 2 * H;
-            MTTS_TRY(skinny_launch(k, s));
+            MTTS_TRY(skinny_launch(k, sd[d]));
         }
     }
+    MTTS_CHECK_HIP(hipEventRecord(ev_join, sd[1]));
+    MTTS_CHECK_HIP(hipStreamWaitEvent(s, ev_join, 0));
     return 0;
 }

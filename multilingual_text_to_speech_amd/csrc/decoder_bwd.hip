@@ -401,32 +401,47 @@ MTTS_API int mtts_bilstm_bwd(const BiLstmArgs* fwd, const BiLstmGradArgs* grad, 
     hipStream_t s = (hipStream_t)stream;
     const int B = a.B, L = a.L, H = a.H, Cin = a.Cin;
     const long BH = (long)B * H, B4H = 4 * BH;
-    for (int d = 0; d < 2; ++d) {
+    // both directions' recurrences run concurrently (reverse direction on the side stream, own scratch halves); the batched
+    // products that follow share dx and the split-K scratch and stay on the caller's stream
+    hipStream_t sd[2] = {s, side_stream()};
+    if (!sd[1]) return mtts_fail("bilstm backward: cannot create the side stream");
+    hipEvent_t ev_fork = pool_event(), ev_join = pool_event();
+    MTTS_CHECK_HIP(hipEventRecord(ev_fork, s));
+    MTTS_CHECK_HIP(hipStreamWaitEvent(sd[1], ev_fork, 0));
+    for (int d = 1; d >= 0; --d) {
         MTTS_REQUIRE(a.gates[d], "bilstm backward needs the saved gates");
-        MTTS_TRY(transpose2d(a.w_hh[d], g.w_hh_T[d], 4 * H, H, s));
-        MTTS_CHECK_HIP(hipMemsetAsync(g.dc, 0, 2 * BH * sizeof(float), s));
-        MTTS_CHECK_HIP(hipMemsetAsync(g.dh_carry, 0, 2 * BH * sizeof(float), s));
+        hipStream_t q_s = sd[d];
+        float* part = g.part + (long)d * g.ksb * BH;
+        float* dc = g.dc + (long)d * 2 * BH;
+        float* dh_carry = g.dh_carry + (long)d * 2 * BH;
+        MTTS_TRY(transpose2d(a.w_hh[d], g.w_hh_T[d], 4 * H, H, q_s));
+        MTTS_CHECK_HIP(hipMemsetAsync(dc, 0, 2 * BH * sizeof(float), q_s));
+        MTTS_CHECK_HIP(hipMemsetAsync(dh_carry, 0, 2 * BH * sizeof(float), q_s));
         for (int st = L - 1; st >= 0; --st) {      // reverse of the forward processing order
             const int t = d == 0 ? st : L - 1 - st;
             const int s_in = d == 0 ? t : t + 1;
             SkinnyArgs k; memset(&k, 0, sizeof(k));
             k.B = B; k.H = H; k.lstm = 2; k.nseg = 0; k.ksplit = 1;
             k.dh_a = g.dy + (long)t * 2 * H + d * H; k.ld_dh_a = L * 2 * H;
-            k.dh_b = g.dh_carry + ((st + 1) & 1) * BH; k.dh_carry_out = g.dh_carry + (st & 1) * BH;
-            if (st < L - 1) { k.part = g.part; k.n_part = g.ksb; k.part_ks = BH; k.part_ld = H; k.part_col0 = 0; }
+            k.dh_b = dh_carry + ((st + 1) & 1) * BH; k.dh_carry_out = dh_carry + (st & 1) * BH;
+            if (st < L - 1) { k.part = part; k.n_part = g.ksb; k.part_ks = BH; k.part_ld = H; k.part_col0 = 0; }
             k.gates = a.gates[d] + (long)t * B4H; k.c_prev = a.c[d] + s_in * BH;
-            k.dc_in = g.dc + ((st + 1) & 1) * BH; k.dc_out = g.dc + (st & 1) * BH;
+            k.dc_in = dc + ((st + 1) & 1) * BH; k.dc_out = dc + (st & 1) * BH;
             k.lengths = a.lengths; k.t = t;
             k.dgates_out = g.dxproj[d] + (long)t * B4H; k.ld_dgates = 4 * H;
-            MTTS_TRY(skinny_launch(k, s));
+            MTTS_TRY(skinny_launch(k, q_s));
             if (st > 0) {
                 SkinnyArgs q; memset(&q, 0, sizeof(q));
                 q.nseg = 1; q.B = B; q.N = H; q.ksplit = g.ksb;
                 q.seg[0] = SkSeg{g.dxproj[d] + (long)t * B4H, g.w_hh_T[d], 4 * H, 4 * H, 4 * H, 0, 0};
-                q.out = g.part; q.ldo = H; q.out_ks = BH;
-                MTTS_TRY(skinny_launch(q, s));
+                q.out = part; q.ldo = H; q.out_ks = BH;
+                MTTS_TRY(skinny_launch(q, q_s));
             }
         }
+    }
+    MTTS_CHECK_HIP(hipEventRecord(ev_join, sd[1]));
+    MTTS_CHECK_HIP(hipStreamWaitEvent(s, ev_join, 0));
+    for (int d = 0; d < 2; ++d) {
         // dx (+)= dG W_ih ; dW_ih = dG^T x ; dW_hh = dG^T h_prev ; biases
         MTTS_TRY(gm(g.dxproj[d], a.w_ih[d], g.dx, L * B, Cin, 4 * H, 4 * H, Cin, Cin, false, true, d == 0 ? 0.f : 1.f, s));
         MTTS_TRY(gm(g.dxproj[d], a.x, g.d_w_ih[d], 4 * H, Cin, L * B, 4 * H, Cin, Cin, true, true, 0.f, s));

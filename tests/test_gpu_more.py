@@ -272,3 +272,28 @@ def test_fused_loss_and_adam_match_torch():
         for a, b in zip(p1, p2):
             assert (a - b).abs().max().item() <= 1e-6
     assert set(o1.state_dict()['state'][0].keys()) == set(o2.state_dict()['state'][0].keys())
+
+
+@pytest.mark.parametrize('variant', ['nt', 'nn', 'tt', 'tn'])
+def test_split_bf16_gemm_core_is_fp32_accurate(variant):
+    """The default GEMM core evaluates fp32 products as six bf16 partial products (csrc/gemm.hip).  Its error against an
+    fp64 product must stay at the level of an fp32 accumulation: the yardstick is torch.matmul in fp32 (rocBLAS, exact fp32
+    products) on the same data, measured in units of sum|a_k b_k| per output element, on wide-dynamic-range data, ragged
+    sizes and all four storage variants.  (An operand rounded to ONE bf16 would sit near 2^-9 = 2e-3 on this scale.)"""
+    from multilingual_text_to_speech_amd import kernels as K
+    torch.manual_seed(3)
+    M, N, Kd = 333, 517, 1234          # none a multiple of the 128x128x32 tile
+    dev = torch.device('cuda')
+    # values spanning ~12 binades so that the low split planes matter
+    A = (torch.randn(M, Kd, device=dev) * torch.exp2(torch.randint(-6, 6, (M, Kd), device=dev).float()))
+    Bm = (torch.randn(N, Kd, device=dev) * torch.exp2(torch.randint(-6, 6, (N, Kd), device=dev).float()))
+    C = torch.empty(M, N, device=dev)
+    tA, tB = variant[0] == 't', variant[1] == 'n'
+    a_st = A.t().contiguous() if tA else A          # transA: stored [K, M]
+    b_st = Bm.t().contiguous() if tB else Bm        # transB: stored [K, N]
+    K.gemm(a_st, b_st, C, M, N, Kd, M if tA else Kd, N if tB else Kd, N, transA=tA, transB=tB)
+    ref = A.double() @ Bm.double().t()
+    scale = A.double().abs() @ Bm.double().abs().t()
+    err = ((C.double() - ref).abs() / scale).max().item()
+    err_torch = (((A @ Bm.t()).double() - ref).abs() / scale).max().item()
+    assert err <= 1.25 * err_torch + 2.0 ** -24, f'{variant}: split-bf16 GEMM error {err:.3e} (torch fp32 matmul: {err_torch:.3e})'
