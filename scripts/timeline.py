@@ -37,3 +37,19 @@ i_f0, i_f1, i_l, i_b0, i_b1, i_ad = [m[1] for m in marks]
 dump(0, i_f0, 'before decoder fwd chain (encoder + hoisted)')
 dump(i_f1, i_b0, 'fwd chain end -> bwd chain start (frame proj, postnet fwd, loss, postnet bwd, hoisted bwd)')
 dump(i_b1, len(step) - 1, 'after bwd chain (bwd_post, encoder bwd, adam)')
+
+def gaps(a, b, title, min_gap=30.0):
+    print('--- idle gaps > %.0f us in %s' % (min_gap, title))
+    cur_end = step[a][2]; tot = 0
+    for r in step[a + 1:b + 1]:
+        if r[1] > cur_end:
+            gp = (r[1] - cur_end) / 1e3
+            tot += gp
+            if gp >= min_gap: print('   at %8.2f ms  idle %7.1f us  before %s' % ((cur_end - t0) / 1e6, gp, r[0][:70]))
+        cur_end = max(cur_end, r[2])
+    print('   total idle %.2f ms of %.2f ms' % (tot / 1e3, (step[b][2] - step[a][1]) / 1e6))
+gaps(0, i_f0, 'pre-chain fwd')
+gaps(i_f1, i_b0, 'between chains')
+gaps(i_b1, len(step) - 1, 'after bwd chain')
+gaps(i_f0, i_f1, 'fwd chain', 1e9)
+gaps(i_b0, i_b1, 'bwd chain', 1e9)
