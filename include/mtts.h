@@ -63,7 +63,8 @@ typedef struct GemmArgs {
     float beta;
     int act;
     float mask_scale;
-    int nosplit;      /* != 0: never use the split-K workspace (launches on a second stream) */
+    int nosplit;      /* helper-stream launches: 1 = never split K; 2 = may split K into the UPPER half of the workspace (at most one
+                         stream may use mode 2 at a time); both ask for one workgroup per CU.  0 = caller's stream, lower half. */
 } GemmArgs;
 
 int mtts_gemm_ex(const GemmArgs* args, void* stream);

@@ -253,7 +253,7 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
     if (!sw) return mtts_fail("decoder backward: cannot create the weight-gradient stream");
     auto wgrad = [&](const float* dY, int ldy, int Mw, const float* X, int ldx, int Nw, float* dW, int ldw, int rows, float beta) -> int {
         GemmArgs q; memset(&q, 0, sizeof(q));
-        q.taps = 1; q.batch = 1; q.zt = 1; q.alpha = 1.f; q.mask_scale = 1.f; q.nosplit = 1; q.transA = 1; q.transB = 1;
+        q.taps = 1; q.batch = 1; q.zt = 1; q.alpha = 1.f; q.mask_scale = 1.f; q.nosplit = 2; q.transA = 1; q.transB = 1;
         q.A = dY; q.lda = ldy; q.M = Mw; q.B = X; q.ldb = ldx; q.N = Nw; q.C = dW; q.ldc = ldw; q.K = rows; q.Kc = rows; q.beta = beta;
         return mtts_gemm_ex(&q, sw);
     };

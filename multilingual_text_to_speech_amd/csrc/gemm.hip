@@ -482,11 +482,18 @@ MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
     {
         const long tiles = (long)ntx * nty * p.batch * p.zt;
         const int nkb = cdiv(p.K, BK);
-        if (g_ws_host && !p.nosplit && tiles < 512 && nkb >= 64) {
+        const size_t half = g_ws_bytes / 2;
+        if (g_ws_host && p.nosplit == 0 && tiles < 512 && nkb >= 64) {
             S = (int)((1024 + tiles - 1) / tiles);
             if (S > nkb / 16) S = nkb / 16;
             if (S > 32) S = 32;
-            while (S > 1 && (size_t)S * p.batch * p.zt * p.M * p.N * sizeof(float) > g_ws_bytes) --S;
+            while (S > 1 && (size_t)S * p.batch * p.zt * p.M * p.N * sizeof(float) > half) --S;
+            if (S < 1) S = 1;
+        } else if (g_ws_host && p.nosplit == 2 && tiles < 128 && nkb >= 32) {   // helper stream: aim at one workgroup per CU
+            S = (int)(256 / tiles);
+            if (S > nkb / 16) S = nkb / 16;
+            if (S > 32) S = 32;
+            while (S > 1 && (size_t)S * p.batch * p.zt * p.M * p.N * sizeof(float) > half) --S;
             if (S < 1) S = 1;
         }
     }
@@ -509,7 +516,7 @@ MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
         hipFuncSetAttribute((const void*)gemm_split_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr_done = true;
     }
-    float* ws = g_ws_host;
+    float* ws = p.nosplit == 2 ? g_ws_host + g_ws_bytes / 2 / sizeof(float) : g_ws_host;
     if (exact_f32) {
         if (!p.transA && !p.transB) hipLaunchKernelGGL((gemm_mfma_kernel<false, false>), grid, dim3(256), lds, s, p, ws);
         else if (!p.transA && p.transB) hipLaunchKernelGGL((gemm_mfma_kernel<false, true>), grid, dim3(256), lds, s, p, ws);
