@@ -532,6 +532,9 @@ int mtts_grad_reverse_clamp(const float* g, float* out, long n, float l, float c
  * them and returns the summed duration in ms and the sample count.  Not for use inside timed regions' setup. */
 int mtts_prof_begin(int max_samples, int stride);
 int mtts_prof_end(float* total_ms, int* count);
+/* summed duration (ms) of the EMPTY event brackets recorded in front of every sample: the cost of an event pair with nothing
+ * between, subtracted by bench.py from the kernel brackets */
+float mtts_prof_empty_ms(void);
 
 const char* mtts_last_error(void);
 int mtts_version(void);

@@ -10,6 +10,7 @@
 //              chain A: att-LSTM([ctx,h]) -> query -> attention      (per step)
 //              chain B: gen-LSTM(h_gen) with precomputed input gates  (per step, after chain A).
 #include "common.h"
+#include <stdlib.h>
 
 static inline int round4(int x) { return (x + 3) & ~3; }
 
@@ -217,30 +218,6 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
         return 0;
     }
 
-    if (false) {
-        // generator-LSTM input gates for all steps of the range: [h_att, ctx] W_ih^T
-        MTTS_TRY(gemm_plain(a.h_att + (a.t0 + 1) * BH, a.gen_w_ih, a.pre_gen + a.t0 * B4H, nsteps * B, 4 * H, H, H, H + Dm, 4 * H,
-                            false, false, 1.f, 0.f, nullptr, 0, s));
-        MTTS_TRY(gemm_plain(a.ctx + (a.t0 + 1) * BD, a.gen_w_ih + H, a.pre_gen + a.t0 * B4H, nsteps * B, 4 * H, Dm, Dm, H + Dm, 4 * H,
-                            false, false, 1.f, 1.f, nullptr, 0, s));
-        for (int t = a.t0; t < a.t1; ++t) {
-            SkinnyArgs k; memset(&k, 0, sizeof(k));
-            k.B = B; k.N = 4 * H; k.ksplit = 1; k.lstm = 1; k.H = H; k.nseg = 1;
-            k.seg[0] = SkSeg{a.h_gen + t * BH, a.gen_w_hh, H, H, H, 0, 0};
-            k.pre = a.pre_gen + t * B4H; k.ldpre = 4 * H;
-            k.b_ih = a.gen_b_ih; k.b_hh = a.gen_b_hh;
-            k.h_prev = a.h_gen + t * BH; k.c_prev = a.c_gen + t * BH;
-            k.h_out = a.h_gen + (t + 1) * BH; k.c_out = a.c_gen + (t + 1) * BH;
-            k.gates_out = a.gates_gen ? a.gates_gen + t * B4H : nullptr;
-            lstm_reg(a, k, a.gen_hmask, a.gen_cmask, t);
-            MTTS_TRY(skinny_launch(k, s));
-        }
-        float* o = a.out + (long)(a.t0 + 1) * B * Mo;
-        MTTS_TRY(gemm_plain(a.h_gen + (a.t0 + 1) * BH, a.w_out, o, nsteps * B, M + 1, H, H, H + Dm, Mo, false, false, 1.f, 0.f,
-                            a.b_out, 0, s));
-        MTTS_TRY(gemm_plain(a.ctx + (a.t0 + 1) * BD, a.w_out + H, o, nsteps * B, M + 1, Dm, Dm, H + Dm, Mo, false, false, 1.f, 1.f,
-                            nullptr, 0, s));
-    }
     return 0;
 }
 

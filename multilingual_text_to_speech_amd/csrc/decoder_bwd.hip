@@ -7,6 +7,7 @@
 // Per step only skinny GEMMs against TRANSPOSED recurrent weights, the fused LSTM-cell backward epilogue and the
 // attention backward kernel run; every weight gradient is one large MFMA GEMM over the saved gate gradients.
 #include "common.h"
+#include <stdlib.h>
 #include <algorithm>
 #include <vector>
 

@@ -7,7 +7,7 @@ namespace {
 struct Prof {
     bool on = false;
     int stride = 1, used = 0;
-    std::vector<hipEvent_t> e0, e1;
+    std::vector<hipEvent_t> ec, e0, e1;     // ec -> e0: empty bracket (cost of one event packet); e0 -> e1: the kernel
 } g_prof;
 }
 
@@ -16,6 +16,7 @@ bool prof_sample(int t, hipStream_t s, int phase) {
     if (!g_prof.on || (t % g_prof.stride) != 0) return false;
     if (phase == 0) {
         if (g_prof.used >= (int)g_prof.e0.size()) return false;
+        hipEventRecord(g_prof.ec[g_prof.used], s);
         hipEventRecord(g_prof.e0[g_prof.used], s);
         return true;
     }
@@ -25,11 +26,14 @@ bool prof_sample(int t, hipStream_t s, int phase) {
 }
 
 MTTS_API int mtts_prof_begin(int max_samples, int stride) {
+    for (auto e : g_prof.ec) hipEventDestroy(e);
     for (auto e : g_prof.e0) hipEventDestroy(e);
     for (auto e : g_prof.e1) hipEventDestroy(e);
+    g_prof.ec.assign(max_samples, nullptr);
     g_prof.e0.assign(max_samples, nullptr);
     g_prof.e1.assign(max_samples, nullptr);
     for (int i = 0; i < max_samples; ++i) {
+        MTTS_CHECK_HIP(hipEventCreate(&g_prof.ec[i]));
         MTTS_CHECK_HIP(hipEventCreate(&g_prof.e0[i]));
         MTTS_CHECK_HIP(hipEventCreate(&g_prof.e1[i]));
     }
@@ -39,15 +43,23 @@ MTTS_API int mtts_prof_begin(int max_samples, int stride) {
     return 0;
 }
 
+static float g_prof_empty_ms = 0.f;
+// Summed duration (ms) of the empty brackets recorded in front of every sample of the last mtts_prof_end():
+// what an event pair costs with nothing between, to be subtracted from the kernel brackets.
+MTTS_API float mtts_prof_empty_ms(void) { return g_prof_empty_ms; }
+
 // Synchronises the recorded events; returns the number of samples and their summed duration (ms).
 MTTS_API int mtts_prof_end(float* total_ms, int* count) {
     g_prof.on = false;
     float tot = 0.f;
+    g_prof_empty_ms = 0.f;
     for (int i = 0; i < g_prof.used; ++i) {
         float ms = 0.f;
         MTTS_CHECK_HIP(hipEventSynchronize(g_prof.e1[i]));
         MTTS_CHECK_HIP(hipEventElapsedTime(&ms, g_prof.e0[i], g_prof.e1[i]));
         tot += ms;
+        MTTS_CHECK_HIP(hipEventElapsedTime(&ms, g_prof.ec[i], g_prof.e0[i]));
+        g_prof_empty_ms += ms;
     }
     *total_ms = tot;
     *count = g_prof.used;

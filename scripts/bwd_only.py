@@ -1,0 +1,21 @@
+import os, sys, time, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import bench
+from multilingual_text_to_speech_amd.params import presets, Params as hp
+from multilingual_text_to_speech_amd.modules.tacotron2 import Tacotron
+import multilingual_text_to_speech_amd.kernels as K
+presets.apply('shared_training')
+torch.manual_seed(0)
+dev = torch.device('cuda')
+model = Tacotron().to(dev).train()
+b = bench.synthetic_batch(hp, 64, 120, 600, dev)
+def sync(): torch.cuda.synchronize(); return time.perf_counter()
+with torch.no_grad():
+    emb = K.embedding(model._embedding.weight, b['text'], 0); enc0 = model._encoder(emb, b['text_length'], None)
+lang = b['languages'].unsqueeze(1).expand(-1, 120)
+for it in range(4):
+    enc = enc0.detach().requires_grad_(True)
+    t0 = sync(); spec, stop, align = model._decoder(enc, b['text_length'], b['target'], 1.0, None, lang); t1 = sync()
+    loss = spec.sum() + stop.sum() + align.sum()
+    t2 = sync(); loss.backward(); t3 = sync()
+    print('decoder fwd %.2f ms   bwd %.2f ms' % ((t1 - t0) * 1e3, (t3 - t2) * 1e3))
