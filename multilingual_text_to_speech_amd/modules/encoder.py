@@ -57,9 +57,11 @@ class MultiEncoder(Module):
         self._num_langs = num_langs
         self._encoders = ModuleList([Encoder(*encoder_args) for _ in range(num_langs)])
 
-    def forward(self, x, x_lenghts, x_langs):
+    def forward(self, x, x_lenghts, x_langs, blend=False):
         xs = None
-        x_langs_normed = x_langs / x_langs.sum(2, keepdim=True)[0]
+        # the reference divides by the FIRST sample's sums (it is only ever blended at batch 1); batched synthesis
+        # (blend=True) normalises every utterance by its own sums, i.e. the batch-1 result per utterance
+        x_langs_normed = x_langs / (x_langs.sum(2, keepdim=True) if blend else x_langs.sum(2, keepdim=True)[0])
         for l in range(self._num_langs):
             w = x_langs_normed[:, :, l]
             if not bool(w.bool().any()):
@@ -79,6 +81,19 @@ def _to_groups(x, groups, channels):
 def _from_groups(x, groups, channels):
     n, L = x.shape[0], x.shape[1]
     return x.reshape(n, L, groups, channels).permute(0, 2, 1, 3).reshape(n * groups, L, channels)
+
+
+def _expand_groups(x, groups):
+    """Every utterance replicated into all G language groups: row b*G + g belongs to group g."""
+    B, L, C = x.shape
+    return x.unsqueeze(1).expand(B, groups, L, C).reshape(B * groups, L, C)
+
+
+def _blend_batch(x, x_langs, groups):
+    """Batched synthesis: rows b*G + g of x are utterance b through group g; mix by the utterance's own weights."""
+    BG, L, C = x.shape
+    norm = x_langs / x_langs.sum(2, keepdim=True)                       # [B, L, G]
+    return (x.reshape(BG // groups, groups, L, C) * norm.permute(0, 2, 1).unsqueeze(-1)).sum(1)
 
 
 def _blend_groups(x, x_langs, groups):
@@ -107,14 +122,18 @@ class ConvolutionalEncoder(Module):
                               groups=groups))
         self._layers = Sequential(*layers)
 
-    def forward(self, x, x_lenghts=None, x_langs=None):
-        single = x_langs is not None and x_langs.shape[0] == 1
+    def forward(self, x, x_lenghts=None, x_langs=None, blend=False):
+        single = x_langs is not None and x_langs.shape[0] == 1 and not blend
         if single:
             x = x.expand((self._groups, -1, -1))
+        elif blend:
+            x = _expand_groups(x, self._groups)
         x = _to_groups(x.contiguous(), self._groups, self._input_dim)
         for n, layer in enumerate(self._layers):
             x = layer(x, f'enc.{n}')
         x = _from_groups(x, self._groups, self._output_dim)
+        if blend:
+            return _blend_batch(x, x_langs, self._groups)
         return _blend_groups(x, x_langs, self._groups) if single else x
 
 
@@ -133,13 +152,17 @@ class GeneratedConvolutionalEncoder(Module):
         self._layers = Sequential(*layers)
         self._embedding = Embedding(groups, embedding_dim)
 
-    def forward(self, x, x_lenghts=None, x_langs=None):
-        single = x_langs is not None and x_langs.shape[0] == 1
+    def forward(self, x, x_lenghts=None, x_langs=None, blend=False):
+        single = x_langs is not None and x_langs.shape[0] == 1 and not blend
         if single:
             x = x.expand((self._groups, -1, -1))
+        elif blend:
+            x = _expand_groups(x, self._groups)
         e = K.embedding(self._embedding.weight, torch.arange(self._groups, device=x.device))
         x = _to_groups(x.contiguous(), self._groups, self._input_dim)
         for n, layer in enumerate(self._layers):
             x = layer(e, x, f'enc.{n}')
         x = _from_groups(x, self._groups, self._output_dim)
+        if blend:
+            return _blend_batch(x, x_langs, self._groups)
         return _blend_groups(x, x_langs, self._groups) if single else x

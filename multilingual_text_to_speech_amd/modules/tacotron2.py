@@ -117,7 +117,7 @@ class Decoder(Module):
         tgt = target.transpose(1, 2).contiguous()
         return D.decode_train(memory, tgt, encoded_lenghts, teacher, masks, self._cfg(), w)
 
-    def inference(self, encoded_input, speaker, language, lengths=None):
+    def inference(self, encoded_input, speaker, language, lengths=None, stop_threshold=0.5):
         memory = self._memory(encoded_input, speaker, language)
         B, L = memory.shape[0], memory.shape[1]
         if lengths is None:
@@ -125,7 +125,8 @@ class Decoder(Module):
         masks = self._step_masks(self._max_frames, B, memory.device)
         w = D.decoder_weights(self, self._attention, self._prenet)
         with torch.no_grad():
-            frames, _, _, n = D.decode_free(memory, lengths, w, self._cfg(), masks, self._max_frames, hp.stop_frames)
+            frames, _, _, n = D.decode_free(memory, lengths, w, self._cfg(), masks, self._max_frames, hp.stop_frames,
+                                            stop_threshold=stop_threshold)
         return frames, n
 
 
@@ -232,6 +233,56 @@ class Tacotron(Module):
             frames, n = self._decoder.inference(encoded, speaker, language)
             post = self._postnet(frames[:, :n[0]].contiguous(), None)
         return post.transpose(1, 2).squeeze(0)
+
+
+    def inference_batch(self, texts, speakers=None, languages=None, stop_threshold=0.5):
+        """Batched synthesis with the batch-1 reference semantics per utterance.
+
+        texts: list of 1-D int64 token tensors (EOS included); speakers: list of speaker ids or None; languages: list of
+        per-character weight matrices [L_i, n_languages] (synthesize.language_weights) or None.
+        Encoder and post-net run once per bucket of equal length (no padding inside a bucket, so 'same' convolutions and
+        BatchNorm see exactly what the batch-1 call sees); the autoregressive decoder - the expensive part - runs ONCE
+        for all utterances over zero-padded memories with per-sample lengths and the reference's per-sample stop rule.
+        Returns a list of [num_mels, n_i] spectrograms in input order."""
+        dev = self._embedding.weight.device
+        n_utt = len(texts)
+        lens = [int(t.numel()) for t in texts]
+        Lmax = max(lens)
+        grouped = hp.encoder_type in ('convolutional', 'generated')
+        blended = hp.encoder_type in ('convolutional', 'generated', 'separate')
+        encoded = [None] * n_utt
+        lang_ids = [None] * n_utt
+        with torch.no_grad():
+            for L in sorted(set(lens)):
+                idx = [i for i in range(n_utt) if lens[i] == L]
+                text = torch.stack([texts[i].to(dev) for i in idx])
+                lw = torch.stack([languages[i].to(dev).reshape(L, -1) for i in idx]) if languages is not None else None
+                emb = K.embedding(self._embedding.weight, text, padding_idx=0)
+                tl = torch.full((len(idx),), L, dtype=torch.int64)
+                enc = self._encoder(emb, tl, lw, blend=True) if blended else self._encoder(emb, tl, lw)
+                ids = torch.argmax(lw, dim=2) if lw is not None else None
+                for j, i in enumerate(idx):
+                    encoded[i] = enc[j]
+                    lang_ids[i] = ids[j] if ids is not None else None
+            C = encoded[0].shape[-1]
+            memory_in = torch.zeros(n_utt, Lmax, C, device=dev)
+            lang = torch.zeros(n_utt, Lmax, dtype=torch.int64, device=dev) if languages is not None else None
+            spk = None
+            if speakers is not None:
+                spk = torch.as_tensor([int(v) for v in speakers], dtype=torch.int64, device=dev).unsqueeze(1).expand(-1, Lmax)
+            for i in range(n_utt):
+                memory_in[i, :lens[i]] = encoded[i]
+                if lang is not None:
+                    lang[i, :lens[i]] = lang_ids[i]
+            frames, n = self._decoder.inference(memory_in, spk, lang, lengths=torch.as_tensor(lens, dtype=torch.int64),
+                                                stop_threshold=stop_threshold)
+            out = [None] * n_utt
+            for nf in sorted(set(n)):
+                idx = [i for i in range(n_utt) if n[i] == nf]
+                post = self._postnet(frames[idx, :nf].contiguous(), None)
+                for j, i in enumerate(idx):
+                    out[i] = post[j].transpose(0, 1)
+        return out
 
 
 class TacotronLoss(Module):

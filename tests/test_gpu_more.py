@@ -297,3 +297,52 @@ def test_split_bf16_gemm_core_is_fp32_accurate(variant):
     err = ((C.double() - ref).abs() / scale).max().item()
     err_torch = (((A @ Bm.t()).double() - ref).abs() / scale).max().item()
     assert err <= 1.25 * err_torch + 2.0 ** -24, f'{variant}: split-bf16 GEMM error {err:.3e} (torch fp32 matmul: {err_torch:.3e})'
+
+
+@pytest.mark.parametrize('name', golden_names('infer'))
+def test_batched_inference_equals_batch1_per_utterance(name):
+    """Tacotron.inference_batch (bucketed encoder / post-net, ONE batched decoder run with per-sample lengths and stop rule)
+    must reproduce Tacotron.inference - the reference's batch-1 semantics, pinned by the *_infer fixtures - for every
+    utterance of a ragged batch, given the same prenet dropout draws."""
+    from multilingual_text_to_speech_amd.masks import provider
+    from multilingual_text_to_speech_amd.params import Params as hp
+    fx = load_golden(name)
+    model = build_hip_model(fx)
+    dev = torch.device('cuda')
+    base = fx['text'][0].clone()
+    L0 = base.numel()
+    g = torch.Generator().manual_seed(11)
+    texts = [base, base.flip(0).contiguous(), base[:max(3, L0 - 2)].clone()]
+    n_utt = len(texts)
+    n_lang = len(hp.languages) if hp.multi_language else 0
+    langs = None
+    if fx['languages'] is not None:
+        fl = fx['languages']
+        langs = []
+        for i, t in enumerate(texts):
+            if fl.dim() == 3:        # per-character weights: reuse the fixture's (rolled for variety), cut to length
+                w = fl[0].roll(i, 0)[:t.numel()].clone()
+            else:                    # a language id -> one-hot rows
+                w = torch.zeros(t.numel(), n_lang); w[:, (int(fl.reshape(-1)[0]) + i) % n_lang] = 1.0
+            langs.append(w)
+    spks = None
+    if fx['speakers'] is not None:
+        spks = [(int(fx['speakers'].reshape(-1)[0]) + i) % max(1, hp.speaker_number) for i in range(n_utt)]
+    Tmax, P = model._decoder._max_frames, hp.prenet_dimension
+    n_pre = len(model._decoder._prenet._layers)
+    draws = [(torch.rand(Tmax, n_utt, P, generator=g) >= model._decoder._prenet._dropout_rate).to(torch.uint8) for _ in range(n_pre)]
+    try:
+        provider.injected = {f'dec.prenet.{k}': draws[k].to(dev) for k in range(n_pre)}
+        batch = model.inference_batch(texts, spks, langs)
+        singles = []
+        for i, t in enumerate(texts):
+            provider.injected = {f'dec.prenet.{k}': draws[k][:, i:i + 1].contiguous().to(dev) for k in range(n_pre)}
+            lw = langs[i].unsqueeze(0).to(dev) if langs is not None else None
+            sp = torch.tensor([spks[i]], dtype=torch.int64, device=dev) if spks is not None else None
+            singles.append(model.inference(t.clone().to(dev), sp, lw))
+    finally:
+        provider.injected = None
+    for i in range(n_utt):
+        assert batch[i].shape == singles[i].shape, (name, i, batch[i].shape, singles[i].shape)
+        err = (batch[i] - singles[i]).abs().max().item()
+        assert err <= 1e-3, f'{name} utterance {i}: max |delta| = {err:.3e}'
