@@ -41,9 +41,10 @@ static inline size_t att_lds_bytes(int A, int L, int ksz) {
 // Wave w owns attention columns [16w, 16w+16) (A <= 128) for both 16-row tiles of the chunk.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int UP_LD = 36;     // filter-bank row: 32 taps + 4 pad floats (conflict-free ds_read_b128)
-constexpr int NE4_MAX = 8;    // PL float4 per thread (L*A/4 <= NE4_MAX * ATT_THREADS)
+// NE4_MAX = PL float4 per thread (L*A/4 <= NE4_MAX * ATT_THREADS): 8 covers the training shapes (L <= 128 at A = 128) inside 128
+// VGPRs, 16 covers synthesis inputs up to L = 256.
 
-template <int G>              // G = A / 4 lanes cover one position's A values (16 or 32)
+template <int G, int NE4_MAX, int NMT = 2>     // G = A / 4 lanes per position (16 or 32); NMT 16-row tiles of PL_next per workgroup
 __global__ __launch_bounds__(ATT_THREADS) void attn_step_kernel(AttnStepArgs p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x, ch = blockIdx.y;
@@ -95,11 +96,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_kernel(AttnStepArgs p) 
             mem4[j] = (nc4 > 0) ? *reinterpret_cast<const float4*>(mem + (long)l * Dm) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    float mtD[2][4], us[NU_MAX];
+    float mtD[NMT][4], us[NU_MAX];
     const int a_own = min(16 * wave + i16, A - 1);
     if (p.PL_next) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int l = min(l0 + 16 * mt + 4 * q4 + r, L - 1);
@@ -189,14 +190,15 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_kernel(AttnStepArgs p) 
 
     // ---- PL for the next step, rows [l0, l1): loc = cumwin x U^T on MFMA, + M + bias
     if (p.PL_next && 16 * wave < A) {
-        f32x4 acc[2];
-        acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 acc[NMT];
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const float4 bf = *reinterpret_cast<const float4*>(Up + (16 * wave + i16) * UP_LD + 16 * c + 4 * q4);
             const float bv[4] = {bf.x, bf.y, bf.z, bf.w};
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+            for (int mt = 0; mt < NMT; ++mt) {
                 const float* cw = cumw + l0 + 16 * mt + i16 + 16 * c + 4 * q4;
 #pragma unroll
                 for (int s2 = 0; s2 < 4; ++s2) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cw[s2], bv[s2], acc[mt], 0, 0, 0);
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_kernel(AttnStepArgs p) 
         const int a = 16 * wave + i16;
         const float bb = bias[min(a, A - 1)];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int l = l0 + 16 * mt + 4 * q4 + r;
@@ -332,12 +334,17 @@ int attn_step_launch(const AttnStepArgs& p, hipStream_t s) {
     const int nc4 = dc / 4, ng = nc4 > 0 ? (ATT_THREADS / nc4 > 0 ? ATT_THREADS / nc4 : 1) : 1;
     const int lc = (p.L + p.nch - 1) / p.nch;
     const int G = p.A / 4;
-    const bool fast = (p.A == 64 || p.A == 128) && p.L <= ATT_THREADS && (long)p.L * p.A <= 4L * NE4_MAX * ATT_THREADS &&
-                      (p.L + ng - 1) / ng <= NC_MAX && lc <= 32 && p.ksz <= 32 && lds_fast <= 64 * 1024 &&
+    const long la4 = (long)p.L * p.A / 4;
+    const bool fast = (p.A == 64 || p.A == 128) && p.L <= ATT_THREADS && la4 <= 16L * ATT_THREADS &&
+                      (p.L + ng - 1) / ng <= NC_MAX && lc <= 64 && p.ksz <= 32 && lds_fast <= 64 * 1024 &&
                       (long)p.A * p.ksz <= (long)NU_MAX * ATT_THREADS && p.kq <= KQ_MAX;
-    if (fast && G == 32) hipLaunchKernelGGL(attn_step_kernel<32>, dim3(p.B, p.nch), dim3(ATT_THREADS), lds_fast, s, p);
-    else if (fast && G == 16) hipLaunchKernelGGL(attn_step_kernel<16>, dim3(p.B, p.nch), dim3(ATT_THREADS), lds_fast, s, p);
-    else hipLaunchKernelGGL(attn_step_generic_kernel, dim3(p.B, p.nch), dim3(ATT_THREADS), lds, s, p);
+    const bool small = la4 <= 8L * ATT_THREADS && lc <= 32;
+    const dim3 grid(p.B, p.nch), blk(ATT_THREADS);
+    if (fast && G == 32 && small) hipLaunchKernelGGL((attn_step_kernel<32, 8>), grid, blk, lds_fast, s, p);
+    else if (fast && G == 32) hipLaunchKernelGGL((attn_step_kernel<32, 16, 4>), grid, blk, lds_fast, s, p);
+    else if (fast && G == 16 && small) hipLaunchKernelGGL((attn_step_kernel<16, 8>), grid, blk, lds_fast, s, p);
+    else if (fast && G == 16) hipLaunchKernelGGL((attn_step_kernel<16, 16, 4>), grid, blk, lds_fast, s, p);
+    else hipLaunchKernelGGL(attn_step_generic_kernel, grid, blk, lds, s, p);
     MTTS_CHECK_LAUNCH("attn_step_kernel");
     return 0;
 }

@@ -158,6 +158,16 @@ def decode_train(memory, target, lengths, teacher, masks, cfg, w):
     return DecoderFn.apply(memory, target, lengths, teacher, masks, cfg, n, *flat)
 
 
+_COPY_STREAMS = {}
+
+
+def _copy_stream(dev):
+    key = torch.device(dev).index or 0
+    if key not in _COPY_STREAMS:
+        _COPY_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _COPY_STREAMS[key]
+
+
 def decode_free(memory, lengths, w, cfg, masks, max_frames, stop_frames, chunk=32, stop_threshold=0.5, dims=None):
     """Free-running decode with the reference's stop rule (tacotron2.py:201-207), batch >= 1.
 
@@ -173,24 +183,43 @@ def decode_free(memory, lengths, w, cfg, masks, max_frames, stop_frames, chunk=3
     st = DecoderState(B, L, max_frames, (M, P, H, A, Dm, ksz, C), dev, len(w['prenet_w']), save_gates=False, fast=False,
                       kq=cfg.get('kq', 8))
     lengths32 = lengths.to(device=dev, dtype=torch.int32).contiguous()
-    armed = [-1] * B
-    done = [None] * B
-    t = 0
-    while t < max_frames and any(d is None for d in done):
+    # The stop rule is evaluated on the host per chunk while the device already runs the NEXT chunk (speculatively): the
+    # stop logits of chunk k leave through a copy stream once an event after chunk k has fired.
+    import numpy as np
+    armed = np.full(B, -1, dtype=np.int64)
+    done = np.full(B, -1, dtype=np.int64)
+    copy_stream = _copy_stream(dev)
+
+    def submit(t):
         t1 = min(max_frames, t + chunk)
         run_decoder(st, w, memory, lengths32, None, None, masks, cfg, t, t1)
-        stops = torch.sigmoid(st.out[t + 1:t1 + 1, :, M]).cpu()
-        for i in range(t, t1):
-            for b in range(B):
-                if done[b] is not None or not bool(stops[i - t, b] >= stop_threshold):
-                    continue
-                if armed[b] == -1:
-                    armed[b] = stop_frames
-                    continue
-                armed[b] -= 1
-                if armed[b] == 0:
-                    done[b] = i + 1
-        t = t1
+        flags = (torch.sigmoid(st.out[t + 1:t1 + 1, :, M]) >= stop_threshold)
+        ev = torch.cuda.Event()
+        ev.record()
+        return t, t1, flags, ev
+
+    def evaluate(t, t1, flags, ev):
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(ev)
+            flags.record_stream(copy_stream)
+            host = flags.to('cpu', non_blocking=False).numpy()
+        for i in range(t1 - t):
+            f = host[i] & (done < 0)
+            first = f & (armed == -1)
+            again = f & (armed != -1)
+            armed[first] = stop_frames
+            armed[again] -= 1
+            done[again & (armed == 0)] = t + i + 1
+
+    pending = submit(0) if max_frames > 0 else None
+    while pending is not None:
+        nxt = submit(pending[1]) if pending[1] < max_frames else None
+        evaluate(*pending)
+        if (done >= 0).all():
+            break
+        pending = nxt
+    torch.cuda.current_stream(dev).synchronize()
+    done = [int(d) if d >= 0 else None for d in done]
     n = [d if d is not None else max_frames for d in done]
     Tn = max(n)
     frames = st.out[1:Tn + 1, :, :M].transpose(0, 1).contiguous()
