@@ -1,0 +1,136 @@
+"""Host-side input pipeline: symbol ids, language-ordered sharded batches, collation, checkpoints.
+Expected values restate reference behaviour (utils/samplers.py:50-122, dataset/dataset.py:262-322, utils/text.py:115-120)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from multilingual_text_to_speech_amd import data as D
+from multilingual_text_to_speech_amd.params import Params as hp, reset_defaults
+
+
+@pytest.fixture
+def corpus(tmp_path):
+    reset_defaults()
+    hp.languages = ['de', 'fr', 'nl']
+    hp.multi_language, hp.multi_speaker = True, True
+    hp.normalize_spectrogram = False
+    rng = np.random.RandomState(0)
+    counts = {'de': 9, 'fr': 7, 'nl': 8}
+    lines, k = [], 0
+    os.makedirs(tmp_path / 'spec')
+    for r in range(9):                      # interleave so that file order != language order
+        for lang in ('nl', 'de', 'fr'):
+            if r >= counts[lang]:
+                continue
+            T = int(rng.randint(20, 40))
+            np.save(tmp_path / 'spec' / f'{k}.npy', rng.randn(hp.num_mels, T).astype(np.float32))
+            text = 'ab c!' * (1 + k % 3)
+            lines.append(f'{k:06d}|spk{k % 4}|{lang}|wav/{k}.wav|spec/{k}.npy|lin/{k}.npy|{text}|{text}')
+            k += 1
+    lines.append('999999|spkX|xx|a|b|c|ignored language|ignored')
+    meta = tmp_path / 'train.txt'
+    meta.write_text('\n'.join(lines) + '\n', encoding='utf-8')
+    yield D.MelDataset(str(meta), str(tmp_path)), counts
+    reset_defaults()
+
+
+def test_symbol_ids_follow_reference_order():
+    reset_defaults()
+    ids = D.to_sequence('a?§')          # known letter, punctuation, unknown symbol
+    table = D.symbol_table()
+    assert (table['_'], table['~'], table['@']) == (0, 1, 2)
+    assert ids[-1] == 1 and ids[2] == 2 and len(ids) == 4
+    assert ids[0] == 3 + len(hp.punctuations_in) + len(hp.punctuations_out) + hp.characters.index('a')
+    assert max(table.values()) == hp.symbols_count() + 3 - 1
+
+
+def test_dataset_reads_meta_file(corpus):
+    ds, counts = corpus
+    assert len(ds) == sum(counts.values())                       # the line of an unlisted language is skipped
+    assert ds.unique_speakers == ['spk0', 'spk1', 'spk2', 'spk3']
+    spk, lang, tokens, mel, lin = ds[0]
+    assert lang == hp.languages.index('nl') and lin is None and mel.shape[0] == hp.num_mels and tokens[-1] == 1
+
+
+def test_perfect_batches_are_language_ordered_and_sharded(corpus):
+    ds, counts = corpus
+    G = 3
+    s = D.PerfectBatchSampler(ds, hp.languages, 6, shuffle=False, drop_last=True)
+    batches = list(s)
+    assert len(batches) == min(counts.values()) * G // 6          # rounds stop with the rarest language
+    for b in batches:
+        assert [ds.items[i]['language'] for i in b] == [0, 1, 2, 0, 1, 2]
+    flat = [i for b in batches for i in b]
+    assert len(set(flat)) == len(flat)                            # sequential sampling never repeats
+    # without drop_last the tail keeps whole groups only (7 rounds * 3 = 21 = 3 full batches + 3)
+    tail = list(D.PerfectBatchSampler(ds, hp.languages, 6, shuffle=False, drop_last=False))
+    assert [len(b) for b in tail] == [6, 6, 6, 3] and len(s) == 4  # __len__ = ceil(7 / 2) like the reference
+    # two ranks: contiguous halves with whole groups, together the global batch
+    r0 = list(D.PerfectBatchSampler(ds, hp.languages, 12, shuffle=True, drop_last=True, rank=0, world=2, seed=5))
+    r1 = list(D.PerfectBatchSampler(ds, hp.languages, 12, shuffle=True, drop_last=True, rank=1, world=2, seed=5))
+    whole = list(D.PerfectBatchSampler(ds, hp.languages, 12, shuffle=True, drop_last=True, seed=5))
+    assert len(r0) == len(r1) == len(whole) == 1
+    assert r0[0] + r1[0] == whole[0]
+    for part in (r0[0], r1[0]):
+        assert [ds.items[i]['language'] for i in part] == [0, 1, 2, 0, 1, 2]
+    with pytest.raises(AssertionError):
+        D.PerfectBatchSampler(ds, hp.languages, 9, world=2)       # 9 % (3 * 2) != 0
+
+
+def test_collate_pads_and_marks_stop_frames(corpus):
+    ds, _ = corpus
+    items = [ds[i] for i in (0, 4, 8, 2)]
+    for sort in (False, True):                                    # the sorted branch crashes in the reference (:299-303)
+        u, ul, mel, lin, ml, stop, spk, lang = D.Collate(sort)(items)
+        order = sorted(range(4), key=lambda i: -len(items[i][2])) if sort else list(range(4))
+        if sort:
+            assert ul.tolist() == sorted(ul.tolist(), reverse=True)
+        assert lin is None and u.shape == (4, int(ul.max())) and mel.shape == (4, hp.num_mels, int(ml.max()))
+        for row, i in enumerate(order):
+            s_, l_, tok, m, _ = items[i]
+            assert len(tok) == ul[row] and u[row, :len(tok)].tolist() == tok and not u[row, len(tok):].any()
+            T = m.shape[1]
+            assert ml[row] == T and torch.equal(mel[row, :, :T], torch.as_tensor(m)) and not mel[row, :, T:].any()
+            assert stop[row].tolist() == [0.0] * (T - hp.stop_frames) + [1.0] * (mel.shape[2] - T + hp.stop_frames)
+            assert spk[row] == s_ and lang[row] == l_
+    batch = D.batch_to_device(D.Collate(False)(items), 'cpu')
+    assert set(batch) == {'text', 'text_length', 'target', 'target_length', 'stop', 'speakers', 'languages'}
+
+
+def test_imbalanced_sampler_weights(corpus):
+    ds, counts = corpus
+    g = torch.Generator().manual_seed(0)
+    draws = [i for _ in range(40) for i in D.RandomImbalancedSampler(ds, generator=g)]
+    share = np.bincount([ds.items[i]['language'] for i in draws], minlength=3) / len(draws)
+    assert np.abs(share - 1 / 3).max() < 0.05                      # languages equalised despite 9/7/8 utterances
+
+
+def test_checkpoint_round_trip(tmp_path):
+    reset_defaults()
+    hp.version = 'unit'
+    hp.batch_size = 48
+    model = torch.nn.DataParallel(torch.nn.Linear(4, 3)) if False else torch.nn.Linear(4, 3)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    sched = torch.optim.lr_scheduler.StepLR(opt, 10, 0.5)
+
+    class Crit:
+        def __init__(self): self.v = 3
+        def state_dict(self): return {'v': self.v}
+        def load_state_dict(self, d): self.v = d['v']
+    crit = Crit()
+    path = str(tmp_path / 'ckpt')
+    D.save_checkpoint(path, 7, model, opt, sched, crit)
+    state = torch.load(path, weights_only=False)
+    assert set(state) == {'epoch', 'model', 'optimizer', 'scheduler', 'parameters', 'criterion'}      # train.py:302-310
+    # a DataParallel-era checkpoint ('module.' prefix) loads too
+    state['model'] = {'module.' + k: v + 1 for k, v in state['model'].items()}
+    torch.save(state, path)
+    reset_defaults()
+    crit.v = 0
+    m2 = torch.nn.Linear(4, 3)
+    st = D.load_checkpoint(path, m2, torch.optim.Adam(m2.parameters()), None, crit)
+    assert st['epoch'] == 7 and hp.batch_size == 48 and hp.version == 'unit' and crit.v == 3
+    assert torch.equal(m2.weight, model.weight + 1)
+    reset_defaults()

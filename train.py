@@ -4,9 +4,11 @@
     python train.py --hyper_parameters generated_switching --synthetic            # single GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train.py ...   # data parallel (RCCL)
 
-The reference's dataset / audio / TensorBoard stack (librosa, phonemizer, ...) is outside the hot path and absent from
-this image, so this entry point drives the model with the synthetic batches of SURVEY.md section 8(d) (`--synthetic`,
-the default) or with pre-collated tensors saved by the user (`--batches file.pt`: a list of dicts with the keys of
+The reference's audio / phonemiser / TensorBoard stack (librosa, phonemizer, ...) is outside the hot path and absent from
+this image.  With `--data_root DIR` (containing train.txt [+ val.txt] meta-files and cached mel `.npy` files, the
+reference's on-disk format) the loop runs epochs over multilingual_text_to_speech_amd.data (language-ordered, per-rank
+sharded batches; StepLR and checkpoint cadence of train.py:260-310).  Otherwise it drives the model with the synthetic
+batches of SURVEY.md section 8(d) or with pre-collated tensors (`--batches file.pt`: a list of dicts with the keys of
 bench.synthetic_batch).  Checkpoints use the reference's dictionary layout (train.py:302-310).
 """
 import argparse
@@ -28,6 +30,8 @@ def main():
     ap.add_argument("--frames", type=int, default=600)
     ap.add_argument("--chars", type=int, default=120)
     ap.add_argument("--batches", type=str, default=None)
+    ap.add_argument("--data_root", type=str, default=None, help="directory with train.txt / val.txt and cached spectrograms")
+    ap.add_argument("--loader_workers", type=int, default=2)
     ap.add_argument("--synthetic", action="store_true", default=True)
     args = ap.parse_args()
 
@@ -67,6 +71,8 @@ def main():
     G = hp.language_number if hp.encoder_type in ('generated', 'convolutional') else 1
     per = hp.batch_size // world
     D.shard_bounds(per * world, rank, world, G)
+    if args.data_root:
+        return train_on_dataset(args, hp, model, opt, crit, buckets, rank, world, device, epoch0, ckpt_dir, state)
     batches = torch.load(args.batches) if args.batches else None
     for step in range(args.steps):
         batch = batches[step % len(batches)] if batches else synthetic_batch(hp, per, args.chars, args.frames, device, seed=step * world + rank)
@@ -80,6 +86,48 @@ def main():
         torch.save({'epoch': epoch0, 'model': model.state_dict(), 'optimizer': opt.state_dict(), 'scheduler': {},
                     'parameters': hp.state_dict(), 'criterion': crit.state_dict()}, path)
         print('saved', path)
+
+
+def train_on_dataset(args, hp, model, opt, crit, buckets, rank, world, device, epoch0, ckpt_dir, state):
+    """Epoch loop of the reference (train.py:218-310) over cached spectrograms, one process per GPU."""
+    from torch.utils.data import DataLoader
+    from multilingual_text_to_speech_amd import data as DT
+    train_set = DT.MelDataset(os.path.join(args.data_root, 'train.txt'), args.data_root)
+    val_path = os.path.join(args.data_root, 'val.txt')
+    val_set = DT.MelDataset(val_path, args.data_root, train_set.unique_speakers) if os.path.exists(val_path) else None
+    grouped = hp.encoder_type in ('generated', 'convolutional')
+    langs = hp.languages if grouped else [None]
+
+    def loader(ds, shuffle, drop_last):
+        if grouped:
+            sampler = DT.PerfectBatchSampler(ds, hp.languages, hp.batch_size, shuffle=shuffle, drop_last=drop_last, rank=rank, world=world)
+        else:       # one "language" bucket = plain (optionally balanced) batches, sharded the same way
+            class _Flat:
+                items = [{'language': 0}] * len(ds)
+            sampler = DT.PerfectBatchSampler(_Flat(), [None], hp.batch_size, shuffle=shuffle, drop_last=drop_last, rank=rank, world=world)
+        return DataLoader(ds, batch_sampler=sampler, collate_fn=DT.Collate(not grouped), num_workers=args.loader_workers), sampler
+
+    train_data, train_sampler = loader(train_set, True, True)
+    # StepLR counted in epochs like the reference (train.py:266-271,296-297)
+    step_size = max(1, hp.learning_rate_decay_each // max(1, len(train_data)))
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size, hp.learning_rate_decay)
+    if state is not None and state.get('scheduler'):
+        sched.load_state_dict(state['scheduler'])
+    for epoch in range(epoch0, hp.epochs):
+        train_sampler.set_epoch(epoch)
+        model.train()
+        t0, frames = time.time(), 0
+        for collated in train_data:
+            batch = DT.batch_to_device(collated, device)
+            loss = train_step(model, crit, opt, buckets, batch, hp)
+            frames += int(batch['target_length'].sum())
+        torch.cuda.synchronize()
+        if hp.learning_rate_decay_start - hp.learning_rate_decay_each < epoch * len(train_data):
+            sched.step()
+        if rank == 0:
+            print(f'epoch {epoch}: loss {loss.item():.4f}  {frames * world / (time.time() - t0):.0f} frames/s', flush=True)
+            if (epoch + 1) % hp.checkpoint_each_epochs == 0:
+                DT.save_checkpoint(os.path.join(ckpt_dir, f'{hp.version}_loss-{epoch}-{loss.item():2.3f}'), epoch, model, opt, sched, crit)
 
 
 if __name__ == '__main__':
