@@ -79,10 +79,24 @@ class MelDataset(torch.utils.data.Dataset):
     def __len__(self):
         return len(self.items)
 
-    def __getitem__(self, index):
-        it = self.items[index]
+    def _raw(self, it):
         mel = np.load(os.path.join(self.root_dir, it['spectrogram']))
         assert mel.shape[0] == hp.num_mels, f'spectrogram has {mel.shape[0]} channels, expected {hp.num_mels}'
+        return mel
+
+    def get_normalization_constants(self):
+        """Per-channel mean of means / mean of standard deviations over the collection, each [num_mels, 1]
+        (dataset/dataset.py:165-176); train.py stores them in hp.mel_normalize_mean / _variance before the first batch."""
+        mean, std = 0.0, 0.0
+        for it in self.items:
+            mel = self._raw(it)
+            mean = mean + np.mean(mel, axis=1, keepdims=True)
+            std = std + np.std(mel, axis=1, keepdims=True)
+        return mean / len(self.items), std / len(self.items)
+
+    def __getitem__(self, index):
+        it = self.items[index]
+        mel = self._raw(it)
         if hp.normalize_spectrogram:
             mel = (mel - hp.mel_normalize_mean) / hp.mel_normalize_variance
         return it['speaker'], it['language'], it['phonemes'] if hp.use_phonemes else it['text'], mel, None

@@ -52,6 +52,10 @@ def test_dataset_reads_meta_file(corpus):
     assert ds.unique_speakers == ['spk0', 'spk1', 'spk2', 'spk3']
     spk, lang, tokens, mel, lin = ds[0]
     assert lang == hp.languages.index('nl') and lin is None and mel.shape[0] == hp.num_mels and tokens[-1] == 1
+    mean, std = ds.get_normalization_constants()
+    assert mean.shape == std.shape == (hp.num_mels, 1)
+    hp.normalize_spectrogram, hp.mel_normalize_mean, hp.mel_normalize_variance = True, mean, std
+    assert np.allclose(ds[0][3], (mel - mean) / std)
 
 
 def test_perfect_batches_are_language_ordered_and_sharded(corpus):

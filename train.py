@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--batches", type=str, default=None)
     ap.add_argument("--data_root", type=str, default=None, help="directory with train.txt / val.txt and cached spectrograms")
     ap.add_argument("--loader_workers", type=int, default=2)
+    ap.add_argument("--epochs", type=int, default=None, help="override hp.epochs (dataset mode)")
     ap.add_argument("--synthetic", action="store_true", default=True)
     args = ap.parse_args()
 
@@ -96,7 +97,8 @@ def train_on_dataset(args, hp, model, opt, crit, buckets, rank, world, device, e
     val_path = os.path.join(args.data_root, 'val.txt')
     val_set = DT.MelDataset(val_path, args.data_root, train_set.unique_speakers) if os.path.exists(val_path) else None
     grouped = hp.encoder_type in ('generated', 'convolutional')
-    langs = hp.languages if grouped else [None]
+    if hp.normalize_spectrogram and state is None:      # train.py:246-250; restored from the checkpoint's parameters otherwise
+        hp.mel_normalize_mean, hp.mel_normalize_variance = train_set.get_normalization_constants()
 
     def loader(ds, shuffle, drop_last):
         if grouped:
@@ -113,7 +115,7 @@ def train_on_dataset(args, hp, model, opt, crit, buckets, rank, world, device, e
     sched = torch.optim.lr_scheduler.StepLR(opt, step_size, hp.learning_rate_decay)
     if state is not None and state.get('scheduler'):
         sched.load_state_dict(state['scheduler'])
-    for epoch in range(epoch0, hp.epochs):
+    for epoch in range(epoch0, args.epochs if args.epochs is not None else hp.epochs):
         train_sampler.set_epoch(epoch)
         model.train()
         t0, frames = time.time(), 0
