@@ -45,7 +45,10 @@ def synthetic_batch(hp, B, L, T, device, seed=1):
 
 
 def train_step(model, crit, opt, buckets, batch, hp):
-    opt.zero_grad(set_to_none=True)
+    if buckets is not None and buckets.overlap:
+        buckets.zero_grad()              # gradients are views into the all-reduce buckets
+    else:
+        opt.zero_grad(set_to_none=True)
     post, pre, stop, align, spk, enc = model(batch['text'], batch['text_length'], batch['target'], batch['target_length'],
                                              batch['speakers'], batch['languages'], 1.0)
     dev = post.device
@@ -153,7 +156,7 @@ def main():
     crit = TacotronLoss(hp.guided_attention_steps, hp.guided_attention_toleration, hp.guided_attention_gain)
     from multilingual_text_to_speech_amd.optim import FusedAdam
     opt = FusedAdam(model.parameters(), lr=hp.learning_rate, weight_decay=hp.weight_decay)
-    buckets = D.GradientBuckets(model.parameters()) if world > 1 else None
+    buckets = D.GradientBuckets(model.parameters(), overlap=True) if world > 1 else None
     batch = synthetic_batch(hp, B, L, T, device, seed=1 + rank)
 
     def barrier():

@@ -44,9 +44,15 @@ class GradientBuckets:
     bucket and scale by 1/world so that the result equals the gradient of the global-batch mean loss.
 
     Bucket size is chosen for xGMI's point-to-point links: a few large collectives (default 64 MiB) rather than
-    per-tensor launches."""
+    per-tensor launches.
 
-    def __init__(self, params, bucket_bytes=64 << 20):
+    overlap=True (the training loop): every parameter's .grad is a VIEW into its bucket's flat buffer and a
+    post-accumulate hook launches the bucket's asynchronous all-reduce the moment its last gradient has been written, so
+    the collective of the post-net / decoder buckets runs under the rest of the backward pass.  Use `zero_grad()` instead
+    of the optimizer's (which would detach the views) and `all_reduce()` after backward to launch whatever is left (buckets
+    with unused parameters), wait and scale.  overlap=False reduces after backward from a concatenated copy."""
+
+    def __init__(self, params, bucket_bytes=64 << 20, overlap=False):
         self.params = [p for p in params if p.requires_grad]
         self.buckets = []
         cur, cur_n = [], 0
@@ -59,12 +65,54 @@ class GradientBuckets:
         if cur:
             self.buckets.append(cur)
         self.flat = [None] * len(self.buckets)
+        self.overlap = bool(overlap)
+        self._works = [None] * len(self.buckets)
+        self._pending = [0] * len(self.buckets)
+        self._bucket_of = {}
+        self._hooks = []
+        if self.overlap:
+            for i, bucket in enumerate(self.buckets):
+                n = sum(p.numel() for p in bucket)
+                self.flat[i] = torch.zeros(n, dtype=bucket[0].dtype, device=bucket[0].device)
+                for p in bucket:
+                    self._bucket_of[id(p)] = i
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+            self.zero_grad()
+
+    def zero_grad(self):
+        """Zero the flat buffers and (re)attach every .grad as a view into them; arms the hooks for the next backward."""
+        for i, bucket in enumerate(self.buckets):
+            self.flat[i].zero_()
+            off = 0
+            for p in bucket:
+                n = p.numel()
+                p.grad = self.flat[i][off:off + n].view_as(p)
+                off += n
+            self._pending[i] = len(bucket)
+            self._works[i] = None
+
+    def _launch(self, i):
+        if dist.is_initialized() and dist.get_world_size() > 1 and self._works[i] is None:
+            self._works[i] = dist.all_reduce(self.flat[i], op=dist.ReduceOp.SUM, async_op=True)
+
+    def _on_grad(self, p):
+        i = self._bucket_of[id(p)]
+        self._pending[i] -= 1
+        if self._pending[i] == 0:
+            self._launch(i)
 
     def all_reduce(self, world=None, async_op=True):
         if not dist.is_initialized():
             return
         world = world or dist.get_world_size()
         if world == 1:
+            return
+        if self.overlap:
+            for i in range(len(self.buckets)):
+                self._launch(i)                       # buckets holding parameters that received no gradient this step
+            for i in range(len(self.buckets)):
+                self._works[i].wait()
+                self.flat[i].mul_(1.0 / world)
             return
         works = []
         for i, bucket in enumerate(self.buckets):

@@ -38,6 +38,51 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _worker_overlap(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from multilingual_text_to_speech_amd import dist as D
+    D.init(backend='gloo')
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    unused = torch.nn.Parameter(torch.ones(4))                      # never receives a gradient
+    params = list(model.parameters()) + [unused]
+    buckets = D.GradientBuckets(params, bucket_bytes=32, overlap=True)
+    assert len(buckets.buckets) > 2
+    results = []
+    for step in range(2):                                           # second step checks re-arming / zeroing
+        buckets.zero_grad()
+        g = torch.Generator().manual_seed(100 * step + rank)
+        x = torch.randn(4, 7, generator=g)
+        ref = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+        ref.load_state_dict(model.state_dict())
+        ref(x).pow(2).mean().backward()
+        model(x).pow(2).mean().backward()                           # hooks launch the collectives during this call
+        launched = sum(w is not None for w in buckets._works)
+        buckets.all_reduce()
+        assert all(p.grad.data_ptr() >= buckets.flat[buckets._bucket_of[id(p)]].data_ptr() for p in params)   # still views
+        results.append(dict(local=[p.grad.clone() for p in ref.parameters()], reduced=[p.grad.clone() for p in model.parameters()],
+                            unused=unused.grad.clone(), launched=launched))
+    torch.save(results, f'{out}/o{rank}.pt')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_bucket_allreduce_world2(tmp_path):
+    """Gradient-as-bucket-view + post-accumulate hooks: collectives start inside backward, results equal the mean."""
+    port = _free_port()
+    mp.spawn(_worker_overlap, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / 'o0.pt')
+    r1 = torch.load(tmp_path / 'o1.pt')
+    for s0, s1 in zip(r0, r1):
+        assert s0['launched'] >= 2, 'complete buckets must be launched by the hooks before all_reduce() is called'
+        assert not s0['unused'].any()
+        for l0, l1, g0, g1 in zip(s0['local'], s1['local'], s0['reduced'], s1['reduced']):
+            torch.testing.assert_close(g0, (l0 + l1) / 2, rtol=1e-6, atol=1e-7)
+            assert torch.equal(g0, g1)
+
+
 def test_bucketed_allreduce_world2(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
