@@ -346,3 +346,50 @@ def test_batched_inference_equals_batch1_per_utterance(name):
         assert batch[i].shape == singles[i].shape, (name, i, batch[i].shape, singles[i].shape)
         err = (batch[i] - singles[i]).abs().max().item()
         assert err <= 1e-3, f'{name} utterance {i}: max |delta| = {err:.3e}'
+
+
+def _ddp_gpu_worker(rank, world, port, out, fixture):
+    import os
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    import bench
+    from multilingual_text_to_speech_amd import dist as D
+    from multilingual_text_to_speech_amd.optim import FusedAdam
+    from multilingual_text_to_speech_amd.params import Params as hp
+    from multilingual_text_to_speech_amd.modules.tacotron2 import TacotronLoss
+    from tests.helpers import build_hip_model, load_golden
+    D.init(backend='gloo')                      # both ranks share cuda:0; gloo stages device tensors through the host
+    fx = load_golden(fixture)
+    model = build_hip_model(fx).train()
+    if rank == 1:
+        with torch.no_grad():
+            for p in model.parameters():
+                p.mul_(1.01)
+    D.broadcast_parameters(model, 0)
+    opt = FusedAdam(model.parameters(), lr=1e-3, weight_decay=hp.weight_decay)
+    crit = TacotronLoss(hp.guided_attention_steps, hp.guided_attention_toleration, hp.guided_attention_gain)
+    buckets = D.GradientBuckets(model.parameters(), bucket_bytes=1 << 16, overlap=True)
+    G = len(hp.languages) if hp.encoder_type in ('generated', 'convolutional') else 1
+    losses = []
+    for step in range(2):
+        batch = bench.synthetic_batch(hp, 2 * G, 9, 12, torch.device('cuda'), seed=10 * step + rank)
+        losses.append(float(bench.train_step(model, crit, opt, buckets, batch, hp)))
+    torch.cuda.synchronize()
+    torch.save(dict(losses=losses, params=[p.detach().cpu() for p in model.parameters()], nb=len(buckets.buckets)), f'{out}/g{rank}.pt')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_train_steps_two_ranks_one_gpu(tmp_path):
+    """Two processes (gloo, both on cuda:0) run two full train steps with overlapped bucket all-reduce and the fused
+    clip+Adam: replicas must stay bit-identical although every rank sees different data."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_ddp_gpu_worker, args=(2, port, str(tmp_path), 'generated_train'), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / 'g0.pt'), torch.load(tmp_path / 'g1.pt')
+    assert r0['nb'] > 1 and all(map(lambda v: v == v and abs(v) < 1e4, r0['losses'] + r1['losses']))
+    assert r0['losses'] != r1['losses']                         # different shards
+    for a, b in zip(r0['params'], r1['params']):
+        assert torch.equal(a, b)
