@@ -393,3 +393,17 @@ def test_data_parallel_train_steps_two_ranks_one_gpu(tmp_path):
     assert r0['losses'] != r1['losses']                         # different shards
     for a, b in zip(r0['params'], r1['params']):
         assert torch.equal(a, b)
+
+
+def test_exact_f32_gemm_core_selectable():
+    """MTTS_GEMM_EXACT_F32=1 (read once per process) switches every GEMM to the v_mfma_f32_32x32x2_f32 core; the fixture
+    parity of a forward and a backward case must hold on it as well."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MTTS_GEMM_EXACT_F32='1')
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', 'tests/test_gpu_forward.py', 'tests/test_gpu_backward.py',
+                        '-k', 'shared_train or simple_train'], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout
