@@ -51,10 +51,14 @@ def _random_batch(hp, B, L, T, seed=5, ragged=True):
     return text, tl, target, tgl, spk, lang
 
 
-@pytest.mark.parametrize('preset,B', [('shared_training', 4), ('generated_switching', 10)])
-def test_hip_matches_oracle_at_real_widths(preset, B):
+@pytest.mark.parametrize('preset,B,L,T', [('shared_training', 4, 24, 10), ('generated_switching', 10, 24, 10),
+                                          ('shared_training', 1, 1, 1),        # one token, one frame, one sample
+                                          ('shared_training', 17, 33, 2),      # odd batch (two 16-row MFMA tiles, one nearly empty)
+                                          ('generated_switching', 5, 2, 3)])   # inputs shorter than every convolution kernel
+def test_hip_matches_oracle_at_real_widths(preset, B, L, T):
     """Real layer widths (512/1024/...), small batch and lengths so the CPU oracle finishes in seconds; eval mode with the
-    prenet dropout (always on) injected; BN running stats randomised so eval-mode activations stay bounded."""
+    prenet dropout (always on) injected; BN running stats randomised so eval-mode activations stay bounded.  The tiny
+    cases are the degenerate ends of the shape range (single token / frame / sample, ragged odd batches)."""
     from multilingual_text_to_speech_amd.params import presets, Params as hp
     from multilingual_text_to_speech_amd.modules.tacotron2 import Tacotron
     from multilingual_text_to_speech_amd.masks import provider
@@ -68,8 +72,7 @@ def test_hip_matches_oracle_at_real_widths(preset, B):
                 v.copy_(torch.empty(v.shape).uniform_(300.0, 900.0, generator=g) if '_encoder' in k and preset != 'shared_training'
                         else torch.empty(v.shape).uniform_(0.5, 1.5, generator=g))
     model.eval()
-    L, T = 24, 10
-    text, tl, target, tgl, spk, lang = _random_batch(hp, B, L, T)
+    text, tl, target, tgl, spk, lang = _random_batch(hp, B, L, T, ragged=L >= 4)
     keep = {f'dec.prenet.{i}': (torch.rand(T, B, hp.prenet_dimension, generator=g) >= hp.dropout).to(torch.uint8) for i in range(2)}
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     cfg = O.cfg_from_params(hp)
