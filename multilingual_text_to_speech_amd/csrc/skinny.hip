@@ -7,6 +7,14 @@ __global__ __launch_bounds__(NT) void skinny_kernel(SkinnyArgs p) {
     skinny_body<MT>(p, red, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
+// Low-register variant (2-deep load pipeline, <= 128 VGPRs): two 512-thread workgroups fit on one CU.  Used when the grid has more
+// workgroups than the chip has CUs (batch > 64: several row tiles per column block), where co-residency beats pipeline depth.
+template <int MT>
+__global__ __launch_bounds__(NT, 4) void skinny_kernel_lo(SkinnyArgs p) {
+    __shared__ float red[NW][MT * 16][17];
+    skinny_body<MT, 2>(p, red, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
 int skinny_launch(const SkinnyArgs& p, hipStream_t s) {
     MTTS_REQUIRE(p.nseg >= 0 && p.nseg <= 3 && p.B > 0 && (p.nseg > 0 || p.lstm == 2), "skinny: bad nseg/B");
     for (int i = 0; i < p.nseg; ++i) {
@@ -26,6 +34,7 @@ int skinny_launch(const SkinnyArgs& p, hipStream_t s) {
     const int cbs = p.lstm == 1 ? cdiv(p.H, 4) : cdiv(q.N, 16);
     if (p.B <= 16) hipLaunchKernelGGL(skinny_kernel<1>, dim3(cbs, cdiv(p.B, 16), ks), dim3(NT), 0, s, q);
     else if (p.B <= 32) hipLaunchKernelGGL(skinny_kernel<2>, dim3(cbs, cdiv(p.B, 32), ks), dim3(NT), 0, s, q);
+    else if ((long)cbs * cdiv(p.B, 64) * ks > 320) hipLaunchKernelGGL(skinny_kernel_lo<4>, dim3(cbs, cdiv(p.B, 64), ks), dim3(NT), 0, s, q);
     else hipLaunchKernelGGL(skinny_kernel<4>, dim3(cbs, cdiv(p.B, 64), ks), dim3(NT), 0, s, q);
     MTTS_CHECK_LAUNCH("skinny_kernel");
     return 0;
