@@ -76,7 +76,8 @@ def decoder_bwd(ctx, dspec, dstop, dalign):
     buf('dcum_all', _z(T + 1, B, L, device=dev))
     buf('dq_all', _z(T, B, A, device=dev))
     buf('part_gen', _z(ksb, B, H, device=dev))
-    ksc = cfg.get('ksb_ctx', 8)
+    # K-split of the ctx-column input gradient: as many slabs as keep the launch within ONE wave of workgroups (256 CUs)
+    ksc = cfg.get('ksb_ctx', max(1, min(8, 256 // ((Dm + 15) // 16))))
     buf('part_att', _z(ksc * B * Dm + ksb * B * H, device=dev))
     g.ksb, g.nch, g.ksb_ctx = ksb, nch, ksc
     buf('dc_att', _z(2, B, H, device=dev))
