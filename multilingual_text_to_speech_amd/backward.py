@@ -55,8 +55,9 @@ def decoder_bwd(ctx, dspec, dstop, dalign):
     buf('dG_gen', _e(T, B, 4 * H, device=dev))
     if H % 16 == 0 and st.h_att_p is not None:      # MFMA-tile-order copies for the per-step input-gradient GEMMs
         Bp = (B + 15) & ~15
-        buf('dG_att_p', _z(T, Bp * 4 * H, device=dev))
-        buf('dG_gen_p', _z(T, Bp * 4 * H, device=dev))
+        zp = _z if Bp != B else _e                                 # padded batch rows of the packed copies stay zero
+        buf('dG_att_p', zp(T, Bp * 4 * H, device=dev))
+        buf('dG_gen_p', zp(T, Bp * 4 * H, device=dev))
         buf('att_w_rec_Tp', _e(((Dm + H + 15) & ~15) * 4 * H, device=dev))
         buf('gen_w_hh_Tp', _e(H * 4 * H, device=dev))
     if not st.fast:      # general schedule (teacher forcing < 1): per-step chain with transposed full weights
@@ -71,9 +72,10 @@ def decoder_bwd(ctx, dspec, dstop, dalign):
         buf('frames_fed', _e(T, B, M, device=dev))
     buf('dHG', _e(T, B, H, device=dev))
     buf('dHA', _e(T, B, H, device=dev))
-    buf('dctx_all', _z(T + 1, B, Dm, device=dev))
-    buf('dctx_tot', _z(T + 1, B, Dm, device=dev))
-    buf('dcum_all', _z(T + 1, B, L, device=dev))
+    # written slot by slot before they are read; only the boundary slots need clearing
+    buf('dctx_all', _e(T + 1, B, Dm, device=dev))[0].zero_()
+    buf('dctx_tot', _e(T + 1, B, Dm, device=dev))[0].zero_()
+    buf('dcum_all', _z(T + 1, B, L, device=dev))                   # accumulated with atomics by the chunk workgroups
     buf('dq_all', _z(T, B, A, device=dev))
     buf('part_gen', _z(ksb, B, H, device=dev))
     # K-split of the ctx-column input gradient: as many slabs as keep the launch within ONE wave of workgroups (256 CUs)

@@ -27,9 +27,14 @@ class DecoderState:
         self.prenet_act = [e(T, B, P) for _ in range(n_prenet)]
         self.U, self.Mt, self.PL = e(A, ksz), e(B, L, A), e(2, B, L, A)
         self.qpart = e(kq, B, A)
-        self.h_att, self.c_att = z(T + 1, B, H), z(T + 1, B, H)
-        self.h_gen, self.c_gen = z(T + 1, B, H), z(T + 1, B, H)
-        self.ctx, self.cum = z(T + 1, B, Dm), z(T + 1, B, L)
+        # only slot 0 (the initial state) is read before it is written: no need to clear ~1 GB per decode
+        def z0(*s):
+            t = e(*s)
+            t[0].zero_()
+            return t
+        self.h_att, self.c_att = z0(T + 1, B, H), z0(T + 1, B, H)
+        self.h_gen, self.c_gen = z0(T + 1, B, H), z0(T + 1, B, H)
+        self.ctx, self.cum = z0(T + 1, B, Dm), z0(T + 1, B, L)
         self.align = e(T, B, L)
         self.gates_att = e(T, B, 4 * H) if save_gates else None
         self.gates_gen = e(T, B, 4 * H) if save_gates else None
@@ -41,9 +46,10 @@ class DecoderState:
         Bp = (B + 15) & ~15
         use_pack = os.environ.get('MTTS_NO_PACK', '0') != '1'      # debugging / A-B switch: row-major operands only
         hp_ok, dp_ok = use_pack and H % 16 == 0, use_pack and Dm % 16 == 0
-        self.h_att_p = z(T + 1, Bp * H) if hp_ok else None
-        self.h_gen_p = z(T + 1, Bp * H) if hp_ok else None
-        self.ctx_p = z(T + 1, Bp * Dm) if dp_ok else None
+        zp = z0 if Bp == B else z                                  # padded batch rows of the packed copies stay zero
+        self.h_att_p = zp(T + 1, Bp * H) if hp_ok else None
+        self.h_gen_p = zp(T + 1, Bp * H) if hp_ok else None
+        self.ctx_p = zp(T + 1, Bp * Dm) if dp_ok else None
         self.att_w_ctx_p = e(4 * H * Dm) if (dp_ok and H % 4 == 0) else None
         self.att_w_hh_p = e(4 * H * H) if hp_ok else None
         self.gen_w_hh_p = e(4 * H * H) if hp_ok else None
