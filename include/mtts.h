@@ -530,6 +530,11 @@ int mtts_grad_reverse_clamp(const float* g, float* out, long n, float l, float c
 /* Sampling of the dominant step kernel (attention-LSTM skinny GEMM) with HIP events on the launch stream:
  * begin() creates `max_samples` event pairs and samples every `stride`-th decoder step; end() synchronises
  * them and returns the summed duration in ms and the sample count.  Not for use inside timed regions' setup. */
+/* uint8 keep flags (1 = keep) with P(keep) = 1 - p from Philox4x32-10 keyed by `seed`; element i uses counter offset + i/8.
+ * Draws of consecutive calls stay independent when the caller advances `offset` by (n + 7) / 8.  Replaces
+ * `torch.rand(shape) >= p` at every dropout / zoneout site (modules/layers.py:27,37-40,82-86; modules/tacotron2.py:44). */
+int mtts_dropout_keep_mask(uint8_t* out, long n, float p, uint64_t seed, uint64_t offset, void* stream);
+
 int mtts_prof_begin(int max_samples, int stride);
 int mtts_prof_end(float* total_ms, int* count);
 /* summed duration (ms) of the EMPTY event brackets recorded in front of every sample: the cost of an event pair with nothing

@@ -232,3 +232,51 @@ int add3(float* out, int ldo, const float* a, int lda, const float* b, int ldb, 
     MTTS_CHECK_LAUNCH("add3");
     return 0;
 }
+
+
+// ---- dropout keep flags ---------------------------------------------------------------------------------------------------
+// uint8 keep mask (1 = keep) with P(keep) = 1 - p, drawn with Philox4x32-10 (Salmon et al., SC'11; counter = element block,
+// key = seed): one call yields 128 bits = eight 16-bit uniforms = eight flags.  Replaces torch.rand(shape) >= p + cast
+// (write 4 B, read 4 B, write 1 B per element) on the host side of every Dropout / zoneout site (modules/layers.py:27,37-40).
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], const uint32_t (&k)[2]) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0], n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1], n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__global__ void dropout_keep_kernel(uint8_t* __restrict__ out, long n, uint32_t thresh16, uint64_t seed, uint64_t offset) {
+    const long nblk = (n + 7) / 8;
+    for (long blk = (long)blockIdx.x * blockDim.x + threadIdx.x; blk < nblk; blk += (long)gridDim.x * blockDim.x) {
+        const uint64_t ctr = offset + (uint64_t)blk;
+        uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+        uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            philox_round(c, k);
+            k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+        }
+        uint8_t f[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { f[2 * i] = (c[i] & 0xffffu) >= thresh16; f[2 * i + 1] = (c[i] >> 16) >= thresh16; }
+        const long e0 = blk * 8;
+        if (e0 + 8 <= n && (((uintptr_t)(out + e0)) & 7) == 0) {
+            uint64_t w = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w |= (uint64_t)f[i] << (8 * i);
+            *reinterpret_cast<uint64_t*>(out + e0) = w;
+        } else {
+            for (int i = 0; i < 8 && e0 + i < n; ++i) out[e0 + i] = f[i];
+        }
+    }
+}
+
+MTTS_API int mtts_dropout_keep_mask(uint8_t* out, long n, float p, uint64_t seed, uint64_t offset, void* stream) {
+    if (n <= 0) return 0;
+    MTTS_REQUIRE(p >= 0.f && p < 1.f, "dropout probability %f outside [0, 1)", (double)p);
+    const uint32_t thresh = (uint32_t)(p * 65536.0f + 0.5f);      // keep iff u16 >= p * 2^16
+    const long nblk = (n + 7) / 8;
+    int blocks = (int)((nblk + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(dropout_keep_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, n, thresh, seed, offset);
+    MTTS_CHECK_LAUNCH("dropout_keep_kernel");
+    return 0;
+}
