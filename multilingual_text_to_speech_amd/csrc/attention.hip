@@ -15,9 +15,7 @@
 #include "common.h"
 
 constexpr int ATT_THREADS = 512;
-constexpr int NE_MAX = 32;    // PL elements per thread     (L*A      <= NE_MAX * ATT_THREADS)
 constexpr int NC_MAX = 8;     // memory float4 per thread   (ceil(L/ng) <= NC_MAX)
-constexpr int NM_MAX = 8;     // Mt elements per thread     (rows*A   <= NM_MAX * ATT_THREADS)
 constexpr int NU_MAX = 8;     // U elements per thread      (A*ksz    <= NU_MAX * ATT_THREADS)
 constexpr int KQ_MAX = 8;
 

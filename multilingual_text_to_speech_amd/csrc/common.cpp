@@ -42,7 +42,7 @@ static int g_event_next = 0, g_event_count = 0;
 hipStream_t side_stream() {
     if (!g_side) {
         int lo = 0, hi = 0;
-        hipDeviceGetStreamPriorityRange(&lo, &hi);          // lo = least priority
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = 0;          // lo = least priority
         if (hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, lo) != hipSuccess) g_side = nullptr;
     }
     return g_side;
@@ -53,7 +53,7 @@ static hipStream_t g_wgrad = nullptr;
 hipStream_t wgrad_stream() {
     if (!g_wgrad) {
         int lo = 0, hi = 0;
-        hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = 0;
         if (hipStreamCreateWithPriority(&g_wgrad, hipStreamNonBlocking, lo) != hipSuccess) g_wgrad = nullptr;
     }
     return g_wgrad;
@@ -61,8 +61,8 @@ hipStream_t wgrad_stream() {
 
 hipEvent_t pool_event() {
     if (g_event_count < 256) {
-        hipEventCreateWithFlags(&g_events[g_event_count], hipEventDisableTiming);
-        return g_events[g_event_count++];
+        if (hipEventCreateWithFlags(&g_events[g_event_count], hipEventDisableTiming) == hipSuccess) return g_events[g_event_count++];
+        return nullptr;      // hipEventRecord(nullptr) reports the failure to the caller
     }
     hipEvent_t e = g_events[g_event_next];
     g_event_next = (g_event_next + 1) % 256;

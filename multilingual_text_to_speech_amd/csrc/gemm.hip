@@ -506,14 +506,11 @@ MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     static bool attr_done = false;
     if (!attr_done) {   // > 64 KiB of dynamic LDS needs the opt-in attribute
-        hipFuncSetAttribute((const void*)gemm_mfma_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        hipFuncSetAttribute((const void*)gemm_mfma_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        hipFuncSetAttribute((const void*)gemm_mfma_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        hipFuncSetAttribute((const void*)gemm_mfma_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        hipFuncSetAttribute((const void*)gemm_split_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        hipFuncSetAttribute((const void*)gemm_split_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        hipFuncSetAttribute((const void*)gemm_split_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        hipFuncSetAttribute((const void*)gemm_split_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        const void* kernels[8] = {(const void*)gemm_mfma_kernel<false, false>, (const void*)gemm_mfma_kernel<false, true>,
+                                  (const void*)gemm_mfma_kernel<true, false>, (const void*)gemm_mfma_kernel<true, true>,
+                                  (const void*)gemm_split_kernel<false, false>, (const void*)gemm_split_kernel<false, true>,
+                                  (const void*)gemm_split_kernel<true, false>, (const void*)gemm_split_kernel<true, true>};
+        for (const void* k : kernels) MTTS_CHECK_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_done = true;
     }
     float* ws = p.nosplit == 2 ? g_ws_host + g_ws_bytes / 2 / sizeof(float) : g_ws_host;

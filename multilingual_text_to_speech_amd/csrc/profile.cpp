@@ -16,19 +16,19 @@ bool prof_sample(int t, hipStream_t s, int phase) {
     if (!g_prof.on || (t % g_prof.stride) != 0) return false;
     if (phase == 0) {
         if (g_prof.used >= (int)g_prof.e0.size()) return false;
-        hipEventRecord(g_prof.ec[g_prof.used], s);
-        hipEventRecord(g_prof.e0[g_prof.used], s);
+        (void)hipEventRecord(g_prof.ec[g_prof.used], s);
+        (void)hipEventRecord(g_prof.e0[g_prof.used], s);
         return true;
     }
-    hipEventRecord(g_prof.e1[g_prof.used], s);
+    (void)hipEventRecord(g_prof.e1[g_prof.used], s);
     g_prof.used++;
     return true;
 }
 
 MTTS_API int mtts_prof_begin(int max_samples, int stride) {
-    for (auto e : g_prof.ec) hipEventDestroy(e);
-    for (auto e : g_prof.e0) hipEventDestroy(e);
-    for (auto e : g_prof.e1) hipEventDestroy(e);
+    for (auto e : g_prof.ec) (void)hipEventDestroy(e);
+    for (auto e : g_prof.e0) (void)hipEventDestroy(e);
+    for (auto e : g_prof.e1) (void)hipEventDestroy(e);
     g_prof.ec.assign(max_samples, nullptr);
     g_prof.e0.assign(max_samples, nullptr);
     g_prof.e1.assign(max_samples, nullptr);
