@@ -138,3 +138,42 @@ def test_checkpoint_round_trip(tmp_path):
     assert st['epoch'] == 7 and hp.batch_size == 48 and hp.version == 'unit' and crit.v == 3
     assert torch.equal(m2.weight, model.weight + 1)
     reset_defaults()
+
+
+def _reference_language_rows(spec, text_length, languages):
+    """Restatement of the reference's parsing loop (synthesize.py:55-70) used as the expectation."""
+    rows, remaining = [], text_length
+    for token in spec.split(','):
+        parts = token.split('-')
+        row = [0.0] * len(languages)
+        for cw in parts[0].split(':'):
+            name_weight = cw.split('*')
+            row[languages.index(name_weight[0])] = 1.0 if len(name_weight) == 1 else float(name_weight[1])
+        n = int(parts[1]) if len(parts) == 2 else remaining
+        rows += [row] * n
+        remaining -= n
+    return torch.tensor([rows])
+
+
+@pytest.mark.parametrize('spec', ['de', 'de-10,fr-9,de', 'fr*0.75:de*0.25', 'nl-3,fr*0.5:de*0.5-4,de'])
+def test_language_spec_parsing_matches_reference_rules(spec):
+    import synthesize as S
+    langs = ['de', 'fr', 'nl']
+    w = S.language_weights(spec, 30, langs)
+    assert torch.equal(w, _reference_language_rows(spec, 30, langs))
+
+
+def test_synthesize_front_end_tokens_speakers_denormalisation():
+    import synthesize as S
+    reset_defaults()
+    hp.unique_speakers = ['anna', 'bob']
+    assert S.speaker_id('bob') == 1 and S.speaker_id('7') == 7
+    hp.case_sensitive = False
+    ids = S.tokens_of('Ab  c', token_ids=False)
+    assert ids.tolist() == D.to_sequence('ab c') and ids[-1] == 1              # lower-cased, whitespace collapsed, EOS appended
+    assert S.tokens_of('5 6 7', token_ids=True).tolist() == [5, 6, 7, 1]
+    mel = np.ones((hp.num_mels, 3), dtype=np.float32)
+    hp.normalize_spectrogram, hp.mel_normalize_mean, hp.mel_normalize_variance = True, np.full((hp.num_mels, 1), 2.0), np.full((hp.num_mels, 1), 3.0)
+    assert np.allclose(S.denormalize(mel), 5.0)
+    del hp.unique_speakers, hp.mel_normalize_mean, hp.mel_normalize_variance
+    reset_defaults()
