@@ -55,14 +55,14 @@ static int bwd_post(const DecoderArgs& a, const DecoderGradArgs& g, bool prenet_
         MTTS_TRY(gm(g.dG_att, a.h_att, g.d_att_w_hh, 4 * H, H, TB, 4 * H, H, H, true, true, 0.f, s));
     }
     MTTS_TRY(colsum(g.dG_att, g.d_att_b_ih, TB, 4 * H, 4 * H, g.colsum_ws, s));
-    MTTS_TRY(colsum(g.dG_att, g.d_att_b_hh, TB, 4 * H, 4 * H, g.colsum_ws, s));
+    MTTS_CHECK_HIP(hipMemcpyAsync(g.d_att_b_hh, g.d_att_b_ih, (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, s));   // b_ih and b_hh enter the gates identically
     if (!gen_wgrad_done) {
         MTTS_TRY(gm(g.dG_gen, a.h_att + BH, g.d_gen_w_ih, 4 * H, H, TB, 4 * H, H, H + Dm, true, true, 0.f, s));
         MTTS_TRY(gm(g.dG_gen, a.ctx + BD, g.d_gen_w_ih + H, 4 * H, Dm, TB, 4 * H, Dm, H + Dm, true, true, 0.f, s));
         MTTS_TRY(gm(g.dG_gen, a.h_gen, g.d_gen_w_hh, 4 * H, H, TB, 4 * H, H, H, true, true, 0.f, s));
     }
     MTTS_TRY(colsum(g.dG_gen, g.d_gen_b_ih, TB, 4 * H, 4 * H, g.colsum_ws, s));
-    MTTS_TRY(colsum(g.dG_gen, g.d_gen_b_hh, TB, 4 * H, 4 * H, g.colsum_ws, s));
+    MTTS_CHECK_HIP(hipMemcpyAsync(g.d_gen_b_hh, g.d_gen_b_ih, (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, s));
 
     // ---- frame/stop projection and query weights
     if (!att_wgrad_done) {
@@ -449,7 +449,7 @@ MTTS_API int mtts_bilstm_bwd(const BiLstmArgs* fwd, const BiLstmGradArgs* grad, 
         const float* hprev = d == 0 ? a.h[d] : a.h[d] + BH;
         MTTS_TRY(gm(g.dxproj[d], hprev, g.d_w_hh[d], 4 * H, H, L * B, 4 * H, H, H, true, true, 0.f, s));
         MTTS_TRY(colsum(g.dxproj[d], g.d_b_ih[d], L * B, 4 * H, 4 * H, g.colsum_ws, s));
-        MTTS_TRY(colsum(g.dxproj[d], g.d_b_hh[d], L * B, 4 * H, 4 * H, g.colsum_ws, s));
+        MTTS_CHECK_HIP(hipMemcpyAsync(g.d_b_hh[d], g.d_b_ih[d], (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     return 0;
 }
