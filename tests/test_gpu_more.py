@@ -430,3 +430,63 @@ def test_philox_keep_masks_have_the_right_rate_and_do_not_repeat():
     pr2.keep('x', (257, 1031), 0.1, 'cuda'); pr2.keep('x', (257, 1031), 0.5, 'cuda')     # same sequence of calls after reseeding
     assert torch.equal(pr2.keep('x', (4096,), 0.5, 'cuda'), a)
     assert pr.keep('x', (8,), 0.0, 'cuda') is None
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_conv1d_kernels_match_torch_on_random_shapes(seed):
+    """Implicit-GEMM convolution (forward, input gradient, weight gradient) against torch.nn.functional.conv1d in fp64 for random
+    channel counts / kernel sizes / dilations / groups / lengths, including lengths shorter than the receptive field."""
+    from multilingual_text_to_speech_amd import kernels as K
+    g = torch.Generator().manual_seed(100 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    groups = [1, 1, 2, 5][ri(0, 3)]
+    Cg, Og = 4 * ri(1, 40), 4 * ri(1, 40)
+    k, dil = [1, 3, 5, 31][ri(0, 3)], [1, 1, 3, 9][ri(0, 3)]
+    N_, L = ri(1, 5), ri(1, 70)
+    Cin, O = Cg * groups, Og * groups
+    x = torch.randn(N_, L, Cin, generator=g).cuda()
+    w = (torch.randn(O, Cg, k, generator=g) / (Cg * k) ** 0.5).cuda()
+    dy = torch.randn(N_, L, O, generator=g).cuda()
+    wp = K.pack_conv_weight(w)
+    y = K.conv1d_fwd(x, wp, k, dil, groups)
+    dx, dwp = K.conv1d_bwd(x, wp, dy, k, dil, groups)
+    dw = K.unpack_conv_weight(dwp, O, Cg, k)
+    xr = x.double().transpose(1, 2).requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    yr = torch.nn.functional.conv1d(xr, wr, padding=(k - 1) * dil // 2, dilation=dil, groups=groups)
+    yr.backward(dy.double().transpose(1, 2))
+    tol = lambda ref: 2e-5 * max(1.0, ref.abs().max().item())
+    tag = f'groups={groups} Cg={Cg} Og={Og} k={k} dil={dil} N={N_} L={L}'
+    assert (y.double() - yr.transpose(1, 2)).abs().max().item() <= tol(yr), tag
+    assert (dx.double() - xr.grad.transpose(1, 2)).abs().max().item() <= tol(xr.grad), tag
+    assert (dw.double() - wr.grad).abs().max().item() <= tol(wr.grad) * (N_ * L) ** 0.5, tag
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_skinny_gemm_matches_torch_on_random_shapes(seed):
+    """mtts_skinny_gemm (the per-step GEMM of the decoder loop) as a plain multi-segment product out = sum_s x_s W_s^T + bias:
+    random batch sizes (all three row-tile variants, ragged last tile), 1-3 K segments, K split on / off."""
+    import ctypes
+    from multilingual_text_to_speech_amd import _C
+    from multilingual_text_to_speech_amd._C import check, lib, ptr, stream_ptr
+    g = torch.Generator().manual_seed(200 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    B, N, nseg = [1, 7, 16, 23, 40, 64, 100][ri(0, 6)], 4 * ri(1, 80), ri(1, 3)
+    ks = [1, 1, 4][ri(0, 2)]
+    xs = [torch.randn(B, 4 * ri(1, 90), generator=g).cuda() for _ in range(nseg)]
+    ws = [(torch.randn(N, x.shape[1], generator=g) / x.shape[1] ** 0.5).cuda() for x in xs]
+    bias = torch.randn(N, generator=g).cuda()
+    a = _C.SkinnyArgs()
+    a.nseg, a.B, a.N, a.ksplit = nseg, B, N, ks
+    for i, (x, w) in enumerate(zip(xs, ws)):
+        a.seg[i].x, a.seg[i].w, a.seg[i].K, a.seg[i].ldx, a.seg[i].ldw = ptr(x), ptr(w), x.shape[1], x.shape[1], x.shape[1]
+    out = torch.zeros(ks, B, N, device='cuda')
+    a.out, a.ldo = ptr(out), N
+    if ks > 1:
+        a.out_ks = B * N                       # raw partial slabs, summed by the consumer
+    else:
+        a.bias = ptr(bias)
+    check(lib().mtts_skinny_gemm(ctypes.byref(a), stream_ptr()), 'mtts_skinny_gemm')
+    ref = sum(x.double() @ w.double().t() for x, w in zip(xs, ws))
+    got = out.double().sum(0) if ks > 1 else out[0].double() - bias.double()
+    assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()), (B, N, [x.shape[1] for x in xs], ks)
