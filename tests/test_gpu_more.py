@@ -51,18 +51,22 @@ def _random_batch(hp, B, L, T, seed=5, ragged=True):
     return text, tl, target, tgl, spk, lang
 
 
-@pytest.mark.parametrize('preset,B,L,T', [('shared_training', 4, 24, 10), ('generated_switching', 10, 24, 10),
-                                          ('shared_training', 1, 1, 1),        # one token, one frame, one sample
-                                          ('shared_training', 17, 33, 2),      # odd batch (two 16-row MFMA tiles, one nearly empty)
-                                          ('generated_switching', 5, 2, 3)])   # inputs shorter than every convolution kernel
-def test_hip_matches_oracle_at_real_widths(preset, B, L, T):
+@pytest.mark.parametrize('preset,B,L,T,over', [
+    ('shared_training', 4, 24, 10, {}), ('generated_switching', 10, 24, 10, {}),
+    ('shared_training', 1, 1, 1, {}),                                # one token, one frame, one sample
+    ('shared_training', 17, 33, 2, {}),                              # odd batch (two 16-row MFMA tiles, one nearly empty)
+    ('generated_switching', 5, 2, 3, {}),                            # inputs shorter than every convolution kernel
+    ('shared_training', 3, 150, 3, {'attention_dimension': 64}),     # long input + narrow attention: <G=16, NE4=16, NMT=4> kernel
+    ('shared_training', 2, 201, 2, {}),                              # synthesis-length input through the training path
+    ('shared_training', 2, 40, 3, {'attention_dimension': 96, 'attention_kernel_size': 15})])   # generic attention kernels
+def test_hip_matches_oracle_at_real_widths(preset, B, L, T, over):
     """Real layer widths (512/1024/...), small batch and lengths so the CPU oracle finishes in seconds; eval mode with the
     prenet dropout (always on) injected; BN running stats randomised so eval-mode activations stay bounded.  The tiny
     cases are the degenerate ends of the shape range (single token / frame / sample, ragged odd batches)."""
     from multilingual_text_to_speech_amd.params import presets, Params as hp
     from multilingual_text_to_speech_amd.modules.tacotron2 import Tacotron
     from multilingual_text_to_speech_amd.masks import provider
-    presets.apply(preset, speaker_number=7)
+    presets.apply(preset, speaker_number=7, **over)
     torch.manual_seed(0)
     model = Tacotron()
     g = torch.Generator().manual_seed(11)
@@ -131,18 +135,21 @@ def test_full_size_properties_and_schedule_equivalence():
         assert (a - b).abs().max().item() <= 2e-4
 
 
-@pytest.mark.parametrize('preset,B', [('shared_training', 4), ('generated_switching', 5)])
-def test_train_step_gradients_match_oracle_at_real_widths(preset, B):
+@pytest.mark.parametrize('preset,B,L,T,over', [
+    ('shared_training', 4, 20, 9, {}), ('generated_switching', 5, 20, 9, {}),
+    ('shared_training', 3, 150, 3, {'attention_dimension': 64}),     # long input, narrow attention (other template instances)
+    ('shared_training', 2, 40, 3, {'attention_dimension': 96, 'attention_kernel_size': 15}),     # generic attention kernels
+    ('shared_training', 2, 5, 2, {})])                               # tiny sizes through the full backward (BatchNorm over 10 rows)
+def test_train_step_gradients_match_oracle_at_real_widths(preset, B, L, T, over):
     """Full train step (loss + backward) at the real layer widths against the CPU oracle's autograd: exercises the
     MFMA attention kernels, the packed-operand step kernels and the two-stream schedules that the small fixtures bypass."""
     from multilingual_text_to_speech_amd.params import presets, Params as hp
     from multilingual_text_to_speech_amd.modules.tacotron2 import Tacotron, TacotronLoss
     from multilingual_text_to_speech_amd.masks import provider
-    presets.apply(preset, speaker_number=7)
+    presets.apply(preset, speaker_number=7, **over)
     torch.manual_seed(1)
     model = Tacotron().train()
-    L, T = 20, 9
-    text, tl, target, tgl, spk, lang = _random_batch(hp, B, L, T, seed=9)
+    text, tl, target, tgl, spk, lang = _random_batch(hp, B, L, T, seed=9, ragged=L >= 4)
     stop_t = torch.zeros(B, T)
     for b in range(B):
         stop_t[b, max(int(tgl[b]) - hp.stop_frames, 0):] = 1.0
