@@ -36,11 +36,12 @@ class Postnet(Module):
 
     def __init__(self, input_dimension, postnet_dimension, num_blocks, kernel_size, dropout):
         super().__init__()
-        assert num_blocks > 1, 'There must be at least two convolutional blocks in the post-net.'
-        self._convs = Sequential(
-            ConvBlock(input_dimension, postnet_dimension, kernel_size, dropout, 'tanh'),
-            *[ConvBlock(postnet_dimension, postnet_dimension, kernel_size, dropout, 'tanh') for _ in range(num_blocks - 2)],
-            ConvBlock(postnet_dimension, input_dimension, kernel_size, dropout, 'identity'))
+        if num_blocks < 2:
+            raise AssertionError('the post-net needs an input block and an output block at least')
+        widths = [input_dimension] + [postnet_dimension] * (num_blocks - 1) + [input_dimension]
+        blocks = [ConvBlock(widths[i], widths[i + 1], kernel_size, dropout, 'tanh' if i < num_blocks - 1 else 'identity')
+                  for i in range(num_blocks)]
+        self._convs = Sequential(*blocks)
 
     def forward(self, x, x_lengths=None):
         """x [B, T, M] channel-last -> [B, T, M]."""
@@ -56,25 +57,24 @@ class Decoder(Module):
     def __init__(self, output_dim, decoder_dim, attention, generator_rnn, attention_rnn, context_dim, prenet, prenet_dim,
                  max_frames):
         super().__init__()
-        self._prenet = prenet
-        self._attention = attention
-        self._output_dim = output_dim
-        self._decoder_dim = decoder_dim
-        self._max_frames = max_frames
-        self._attention_lstm = attention_rnn
-        self._generator_lstm = generator_rnn
-        self._frame_prediction = Linear(context_dim + decoder_dim, output_dim)
-        self._stop_prediction = Linear(context_dim + decoder_dim, 1)
-        self._speaker_embedding, self._language_embedding = None, None
-        if hp.multi_speaker and hp.speaker_embedding_dimension > 0:
-            self._speaker_embedding = self._get_embedding(hp.speaker_embedding_dimension, hp.speaker_number)
-        if hp.multi_language and hp.language_embedding_dimension > 0:
-            self._language_embedding = self._get_embedding(hp.language_embedding_dimension, len(hp.languages))
+        self._output_dim, self._decoder_dim, self._max_frames = output_dim, decoder_dim, max_frames
+        # sub-module registration order = the reference's state_dict order
+        self._prenet, self._attention = prenet, attention
+        self._attention_lstm, self._generator_lstm = attention_rnn, generator_rnn
+        projection_in = context_dim + decoder_dim                      # cat(h_gen, context)
+        self._frame_prediction = Linear(projection_in, output_dim)
+        self._stop_prediction = Linear(projection_in, 1)
+        # rows appended to every memory position (tacotron2.py:143-146): one table per conditioning signal that is switched on
+        self._speaker_embedding = self._get_embedding(hp.speaker_embedding_dimension, hp.speaker_number) \
+            if hp.multi_speaker and hp.speaker_embedding_dimension > 0 else None
+        self._language_embedding = self._get_embedding(hp.language_embedding_dimension, len(hp.languages)) \
+            if hp.multi_language and hp.language_embedding_dimension > 0 else None
 
-    def _get_embedding(self, embedding_dimension, size=None):
-        embedding = Embedding(size, embedding_dimension)
-        torch.nn.init.xavier_uniform_(embedding.weight)
-        return embedding
+    @staticmethod
+    def _get_embedding(embedding_dimension, size=None):
+        table = Embedding(size, embedding_dimension)
+        torch.nn.init.xavier_uniform_(table.weight)
+        return table
 
     def _memory(self, encoded_input, speaker, language):
         """Concatenate speaker / language embedding rows to the encoder output (tacotron2.py:143-146,158-161)."""
@@ -142,39 +142,38 @@ class Tacotron(Module):
         if hp.reversal_classifier:
             self._reversal_classifier = self._get_adversarial_classifier(hp.reversal_classifier_type)
         self._prenet = Prenet(hp.num_mels, hp.prenet_dimension, hp.prenet_layers, hp.dropout)
-        decoder_input_dimension = hp.encoder_dimension
-        if hp.multi_speaker:
-            decoder_input_dimension += hp.speaker_embedding_dimension
-        if hp.multi_language:
-            decoder_input_dimension += hp.language_embedding_dimension
-        self._attention = self._get_attention(hp.attention_type, decoder_input_dimension)
-        gen_cell_dimension = decoder_input_dimension + hp.decoder_dimension
-        att_cell_dimension = decoder_input_dimension + hp.prenet_dimension
-        if hp.decoder_regularization == 'zoneout':
-            generator_rnn = ZoneoutLSTMCell(gen_cell_dimension, hp.decoder_dimension, hp.zoneout_hidden, hp.zoneout_cell)
-            attention_rnn = ZoneoutLSTMCell(att_cell_dimension, hp.decoder_dimension, hp.zoneout_hidden, hp.zoneout_cell)
-        else:
-            generator_rnn = DropoutLSTMCell(gen_cell_dimension, hp.decoder_dimension, hp.dropout_hidden)
-            attention_rnn = DropoutLSTMCell(att_cell_dimension, hp.decoder_dimension, hp.dropout_hidden)
-        self._decoder = Decoder(hp.num_mels, hp.decoder_dimension, self._attention, generator_rnn, attention_rnn,
-                                decoder_input_dimension, self._prenet, hp.prenet_dimension, hp.max_output_length)
+        # memory width Dm = encoder output + the embedding rows the decoder appends per position
+        memory_dim = hp.encoder_dimension + (hp.speaker_embedding_dimension if hp.multi_speaker else 0) + \
+            (hp.language_embedding_dimension if hp.multi_language else 0)
+        self._attention = self._get_attention(hp.attention_type, memory_dim)
+        H = hp.decoder_dimension
+
+        def cell(input_dim):       # the generator cell is created first, like the reference (parameter-initialisation order)
+            if hp.decoder_regularization == 'zoneout':
+                return ZoneoutLSTMCell(input_dim, H, hp.zoneout_hidden, hp.zoneout_cell)
+            return DropoutLSTMCell(input_dim, H, hp.dropout_hidden)
+        generator_rnn = cell(memory_dim + H)                      # input = [h_att, context]
+        attention_rnn = cell(memory_dim + hp.prenet_dimension)     # input = [prenet(frame), context]
+        self._decoder = Decoder(hp.num_mels, H, self._attention, generator_rnn, attention_rnn, memory_dim, self._prenet,
+                                hp.prenet_dimension, hp.max_output_length)
         self._postnet = self._get_postnet("cbhg" if hp.predict_linear else "conv")
 
     def _get_encoder(self, name):
-        args = (hp.embedding_dimension, hp.encoder_dimension, hp.encoder_blocks, hp.encoder_kernel_size, hp.dropout)
-        ln = 1 if not hp.multi_language else hp.language_number
-        if name == "simple":
-            return Encoder(*args)
-        elif name == "separate":
-            return MultiEncoder(hp.language_number, args)
-        elif name == "shared":
-            return ConditionalEncoder(hp.language_number, hp.input_language_embedding, args)
-        elif name == "convolutional":
-            return ConvolutionalEncoder(hp.embedding_dimension, hp.encoder_dimension, 0.05, ln)
-        elif name == "generated":
-            return GeneratedConvolutionalEncoder(hp.embedding_dimension, hp.encoder_dimension, 0.05, hp.generator_dim,
-                                                 hp.generator_bottleneck_dim, groups=ln)
-        raise ValueError(f'unknown encoder_type {name!r}')
+        """hp.encoder_type -> encoder (tacotron2.py:300-317).  The conv-stack encoders share one argument tuple; the grouped
+        ones get one group per language."""
+        stack = (hp.embedding_dimension, hp.encoder_dimension, hp.encoder_blocks, hp.encoder_kernel_size, hp.dropout)
+        n_groups = hp.language_number if hp.multi_language else 1
+        builders = {
+            'simple': lambda: Encoder(*stack),
+            'separate': lambda: MultiEncoder(hp.language_number, stack),
+            'shared': lambda: ConditionalEncoder(hp.language_number, hp.input_language_embedding, stack),
+            'convolutional': lambda: ConvolutionalEncoder(hp.embedding_dimension, hp.encoder_dimension, 0.05, n_groups),
+            'generated': lambda: GeneratedConvolutionalEncoder(hp.embedding_dimension, hp.encoder_dimension, 0.05, hp.generator_dim,
+                                                               hp.generator_bottleneck_dim, groups=n_groups),
+        }
+        if name not in builders:
+            raise ValueError(f'unknown encoder_type {name!r}')
+        return builders[name]()
 
     def _get_adversarial_classifier(self, name):
         if name == "reversal":
@@ -193,11 +192,14 @@ class Tacotron(Module):
             return Postnet(hp.num_mels, hp.postnet_dimension, hp.postnet_blocks, hp.postnet_kernel_size, hp.dropout)
         raise NotImplementedError('predict_linear=True (CBHG post-net) is outside the MI355X hot path')
 
+    @staticmethod
+    def _per_position(ids, length):
+        """One id per utterance [B] -> the same id at every input position [B, L]; other ranks pass through."""
+        return ids.unsqueeze(1).expand(-1, length) if ids is not None and ids.dim() == 1 else ids
+
     def forward(self, text, text_length, target, target_length, speakers, languages, teacher_forcing_ratio=0.0):
-        if speakers is not None and speakers.dim() == 1:
-            speakers = speakers.unsqueeze(1).expand((-1, text.size(1)))
-        if languages is not None and languages.dim() == 1:
-            languages = languages.unsqueeze(1).expand((-1, text.size(1)))
+        speakers = self._per_position(speakers, text.size(1))
+        languages = self._per_position(languages, text.size(1))
 
         embedded = K.embedding(self._embedding.weight, text, padding_idx=0)
         encoded = self._encoder(embedded, text_length, languages)
@@ -221,10 +223,8 @@ class Tacotron(Module):
     def inference(self, text, speaker=None, language=None):
         """Batch-1 synthesis with the reference's semantics (mutates `text` in place like tacotron2.py:389)."""
         text.unsqueeze_(0)
-        if speaker is not None and speaker.dim() == 1:
-            speaker = speaker.unsqueeze(1).expand((-1, text.size(1)))
-        if language is not None and language.dim() == 1:
-            language = language.unsqueeze(1).expand((-1, text.size(1)))
+        speaker = self._per_position(speaker, text.size(1))
+        language = self._per_position(language, text.size(1))
         with torch.no_grad():
             embedded = K.embedding(self._embedding.weight, text, padding_idx=0)
             encoded = self._encoder(embedded, torch.LongTensor([text.size(1)]), language)
