@@ -57,7 +57,8 @@ def main():
     hp.language_number = len(hp.languages) if hp.multi_language else 0
     device = torch.device('cuda', local)
     model = Tacotron().to(device).train()
-    opt = torch.optim.Adam(model.parameters(), lr=hp.learning_rate, weight_decay=hp.weight_decay)
+    from multilingual_text_to_speech_amd.optim import FusedAdam     # torch.optim.Adam's state_dict, one fused clip+update launch set
+    opt = FusedAdam(model.parameters(), lr=hp.learning_rate, weight_decay=hp.weight_decay)
     crit = TacotronLoss(hp.guided_attention_steps, hp.guided_attention_toleration, hp.guided_attention_gain)
     epoch0 = 0
     if state is not None:
