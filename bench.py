@@ -156,7 +156,7 @@ def main():
     crit = TacotronLoss(hp.guided_attention_steps, hp.guided_attention_toleration, hp.guided_attention_gain)
     from multilingual_text_to_speech_amd.optim import FusedAdam
     opt = FusedAdam(model.parameters(), lr=hp.learning_rate, weight_decay=hp.weight_decay)
-    buckets = D.GradientBuckets(model.parameters(), overlap=True) if world > 1 else None
+    buckets = D.GradientBuckets(model.parameters(), overlap=os.environ.get('MTTS_DDP_OVERLAP', '1') != '0') if world > 1 else None
     batch = synthetic_batch(hp, B, L, T, device, seed=1 + rank)
 
     def barrier():

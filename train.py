@@ -69,7 +69,7 @@ def main():
         crit.load_state_dict(state['criterion'])
         epoch0 = state['epoch'] + 1
     D.broadcast_parameters(model)
-    buckets = D.GradientBuckets(model.parameters(), overlap=True) if world > 1 else None
+    buckets = D.GradientBuckets(model.parameters(), overlap=os.environ.get('MTTS_DDP_OVERLAP', '1') != '0') if world > 1 else None
     G = hp.language_number if hp.encoder_type in ('generated', 'convolutional') else 1
     per = hp.batch_size // world
     D.shard_bounds(per * world, rank, world, G)
