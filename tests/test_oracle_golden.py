@@ -1,5 +1,7 @@
 """Pin the CPU oracle against fixtures recorded from the reference implementation itself
 (oracle/make_golden.py).  CPU only."""
+import os
+
 import pytest
 import torch
 
@@ -54,3 +56,31 @@ def test_inference_matches_reference(name):
                             max_frames=fx['n_frames'], stop_rule=True)
     post = O.postnet(sd, cfg, frames.transpose(1, 2), None, False)
     torch.testing.assert_close(post[0], fx['inference_output'], atol=TOL, rtol=1e-4)
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference'), reason='the reference checkout only exists in the build container')
+@pytest.mark.parametrize('name', ['simple_train', 'generated_train'])
+def test_committed_fixture_is_what_the_reference_produces(name, tmp_path):
+    """Re-run oracle/make_golden.py (which imports and EXECUTES /root/reference) for one configuration and compare every tensor with
+    the committed fixture: the golden vectors are the reference's own outputs, reproducibly."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'oracle', 'make_golden.py'), '--out', str(tmp_path), '--only', name],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    new = torch.load(tmp_path / f'{name}.pt', weights_only=False)
+    old = load_golden(name)
+
+    def same(a, b, path):
+        if isinstance(a, torch.Tensor):
+            assert a.shape == b.shape and torch.allclose(a.float(), b.float(), rtol=1e-5, atol=1e-6), path
+        elif isinstance(a, dict):
+            assert set(a) == set(b), path
+            for k in a:
+                same(a[k], b[k], f'{path}/{k}')
+        elif isinstance(a, (list, tuple)):
+            assert len(a) == len(b), path
+            for i, (u, v) in enumerate(zip(a, b)):
+                same(u, v, f'{path}[{i}]')
+    same(old, new, name)
