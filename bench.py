@@ -44,13 +44,13 @@ def synthetic_batch(hp, B, L, T, device, seed=1):
     return {k: (v.to(device) if torch.is_tensor(v) and k not in ('text_length', 'target_length') else v) for k, v in batch.items()}
 
 
-def train_step(model, crit, opt, buckets, batch, hp):
+def train_step(model, crit, opt, buckets, batch, hp, teacher_forcing=1.0):
     if buckets is not None and buckets.overlap:
         buckets.zero_grad()              # gradients are views into the all-reduce buckets
     else:
         opt.zero_grad(set_to_none=True)
     post, pre, stop, align, spk, enc = model(batch['text'], batch['text_length'], batch['target'], batch['target_length'],
-                                             batch['speakers'], batch['languages'], 1.0)
+                                             batch['speakers'], batch['languages'], teacher_forcing)
     dev = post.device
     loss, _ = crit(batch['text_length'].to(dev), batch['target_length'].to(dev), pre, batch['target'], post, batch['target'],
                    stop, batch['stop'], align, batch['speakers'], spk, enc, None)

@@ -68,8 +68,12 @@ typedef struct GemmArgs {
 } GemmArgs;
 
 int mtts_gemm_ex(const GemmArgs* args, void* stream);
-/* Scratch arena for split-K partial tiles, provided by the caller (the library never allocates); NULL disables split-K. */
+/* Scratch arena for split-K partial tiles, provided by the caller (the library never allocates); NULL disables split-K.
+ * mtts_set_workspace binds the arena to the CURRENT device (default for all of its streams); mtts_set_stream_workspace
+ * gives one caller stream its own arena, which is what makes concurrent callers on different streams of one device
+ * independent: helper streams, ordering events and scratch are all looked up by (device, caller stream). */
 int mtts_set_workspace(void* ptr, size_t bytes);
+int mtts_set_stream_workspace(void* stream, void* ptr, size_t bytes);
 int mtts_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
               int transA, int transB, float alpha, float beta, const float* bias, int act, void* stream);
 
@@ -484,7 +488,7 @@ typedef struct TacoLossArgs {
 int mtts_tacotron_loss(const TacoLossArgs* args, void* stream);
 
 /* mtts_clip_adam_step: torch.nn.utils.clip_grad_norm_(params, max_norm) followed by torch.optim.Adam.step() with L2-coupled
- * weight decay (train.py:84-85,260).  ptrs: device array of 4 pointers per tensor {param, grad, exp_avg, exp_avg_sq};
+ * weight decay (train.py:84-85,260-270).  ptrs: device array of 4 pointers per tensor {param, grad, exp_avg, exp_avg_sq};
  * chunks partition every tensor into blocks of work. */
 typedef struct AdamArgs {
     const int64_t* ptrs;
@@ -501,16 +505,23 @@ typedef struct AdamArgs {
     float eps;
     float step_size;           /* lr / (1 - beta1^t) */
     float inv_sqrt_bc2;        /* 1 / sqrt(1 - beta2^t) */
+    int phase;                 /* 0: norm + update over this table; 1: only the global gradient norm / clip coefficient into norm_out
+                                  (table = ALL parameters); 2: only the update, with the clip coefficient already in norm_out[1]
+                                  (table = one parameter group / bias-correction step: train.py:261-270 trains the encoder with
+                                  its own learning rate while clip_grad_norm_ still spans every parameter) */
 } AdamArgs;
 
 int mtts_clip_adam_step(const AdamArgs* args, void* stream);
 
 /* ---- small data-movement kernels --------------------------------------------------------------------------- */
-/* Embedding lookup (modules/tacotron2.py:363, :122 speaker/language tables): out[r, col0:col0+D] = table[ids[r]] */
-int mtts_embedding_fwd(const float* table, const int64_t* ids, float* out, int rows, int D, int ldo, int col0, void* stream);
-/* dtable[ids[r]] += dout[r, col0:col0+D]; rows with ids == padding_idx are skipped (padding_idx < 0: none) */
+/* Embedding lookup (modules/tacotron2.py:363, :122 speaker/language tables): out[r, col0:col0+D] = table[ids[r]].
+ * `vocab` = rows of the table.  An id outside [0, vocab) reads as a zero row, never touches memory and sets *err (device int,
+ * nullable) to 1; the caller checks it when it next synchronises (torch.nn.Embedding device-asserts in that case). */
+int mtts_embedding_fwd(const float* table, const int64_t* ids, float* out, int rows, int D, int ldo, int col0, long vocab,
+                       int* err, void* stream);
+/* dtable[ids[r]] += dout[r, col0:col0+D]; rows with ids == padding_idx (padding_idx < 0: none) or outside [0, vocab) are skipped */
 int mtts_embedding_bwd(const float* dout, const int64_t* ids, float* dtable, int rows, int D, int ldo, int col0,
-                       int padding_idx, void* stream);
+                       int padding_idx, long vocab, void* stream);
 /* out[r*ldo + c] = in[r*ldi + c] for c < cols (strided 2-D copy, used for concatenations) */
 int mtts_copy2d(const float* in, float* out, int rows, int cols, int ldi, int ldo, void* stream);
 /* [O, I, k] <-> [O, k, I] weight repack for the implicit-GEMM convolution (to_packed != 0: torch layout -> packed) */

@@ -1,6 +1,7 @@
 // Error plumbing + version for libmtts_hip.
 #include "common.h"
 #include <stdarg.h>
+#include <stdlib.h>
 
 thread_local char g_mtts_err[512] = {0};
 
@@ -34,37 +35,115 @@ MTTS_API int mtts_sizeof_struct(int which) {
     }
 }
 
-// ---- side stream + event pool for the two-chain decoder schedules (created once; streams/events are not memory) ----
-static hipStream_t g_side = nullptr;
-static hipEvent_t g_events[256];
-static int g_event_next = 0, g_event_count = 0;
+// ---- per-(device, caller stream) library state ----------------------------------------------------------------------
+// The two-chain decoder schedules need helper streams, ordering events and a split-K scratch arena.  All of it hangs off
+// the (device, stream) the caller passed in, so that two models / threads driving different streams (or devices) of one
+// process never share a helper stream, an event or scratch memory.  Streams and events are created on first use and
+// kept for the life of the process (they are not memory); the scratch arena is always provided by the caller.
+#include <mutex>
+#include <vector>
 
-hipStream_t side_stream() {
-    if (!g_side) {
-        int lo = 0, hi = 0;
-        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = 0;          // lo = least priority
-        if (hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, lo) != hipSuccess) g_side = nullptr;
-    }
-    return g_side;
+namespace {
+struct StreamCtx {
+    int device = 0;
+    hipStream_t owner = nullptr;
+    hipStream_t side = nullptr, wgrad = nullptr;
+    std::vector<hipEvent_t> events;      // ring, grown when its oldest event has not completed yet
+    size_t next = 0;
+    float* ws = nullptr;                 // per-stream override of the device default (mtts_set_stream_workspace)
+    size_t ws_bytes = 0;
+};
+struct DeviceWs { int device; float* ptr; size_t bytes; };
+std::mutex g_mu;
+std::vector<StreamCtx*> g_ctx;
+std::vector<DeviceWs> g_dev_ws;
+
+int current_device() { int d = 0; if (hipGetDevice(&d) != hipSuccess) d = 0; return d; }
+
+// caller must hold g_mu.  A helper stream resolves to the context of the stream it was created for.
+StreamCtx* ctx_locked(hipStream_t s) {
+    const int dev = current_device();
+    for (StreamCtx* c : g_ctx)
+        if (c->device == dev && (c->owner == s || (s && (c->side == s || c->wgrad == s)))) return c;
+    StreamCtx* c = new StreamCtx();
+    c->device = dev; c->owner = s;
+    g_ctx.push_back(c);
+    return c;
+}
+
+hipStream_t low_priority_stream() {
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = 0;          // lo = least priority
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, lo) != hipSuccess) st = nullptr;
+    return st;
+}
+}  // namespace
+
+// low-priority helper stream of caller stream `s`: generator-LSTM chain / reverse BiLSTM direction
+hipStream_t side_stream(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    StreamCtx* c = ctx_locked(s);
+    if (!c->side) c->side = low_priority_stream();
+    return c->side;
 }
 
 // second helper stream (least priority): weight-gradient GEMMs of finished chunks, off both decoder chains
-static hipStream_t g_wgrad = nullptr;
-hipStream_t wgrad_stream() {
-    if (!g_wgrad) {
-        int lo = 0, hi = 0;
-        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = 0;
-        if (hipStreamCreateWithPriority(&g_wgrad, hipStreamNonBlocking, lo) != hipSuccess) g_wgrad = nullptr;
-    }
-    return g_wgrad;
+hipStream_t wgrad_stream(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    StreamCtx* c = ctx_locked(s);
+    if (!c->wgrad) c->wgrad = low_priority_stream();
+    return c->wgrad;
 }
 
-hipEvent_t pool_event() {
-    if (g_event_count < 256) {
-        if (hipEventCreateWithFlags(&g_events[g_event_count], hipEventDisableTiming) == hipSuccess) return g_events[g_event_count++];
-        return nullptr;      // hipEventRecord(nullptr) reports the failure to the caller
+// Steps per chunk of the two-chain decoder schedules (chain hand-off, weight-gradient accumulation granularity).
+// MTTS_CHUNK overrides the default of 48 (read per call: tests run the small fixtures with tiny chunks).
+int decoder_chunk() {
+    const char* e = getenv("MTTS_CHUNK");
+    if (e && e[0]) { const int v = atoi(e); if (v >= 1 && v <= 4096) return v; }
+    return 48;
+}
+
+// An ordering event from the ring of caller stream `s`.  An event is only handed out again once it has completed
+// (hipEventQuery); otherwise the ring grows, so a long decode with tiny chunks can never re-record a pending event.
+hipEvent_t pool_event(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    StreamCtx* c = ctx_locked(s);
+    if (c->events.size() >= 64) {
+        hipEvent_t e = c->events[c->next];
+        if (hipEventQuery(e) == hipSuccess) { c->next = (c->next + 1) % c->events.size(); return e; }
+        (void)hipGetLastError();      // hipErrorNotReady is sticky in hipGetLastError
     }
-    hipEvent_t e = g_events[g_event_next];
-    g_event_next = (g_event_next + 1) % 256;
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;   // hipEventRecord(nullptr) reports it
+    c->events.insert(c->events.begin() + c->next, e);
+    c->next = (c->next + 1) % c->events.size();
     return e;
+}
+
+// Split-K scratch arena visible to launches on `s` (a helper stream sees its owner's arena).
+float* workspace_for(hipStream_t s, size_t* bytes) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    StreamCtx* c = ctx_locked(s);
+    if (c->ws) { *bytes = c->ws_bytes; return c->ws; }
+    for (const DeviceWs& d : g_dev_ws)
+        if (d.device == c->device) { *bytes = d.bytes; return d.ptr; }
+    *bytes = 0;
+    return nullptr;
+}
+
+MTTS_API int mtts_set_workspace(void* ptr, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    const int dev = current_device();
+    for (DeviceWs& d : g_dev_ws)
+        if (d.device == dev) { d.ptr = (float*)ptr; d.bytes = bytes; return 0; }
+    g_dev_ws.push_back(DeviceWs{dev, (float*)ptr, bytes});
+    return 0;
+}
+
+MTTS_API int mtts_set_stream_workspace(void* stream, void* ptr, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    StreamCtx* c = ctx_locked((hipStream_t)stream);
+    c->ws = (float*)ptr; c->ws_bytes = bytes;
+    return 0;
 }

@@ -82,9 +82,12 @@ int transpose2d_ld(const float* in, float* out, int rows, int cols, int ldi, int
 int colsum(const float* x, float* out, int rows, int cols, int ld, float* ws, hipStream_t s);
 int relu_mask_bwd(const float* dy, const float* y, float* dz, long n, float scale, hipStream_t s);
 bool prof_sample(int t, hipStream_t s, int phase);
-hipStream_t side_stream();
-hipStream_t wgrad_stream();
-hipEvent_t pool_event();
+// per-(device, caller stream) helper streams, ordering events and split-K scratch (common.cpp)
+hipStream_t side_stream(hipStream_t s);
+hipStream_t wgrad_stream(hipStream_t s);
+hipEvent_t pool_event(hipStream_t s);
+float* workspace_for(hipStream_t s, size_t* bytes);
+int decoder_chunk();
 
 // ---- DPP (no LDS traffic) reductions inside 16-lane rows, then across rows -----------------------------------
 template <int CTRL>

@@ -118,8 +118,8 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
     }
 
     // fast schedule: chain B trails chain A chunk by chunk on the side stream
-    const int CH = 48;
-    hipStream_t sb = a.fast ? side_stream() : nullptr;
+    const int CH = decoder_chunk();
+    hipStream_t sb = a.fast ? side_stream(s) : nullptr;
     if (a.fast && !sb) return mtts_fail("decoder: cannot create the side stream");
     for (int t = a.t0; t < a.t1; ++t) {
         const bool teach = a.frames_in && a.teacher && a.teacher[t];
@@ -206,14 +206,14 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
         }
         if (a.fast && (((t + 1 - a.t0) % CH) == 0 || t + 1 == a.t1)) {
             const int c1 = t + 1, c0 = a.t0 + ((c1 - a.t0 - 1) / CH) * CH;
-            hipEvent_t ev = pool_event();
+            hipEvent_t ev = pool_event(s);
             MTTS_CHECK_HIP(hipEventRecord(ev, s));
             MTTS_CHECK_HIP(hipStreamWaitEvent(sb, ev, 0));
             MTTS_TRY(gen_chunk(a, c0, c1, sb));
         }
     }
     if (a.fast) {     // join: the caller's stream continues after chain B
-        hipEvent_t ev = pool_event();
+        hipEvent_t ev = pool_event(s);
         MTTS_CHECK_HIP(hipEventRecord(ev, sb));
         MTTS_CHECK_HIP(hipStreamWaitEvent(s, ev, 0));
         return 0;
@@ -232,9 +232,9 @@ MTTS_API int mtts_bilstm_fwd(const BiLstmArgs* args, void* stream) {
     MTTS_REQUIRE((H & 3) == 0 && (a.Cin & 3) == 0, "bilstm: H and Cin must be multiples of 4");
     const long BH = (long)B * H;
     // the two directions are independent (disjoint state, gate and output-column arrays): the reverse one runs on the side stream
-    hipStream_t sd[2] = {s, side_stream()};
+    hipStream_t sd[2] = {s, side_stream(s)};
     if (!sd[1]) return mtts_fail("bilstm: cannot create the side stream");
-    hipEvent_t ev_fork = pool_event(), ev_join = pool_event();
+    hipEvent_t ev_fork = pool_event(s), ev_join = pool_event(s);
     MTTS_CHECK_HIP(hipEventRecord(ev_fork, s));
     MTTS_CHECK_HIP(hipStreamWaitEvent(sd[1], ev_fork, 0));
     for (int d = 1; d >= 0; --d) {

@@ -237,11 +237,11 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
 
     // ---- chain B (generator LSTM, side stream) runs AHEAD of chain A (attention + attention LSTM, caller's stream),
     //      chunk by chunk from the last step backwards; per chunk: recurrence -> batched input gradients -> event.
-    const int CH = 48;
-    hipStream_t sb = side_stream();
+    const int CH = decoder_chunk();
+    hipStream_t sb = side_stream(s);
     if (!sb) return mtts_fail("decoder backward: cannot create the side stream");
     {
-        hipEvent_t ev = pool_event();
+        hipEvent_t ev = pool_event(s);
         MTTS_CHECK_HIP(hipEventRecord(ev, s));
         MTTS_CHECK_HIP(hipStreamWaitEvent(sb, ev, 0));
     }
@@ -250,7 +250,7 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
     // ---- weight gradients ride a third, least-priority stream: every chunk's dG^T x product is queued as soon as its chain
     //      has produced the chunk's dG, and accumulates (beta = 1) into the gradient; one workgroup per CU (nosplit) so that
     //      the step kernels of both chains always find room.  The frame-projection gradient needs no chain at all.
-    hipStream_t sw = wgrad_stream();
+    hipStream_t sw = wgrad_stream(s);
     if (!sw) return mtts_fail("decoder backward: cannot create the weight-gradient stream");
     auto wgrad = [&](const float* dY, int ldy, int Mw, const float* X, int ldx, int Nw, float* dW, int ldw, int rows, float beta) -> int {
         GemmArgs q; memset(&q, 0, sizeof(q));
@@ -259,7 +259,7 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
         return mtts_gemm_ex(&q, sw);
     };
     {
-        hipEvent_t ev = pool_event();
+        hipEvent_t ev = pool_event(s);
         MTTS_CHECK_HIP(hipEventRecord(ev, s));
         MTTS_CHECK_HIP(hipStreamWaitEvent(sw, ev, 0));
         MTTS_TRY(wgrad(dout1, Mo, M + 1, a.h_gen + BH, H, H, g.d_w_out, H + Dm, TB, 0.f));
@@ -298,7 +298,7 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
         MTTS_TRY(mtts_gemm_ex(&q, sb));
         q.B = a.gen_w_ih + H; q.C = g.dctx_all + (c0 + 1) * BD; q.N = Dm; q.ldc = Dm; q.beta = 1.f;
         MTTS_TRY(mtts_gemm_ex(&q, sb));
-        chunk_ev[c] = pool_event();
+        chunk_ev[c] = pool_event(s);
         MTTS_CHECK_HIP(hipEventRecord(chunk_ev[c], sb));
         // generator-LSTM weight gradients of this chunk
         MTTS_CHECK_HIP(hipStreamWaitEvent(sw, chunk_ev[c], 0));
@@ -368,7 +368,7 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
             }
         }
         {   // attention-LSTM and query weight gradients of this chunk
-            hipEvent_t ev = pool_event();
+            hipEvent_t ev = pool_event(s);
             MTTS_CHECK_HIP(hipEventRecord(ev, s));
             MTTS_CHECK_HIP(hipStreamWaitEvent(sw, ev, 0));
             const int n = c1 - c0;
@@ -387,7 +387,7 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
         if (c > 0) MTTS_TRY(submit_B(c - 1));
         MTTS_TRY(submit_A(c));
     }
-    hipEvent_t ev_b_done = pool_event(), ev_w_done = pool_event();
+    hipEvent_t ev_b_done = pool_event(s), ev_w_done = pool_event(s);
     MTTS_CHECK_HIP(hipEventRecord(ev_b_done, sb));
     MTTS_CHECK_HIP(hipEventRecord(ev_w_done, sw));
     MTTS_CHECK_HIP(hipStreamWaitEvent(s, ev_b_done, 0));
@@ -404,9 +404,9 @@ MTTS_API int mtts_bilstm_bwd(const BiLstmArgs* fwd, const BiLstmGradArgs* grad, 
     const long BH = (long)B * H, B4H = 4 * BH;
     // both directions' recurrences run concurrently (reverse direction on the side stream, own scratch halves); the batched
     // products that follow share dx and the split-K scratch and stay on the caller's stream
-    hipStream_t sd[2] = {s, side_stream()};
+    hipStream_t sd[2] = {s, side_stream(s)};
     if (!sd[1]) return mtts_fail("bilstm backward: cannot create the side stream");
-    hipEvent_t ev_fork = pool_event(), ev_join = pool_event();
+    hipEvent_t ev_fork = pool_event(s), ev_join = pool_event(s);
     MTTS_CHECK_HIP(hipEventRecord(ev_fork, s));
     MTTS_CHECK_HIP(hipStreamWaitEvent(sd[1], ev_fork, 0));
     for (int d = 1; d >= 0; --d) {

@@ -130,15 +130,8 @@ __device__ __forceinline__ void store_tile(float* __restrict__ lds, const Tile<T
 
 constexpr int LDS_A = (BM * KC_LD > BK * MC_LD) ? BM * KC_LD : BK * MC_LD;   // floats per operand buffer
 
-// Caller-provided scratch arena for split-K partial tiles (mtts_set_workspace); the library never allocates.
-static float* g_ws_host = nullptr;
-static size_t g_ws_bytes = 0;
-
-MTTS_API int mtts_set_workspace(void* ptr, size_t bytes) {
-    g_ws_host = (float*)ptr;
-    g_ws_bytes = bytes;
-    return 0;
-}
+// The scratch arena for split-K partial tiles is provided by the caller per device / per stream (mtts_set_workspace,
+// mtts_set_stream_workspace in common.cpp); the library never allocates.
 
 // C = epilogue(alpha * sum_s partial_s ...) for split-K launches
 __global__ void gemm_splitk_reduce(GemmArgs p, const float* __restrict__ ws, int S) {
@@ -479,6 +472,8 @@ MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
     const int ntx = cdiv(p.N, BN), nty = cdiv(p.M, BM);
     // split-K when few output tiles face a long reduction (weight gradients): fill ~4 workgroups per CU
     int S = 1;
+    size_t g_ws_bytes = 0;
+    float* g_ws_host = workspace_for((hipStream_t)stream, &g_ws_bytes);
     {
         const long tiles = (long)ntx * nty * p.batch * p.zt;
         const int nkb = cdiv(p.K, BK);

@@ -136,9 +136,12 @@ MTTS_API int mtts_clip_adam_step(const AdamArgs* args, void* stream) {
     const AdamArgs& p = *args;
     hipStream_t s = (hipStream_t)stream;
     MTTS_REQUIRE(p.nchunks > 0, "mtts_clip_adam_step: empty chunk table");
-    hipLaunchKernelGGL(adam_sumsq_kernel, dim3(p.nchunks), dim3(LT), 0, s, p);
-    hipLaunchKernelGGL(adam_norm_kernel, dim3(1), dim3(LT), 0, s, p);
-    hipLaunchKernelGGL(adam_apply_kernel, dim3(p.nchunks), dim3(LT), 0, s, p);
+    MTTS_REQUIRE(p.phase >= 0 && p.phase <= 2, "mtts_clip_adam_step: phase must be 0, 1 or 2");
+    if (p.phase != 2) {
+        hipLaunchKernelGGL(adam_sumsq_kernel, dim3(p.nchunks), dim3(LT), 0, s, p);
+        hipLaunchKernelGGL(adam_norm_kernel, dim3(1), dim3(LT), 0, s, p);
+    }
+    if (p.phase != 1) hipLaunchKernelGGL(adam_apply_kernel, dim3(p.nchunks), dim3(LT), 0, s, p);
     MTTS_CHECK_LAUNCH("clip_adam_step");
     return 0;
 }

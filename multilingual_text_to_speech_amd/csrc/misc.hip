@@ -1,22 +1,27 @@
 // Data-movement kernels: embedding gather / scatter-add, strided 2-D copy, conv weight repack.
 #include "common.h"
 
+// ids outside [0, vocab) never touch memory: the row reads as zeros / contributes no gradient and *err (nullable) is raised,
+// which the host turns into an exception at its next check (torch.nn.Embedding device-asserts instead).
 __global__ void embedding_fwd_kernel(const float* __restrict__ table, const int64_t* __restrict__ ids, float* __restrict__ out,
-                                     int rows, int D, int ldo, int col0) {
-    const long total = (long)rows * D;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long r = i / D; const int d = (int)(i - r * D);
-        out[r * ldo + col0 + d] = table[ids[r] * D + d];
-    }
-}
-
-__global__ void embedding_bwd_kernel(const float* __restrict__ dout, const int64_t* __restrict__ ids, float* __restrict__ dtable,
-                                     int rows, int D, int ldo, int col0, int padding_idx) {
+                                     int rows, int D, int ldo, int col0, long vocab, int* __restrict__ err) {
     const long total = (long)rows * D;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long r = i / D; const int d = (int)(i - r * D);
         const int64_t id = ids[r];
-        if (id == padding_idx) continue;
+        const bool ok = id >= 0 && id < vocab;
+        if (!ok && d == 0 && err) atomicOr(err, 1);
+        out[r * ldo + col0 + d] = ok ? table[id * D + d] : 0.f;
+    }
+}
+
+__global__ void embedding_bwd_kernel(const float* __restrict__ dout, const int64_t* __restrict__ ids, float* __restrict__ dtable,
+                                     int rows, int D, int ldo, int col0, int padding_idx, long vocab) {
+    const long total = (long)rows * D;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / D; const int d = (int)(i - r * D);
+        const int64_t id = ids[r];
+        if (id == padding_idx || id < 0 || id >= vocab) continue;
         atomicAdd(dtable + id * D + d, dout[r * ldo + col0 + d]);
     }
 }
@@ -44,17 +49,18 @@ __global__ void conv_pack_kernel(const float* __restrict__ in, float* __restrict
 static inline int nblocks(long total) { long b = (total + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
 
 MTTS_API int mtts_embedding_fwd(const float* table, const int64_t* ids, float* out, int rows, int D, int ldo, int col0,
-                                void* stream) {
+                                long vocab, int* err, void* stream) {
+    MTTS_REQUIRE(vocab > 0, "embedding_fwd: vocab must be positive");
     hipLaunchKernelGGL(embedding_fwd_kernel, dim3(nblocks((long)rows * D)), dim3(256), 0, (hipStream_t)stream, table, ids, out,
-                       rows, D, ldo, col0);
+                       rows, D, ldo, col0, vocab, err);
     MTTS_CHECK_LAUNCH("embedding_fwd");
     return 0;
 }
 
 MTTS_API int mtts_embedding_bwd(const float* dout, const int64_t* ids, float* dtable, int rows, int D, int ldo, int col0,
-                                int padding_idx, void* stream) {
+                                int padding_idx, long vocab, void* stream) {
     hipLaunchKernelGGL(embedding_bwd_kernel, dim3(nblocks((long)rows * D)), dim3(256), 0, (hipStream_t)stream, dout, ids,
-                       dtable, rows, D, ldo, col0, padding_idx);
+                       dtable, rows, D, ldo, col0, padding_idx, vocab);
     MTTS_CHECK_LAUNCH("embedding_bwd");
     return 0;
 }

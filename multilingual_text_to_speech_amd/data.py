@@ -79,6 +79,17 @@ class MelDataset(torch.utils.data.Dataset):
     def __len__(self):
         return len(self.items)
 
+    def get_num_speakers(self):
+        """dataset/dataset.py:160-163; train.py:239 sizes the speaker table and the adversarial classifier with it."""
+        return len(self.unique_speakers)
+
+    def frames(self, index):
+        """Frame count of utterance `index` from the .npy header (no data is read); cached."""
+        it = self.items[index]
+        if 'frames' not in it:
+            it['frames'] = int(np.load(os.path.join(self.root_dir, it['spectrogram']), mmap_mode='r').shape[1])
+        return it['frames']
+
     def _raw(self, it):
         mel = np.load(os.path.join(self.root_dir, it['spectrogram']))
         assert mel.shape[0] == hp.num_mels, f'spectrogram has {mel.shape[0]} channels, expected {hp.num_mels}'
@@ -95,16 +106,29 @@ class MelDataset(torch.utils.data.Dataset):
         return mean / len(self.items), std / len(self.items)
 
     def __getitem__(self, index):
+        """`index` may be a pair (index, T_global) from the sharding samplers: T_global = longest spectrogram of the GLOBAL
+        mini-batch, which every rank pads to (under DataParallel all replicas see the global max T)."""
+        pad_to = None
+        if isinstance(index, (tuple, list)):
+            index, pad_to = index
         it = self.items[index]
         mel = self._raw(it)
         if hp.normalize_spectrogram:
             mel = (mel - hp.mel_normalize_mean) / hp.mel_normalize_variance
-        return it['speaker'], it['language'], it['phonemes'] if hp.use_phonemes else it['text'], mel, None
+        item = (it['speaker'], it['language'], it['phonemes'] if hp.use_phonemes else it['text'], mel, None)
+        return item if pad_to is None else item + (int(pad_to),)
 
 
-def _shard(batch, rank, world):
+def _shard(batch, rank, world, data_source=None):
+    """Rank `rank`'s contiguous chunk of a GLOBAL mini-batch.  When the dataset can tell frame counts, every index travels
+    with the global batch's longest spectrogram so that all ranks pad to the same T (the loss terms are means over B*M*T
+    elements; the reference computes them on the gathered global batch, train.py:173-179 + modules/tacotron2.py:466-470)."""
     per = len(batch) // world
-    return batch[rank * per:(rank + 1) * per]
+    mine = batch[rank * per:(rank + 1) * per]
+    if data_source is not None and hasattr(data_source, 'frames') and world > 1:
+        t_global = max(data_source.frames(i) for i in batch)
+        return [(i, t_global) for i in mine]
+    return mine
 
 
 class PerfectBatchSampler(torch.utils.data.Sampler):
@@ -116,8 +140,9 @@ class PerfectBatchSampler(torch.utils.data.Sampler):
         G = len(languages)
         ways = G * data_parallel_devices * world
         assert batch_size % ways == 0, 'Batch size must be divisible by number of languages times the number of devices.'
+        self._data = data_source
         self._by_language = [[] for _ in range(G)]
-        for idx in range(len(data_source)):
+        for idx in range(len(data_source.items)):
             self._by_language[data_source.items[idx]['language']].append(idx)
         self._batch_size, self._G, self._ways = batch_size, G, ways
         self._shuffle, self._drop_last, self._rank, self._world = shuffle, drop_last, rank, world
@@ -147,18 +172,59 @@ class PerfectBatchSampler(torch.utils.data.Sampler):
 
     def __iter__(self):
         for b in self._global_batches():
-            yield _shard(b, self._rank, self._world)
+            yield _shard(b, self._rank, self._world, self._data)
 
     def __len__(self):
         per_lang = self._batch_size // self._G
         return min((len(ix) + per_lang - 1) // per_lang for ix in self._by_language)
 
 
+class GlobalBatchSampler(torch.utils.data.Sampler):
+    """Plain (not language-ordered) GLOBAL mini-batches, sharded per rank: the reference's
+    `DataLoader(batch_size, shuffle / sampler=RandomImbalancedSampler)` branch (train.py:231-236) under one process per GPU.
+    `balanced` draws indices with replacement, weight total / count(language) (utils/samplers.py:6-30); the draw is seeded by
+    (seed, epoch) so that every rank sees the same global batches."""
+
+    def __init__(self, data_source, batch_size, shuffle=True, balanced=False, drop_last=True, rank=0, world=1, seed=0):
+        assert batch_size % world == 0, 'Batch size must be divisible by the number of devices.'
+        self._data, self._n = data_source, len(data_source.items)
+        self._batch_size, self._shuffle, self._balanced, self._drop_last = batch_size, shuffle, balanced, drop_last
+        self._rank, self._world, self._seed, self._epoch = rank, world, seed, 0
+
+    def set_epoch(self, epoch):
+        self._epoch = epoch
+
+    def _order(self):
+        g = torch.Generator().manual_seed(self._seed * 1000003 + self._epoch)
+        if self._balanced:
+            return list(RandomImbalancedSampler(self._data, generator=g))
+        if self._shuffle:
+            return torch.randperm(self._n, generator=g).tolist()
+        return list(range(self._n))
+
+    def __iter__(self):
+        order = self._order()
+        for i in range(0, len(order), self._batch_size):
+            b = order[i:i + self._batch_size]
+            if len(b) < self._batch_size:
+                if self._drop_last:
+                    break
+                b = b[:(len(b) // self._world) * self._world]      # equal shards on every rank
+                if not b:
+                    break
+            yield _shard(b, self._rank, self._world, self._data)
+
+    def __len__(self):
+        if self._drop_last:
+            return self._n // self._batch_size
+        return (self._n + self._batch_size - 1) // self._batch_size
+
+
 class RandomImbalancedSampler(torch.utils.data.Sampler):
     """With-replacement sampling with weight total / count(language) (utils/samplers.py:6-30)."""
 
     def __init__(self, data_source, generator=None):
-        langs = [data_source.items[i]['language'] for i in range(len(data_source))]
+        langs = [it['language'] for it in data_source.items]
         freq = {}
         for l in langs:
             freq[l] = freq.get(l, 0) + 1
@@ -180,10 +246,20 @@ class Collate:
 
     def __call__(self, batch):
         n = len(batch)
+        pad_to = max((item[5] for item in batch if len(item) > 5), default=0)       # global max T (data-parallel shards)
+        batch = [item[:5] for item in batch]
         text_len = torch.tensor([len(u) for _, _, u, _, _ in batch], dtype=torch.int64)
         mel_len = torch.tensor([m.shape[1] for _, _, _, m, _ in batch], dtype=torch.int64)
         speakers = torch.tensor([s for s, _, _, _, _ in batch], dtype=torch.int64) if hp.multi_speaker else None
         languages = torch.tensor([l for _, l, _, _, _ in batch], dtype=torch.int64) if hp.multi_language else None
+        # ids index embedding tables on the device: validate them here, on the host, where it is free
+        vocab = hp.symbols_count() + 3
+        worst = max((max(u) for _, _, u, _, _ in batch if len(u)), default=0)
+        if worst >= vocab:
+            raise ValueError(f'symbol id {worst} outside the embedding table ({vocab} rows): use_phonemes / use_punctuation do not '
+                             'match the meta-file')
+        if speakers is not None and getattr(hp, 'speaker_number', 0) and int(speakers.max()) >= hp.speaker_number:
+            raise ValueError(f'speaker id {int(speakers.max())} but hp.speaker_number = {hp.speaker_number}')
         order = list(range(n))
         if self.sort_by_text_length:
             text_len, idx = torch.sort(text_len, descending=True, stable=True)
@@ -191,7 +267,7 @@ class Collate:
             mel_len = mel_len[idx]
             speakers = speakers[idx] if speakers is not None else None
             languages = languages[idx] if languages is not None else None
-        T = int(mel_len.max())
+        T = max(int(mel_len.max()), pad_to)
         utterances = torch.zeros(n, int(text_len.max()), dtype=torch.int64)
         mels = torch.zeros(n, hp.num_mels, T, dtype=torch.float32)
         stops = torch.zeros(n, T, dtype=torch.float32)
@@ -199,7 +275,7 @@ class Collate:
             _, _, u, m, _ = batch[i]
             utterances[row, :len(u)] = torch.as_tensor(u, dtype=torch.int64)
             mels[row, :, :m.shape[1]] = torch.as_tensor(np.asarray(m), dtype=torch.float32)
-            stops[row, m.shape[1] - hp.stop_frames:] = 1
+            stops[row, max(m.shape[1] - hp.stop_frames, 0):] = 1
         return utterances, text_len, mels, None, mel_len, stops, speakers, languages
 
 

@@ -54,6 +54,28 @@ class DecoderState:
         self.att_w_hh_p = e(4 * H * H) if hp_ok else None
         self.gen_w_hh_p = e(4 * H * H) if hp_ok else None
         self.w_query_p = e(((A + 15) & ~15) * H) if hp_ok else None
+        self._args = (B, L, dims, device, n_prenet, save_gates, fast, kq)
+
+    _PER_STEP = ('prenet_act', 'h_att', 'c_att', 'h_gen', 'c_gen', 'ctx', 'cum', 'align', 'gates_att', 'gates_gen', 'out', 'pre_att',
+                 'pre_gen', 'q_all', 'h_att_p', 'h_gen_p', 'ctx_p')
+
+    def grown(self, T):
+        """A state with room for T steps that continues this one: every per-step array keeps its first slots (free-running
+        synthesis allocates geometrically instead of hp.max_output_length = 5000 frames up front)."""
+        B, L, dims, device, n_prenet, save_gates, fast, kq = self._args
+        new = DecoderState(B, L, T, dims, device, n_prenet, save_gates, fast, kq)
+        for name in self._PER_STEP:
+            old, cur = getattr(self, name), getattr(new, name)
+            if old is None:
+                continue
+            if isinstance(old, list):
+                for o, c in zip(old, cur):
+                    c[:o.shape[0]].copy_(o)
+            else:
+                cur[:old.shape[0]].copy_(old)
+        for name in ('U', 'Mt', 'PL', 'qpart', 'att_w_ctx_p', 'att_w_hh_p', 'gen_w_hh_p', 'w_query_p'):      # per-call constants
+            setattr(new, name, getattr(self, name))
+        return new
 
 
 def fill_decoder_args(a, st, w, memory, lengths32, frames_in, teacher_host, masks, cfg):
@@ -174,11 +196,14 @@ def _copy_stream(dev):
     return _COPY_STREAMS[key]
 
 
-def decode_free(memory, lengths, w, cfg, masks, max_frames, stop_frames, chunk=32, stop_threshold=0.5, dims=None):
+def decode_free(memory, lengths, w, cfg, masks, max_frames, stop_frames, chunk=32, stop_threshold=0.5, dims=None,
+                initial_frames=None):
     """Free-running decode with the reference's stop rule (tacotron2.py:201-207), batch >= 1.
 
     Steps run in chunks of `chunk` on the device; after each chunk the stop logits come back to the host and
-    the rule is evaluated per sample.  Returns (frames [B,T',M], stop [B,T'], align [B,T',L], n_frames [B])."""
+    the rule is evaluated per sample.  `masks` is a dict of [max_frames, ...] keep flags or a callable T -> dict (then the
+    per-step buffers start at `initial_frames` and double when the decode outgrows them).
+    Returns (frames [B,T',M], stop [B,T'], align [B,T',L], n_frames [B])."""
     require_gpu(memory)
     memory = memory.contiguous()
     B, L, Dm = memory.shape
@@ -186,7 +211,11 @@ def decode_free(memory, lengths, w, cfg, masks, max_frames, stop_frames, chunk=3
     P, H = w['prenet_w'][0].shape[0], w['att_w_hh'].shape[1]
     A, C, ksz = w['w_query'].shape[0], w['w_conv'].shape[0], w['w_conv'].shape[1]
     dev = memory.device
-    st = DecoderState(B, L, max_frames, (M, P, H, A, Dm, ksz, C), dev, len(w['prenet_w']), save_gates=False, fast=False,
+    mask_fn = masks if callable(masks) else None
+    cap = min(max_frames, max(chunk, initial_frames or 1024)) if mask_fn is not None else max_frames
+    if mask_fn is not None:
+        masks = mask_fn(cap)
+    st = DecoderState(B, L, cap, (M, P, H, A, Dm, ksz, C), dev, len(w['prenet_w']), save_gates=False, fast=False,
                       kq=cfg.get('kq', 8))
     lengths32 = lengths.to(device=dev, dtype=torch.int32).contiguous()
     # The stop rule is evaluated on the host per chunk while the device already runs the NEXT chunk (speculatively): the
@@ -197,7 +226,12 @@ def decode_free(memory, lengths, w, cfg, masks, max_frames, stop_frames, chunk=3
     copy_stream = _copy_stream(dev)
 
     def submit(t):
+        nonlocal st, masks, cap
         t1 = min(max_frames, t + chunk)
+        if t1 > cap:                                 # outgrown: double the per-step buffers, keep what has been decoded
+            cap = min(max_frames, max(2 * cap, t1))
+            st = st.grown(cap)
+            masks = mask_fn(cap)                     # fresh draws; only steps >= t read them
         run_decoder(st, w, memory, lengths32, None, None, masks, cfg, t, t1)
         flags = (torch.sigmoid(st.out[t + 1:t1 + 1, :, M]) >= stop_threshold)
         ev = torch.cuda.Event()

@@ -104,6 +104,28 @@ def linear(x, weight, bias=None, act='identity', mask=None, mask_scale=1.0):
 # Embedding
 # ------------------------------------------------------------------------------------------------
 
+_ERR_FLAGS = {}
+
+
+def _err_flag(device):
+    """One device int per GPU, raised by kernels that met invalid input (an embedding id outside its table)."""
+    key = torch.device(device).index or 0
+    if key not in _ERR_FLAGS:
+        _ERR_FLAGS[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _ERR_FLAGS[key]
+
+
+def check_device_errors(device=None):
+    """Raise if a kernel flagged invalid input since the last check (synchronises; call once per step / synthesis call)."""
+    for key, flag in list(_ERR_FLAGS.items()):
+        if device is not None and (torch.device(device).index or 0) != key:
+            continue
+        if int(flag.item()) != 0:
+            flag.zero_()
+            raise _C.MttsError('an embedding id was outside its table (symbol id >= symbols_count()+3, speaker id >= '
+                               'hp.speaker_number or language id >= hp.language_number); the row was read as zeros')
+
+
 class EmbeddingFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, table, ids, padding_idx):
@@ -111,7 +133,8 @@ class EmbeddingFn(torch.autograd.Function):
         ids = ids.contiguous()
         D = table.shape[1]
         out = _f32(*ids.shape, D, device=table.device)
-        check(lib().mtts_embedding_fwd(ptr(table), ptr(ids), ptr(out), ids.numel(), D, D, 0, stream_ptr()), 'embedding_fwd')
+        check(lib().mtts_embedding_fwd(ptr(table), ptr(ids), ptr(out), ids.numel(), D, D, 0, ctypes.c_long(table.shape[0]),
+                                       ptr(_err_flag(table.device)), stream_ptr()), 'embedding_fwd')
         ctx.save_for_backward(ids)
         ctx.shape, ctx.padding_idx = table.shape, padding_idx
         return out
@@ -123,7 +146,8 @@ class EmbeddingFn(torch.autograd.Function):
         D = ctx.shape[1]
         dtable = torch.zeros(ctx.shape, dtype=torch.float32, device=dout.device)
         check(lib().mtts_embedding_bwd(ptr(dout), ptr(ids), ptr(dtable), ids.numel(), D, D, 0,
-                                       -1 if ctx.padding_idx is None else ctx.padding_idx, stream_ptr()), 'embedding_bwd')
+                                       -1 if ctx.padding_idx is None else ctx.padding_idx, ctypes.c_long(ctx.shape[0]),
+                                       stream_ptr()), 'embedding_bwd')
         return dtable, None, None
 
 

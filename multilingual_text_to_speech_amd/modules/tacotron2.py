@@ -122,7 +122,10 @@ class Decoder(Module):
         B, L = memory.shape[0], memory.shape[1]
         if lengths is None:
             lengths = torch.full((B,), L, dtype=torch.int64)
-        masks = self._step_masks(self._max_frames, B, memory.device)
+        if provider.injected is not None:      # tests inject the reference's draws for all max_frames steps
+            masks = self._step_masks(self._max_frames, B, memory.device)
+        else:                                   # buffers and draws grow with the utterance (not hp.max_output_length up front)
+            masks = lambda T: self._step_masks(T, B, memory.device)
         w = D.decoder_weights(self, self._attention, self._prenet)
         with torch.no_grad():
             frames, _, _, n = D.decode_free(memory, lengths, w, self._cfg(), masks, self._max_frames, hp.stop_frames,
@@ -232,6 +235,7 @@ class Tacotron(Module):
                 language = torch.argmax(language, dim=2)
             frames, n = self._decoder.inference(encoded, speaker, language)
             post = self._postnet(frames[:, :n[0]].contiguous(), None)
+        K.check_device_errors(post.device)         # an id outside an embedding table must not pass silently
         return post.transpose(1, 2).squeeze(0)
 
 
@@ -282,6 +286,7 @@ class Tacotron(Module):
                 post = self._postnet(frames[idx, :nf].contiguous(), None)
                 for j, i in enumerate(idx):
                     out[i] = post[j].transpose(0, 1)
+        K.check_device_errors(dev)
         return out
 
 

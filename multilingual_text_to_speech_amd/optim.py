@@ -47,8 +47,13 @@ class TacotronLossFn(torch.autograd.Function):
 
 class FusedAdam(torch.optim.Adam):
     """torch.optim.Adam (same hyper-parameters, same state_dict layout: step / exp_avg / exp_avg_sq) whose `step` runs
-    clip_grad_norm_ + the Adam update in three kernel launches over a device-side tensor table
-    (reference train.py:84-85: clip_grad_norm_(0.25) then Adam(lr, weight_decay=L2-coupled))."""
+    clip_grad_norm_ + the Adam update in three kernel launches over device-side tensor tables
+    (reference train.py:84-85: clip_grad_norm_(0.25) over ALL parameters, then Adam(lr, weight_decay=L2-coupled);
+    train.py:261-270: optionally two parameter groups, the encoder with its own learning rate).
+
+    One table spans every parameter that has a gradient (global norm / clip coefficient); the update runs once per
+    (parameter group, bias-correction step) so per-group learning rates and parameters that skipped earlier steps keep
+    torch's semantics."""
 
     CHUNK = 1 << 16
 
@@ -56,36 +61,55 @@ class FusedAdam(torch.optim.Adam):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self._tables = {}
 
-    def _table(self, gi, plist):
-        key = (gi, tuple((p.data_ptr(), p.grad.data_ptr()) for p in plist))
-        t = self._tables.get(gi)
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._tables = {}               # the moment buffers were replaced: the cached device tables point at freed memory
+
+    def _table(self, name, plist):
+        # the device table bakes in parameter, gradient AND moment pointers: all of them are part of the cache key
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]['exp_avg'].data_ptr(), self.state[p]['exp_avg_sq'].data_ptr())
+                    for p in plist)
+        t = self._tables.get(name)
         if t is not None and t['key'] == key:
             return t
         dev = plist[0].device
         ptrs, ct, co, cl = [], [], [], []
         for i, p in enumerate(plist):
-            st = self.state[p]
-            ptrs += [p.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr()]
+            ptrs += list(key[i])
             n = p.numel()
             for off in range(0, n, self.CHUNK):
                 ct.append(i); co.append(off); cl.append(min(self.CHUNK, n - off))
         t = dict(key=key, n=len(ct),
                  ptrs=torch.tensor(ptrs, dtype=torch.int64, device=dev), ct=torch.tensor(ct, dtype=torch.int32, device=dev),
                  co=torch.tensor(co, dtype=torch.int64, device=dev), cl=torch.tensor(cl, dtype=torch.int32, device=dev),
-                 partials=torch.empty(len(ct), dtype=torch.float32, device=dev), norm=torch.zeros(2, dtype=torch.float32, device=dev))
-        self._tables[gi] = t
+                 partials=torch.empty(len(ct), dtype=torch.float32, device=dev))
+        self._tables[name] = t
         return t
+
+    def _launch(self, t, norm, phase, max_norm, group=None, step=1):
+        a = _C.AdamArgs()
+        a.ptrs, a.chunk_tensor, a.chunk_off, a.chunk_len = ptr(t['ptrs']), ptr(t['ct']), ptr(t['co']), ptr(t['cl'])
+        a.norm_partials, a.norm_out, a.nchunks, a.phase = ptr(t['partials']), ptr(norm), t['n'], phase
+        a.max_norm = float(max_norm)
+        if group is not None:
+            b1, b2 = group['betas']
+            a.weight_decay, a.beta1, a.beta2, a.eps = group['weight_decay'], b1, b2, group['eps']
+            a.step_size = group['lr'] / (1 - b1 ** step)
+            a.inv_sqrt_bc2 = 1.0 / math.sqrt(1 - b2 ** step)
+        check(lib().mtts_clip_adam_step(ctypes.byref(a), stream_ptr()), 'mtts_clip_adam_step')
 
     @torch.no_grad()
     def step(self, closure=None, max_norm=0.0):
-        """One update; `max_norm > 0` applies clip_grad_norm_ over this optimizer's parameters first.  Returns the device
-        tensor [grad_norm, clip_coefficient] of the (last) parameter group."""
-        norm = None
+        """One update; `max_norm > 0` applies clip_grad_norm_ over ALL of this optimizer's parameters first.  Returns the
+        device tensor [grad_norm, clip_coefficient]."""
+        work = []                                  # (group index, ordinal within the group, step value, parameters)
+        everything = []
         for gi, group in enumerate(self.param_groups):
             plist = [p for p in group['params'] if p.grad is not None]
             if not plist:
                 continue
             require_gpu(*plist)
+            by_step = {}
             for p in plist:
                 st = self.state[p]
                 if len(st) == 0:
@@ -93,17 +117,21 @@ class FusedAdam(torch.optim.Adam):
                     st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 assert p.is_contiguous() and p.grad.is_contiguous()
-            step = int(self.state[plist[0]]['step']) + 1
-            for p in plist:
-                self.state[p]['step'] += 1
-            t = self._table(gi, plist)
-            b1, b2 = group['betas']
-            a = _C.AdamArgs()
-            a.ptrs, a.chunk_tensor, a.chunk_off, a.chunk_len = ptr(t['ptrs']), ptr(t['ct']), ptr(t['co']), ptr(t['cl'])
-            a.norm_partials, a.norm_out, a.nchunks = ptr(t['partials']), ptr(t['norm']), t['n']
-            a.max_norm, a.weight_decay, a.beta1, a.beta2, a.eps = float(max_norm), group['weight_decay'], b1, b2, group['eps']
-            a.step_size = group['lr'] / (1 - b1 ** step)
-            a.inv_sqrt_bc2 = 1.0 / math.sqrt(1 - b2 ** step)
-            check(lib().mtts_clip_adam_step(ctypes.byref(a), stream_ptr()), 'mtts_clip_adam_step')
-            norm = t['norm']
+                st['step'] += 1
+                by_step.setdefault(int(st['step']), []).append(p)
+            everything += plist
+            work += [(gi, k, step, ps) for k, (step, ps) in enumerate(sorted(by_step.items()))]
+        if not everything:
+            return None
+        dev = everything[0].device
+        norm = self._tables.get('norm')
+        if norm is None or norm.device != dev:
+            norm = self._tables['norm'] = torch.zeros(2, dtype=torch.float32, device=dev)
+        if len(work) == 1:                         # the common case: one group, one step value -> one fused call
+            gi, _, step, ps = work[0]
+            self._launch(self._table(('all',), ps), norm, 0, max_norm, self.param_groups[gi], step)
+            return norm
+        self._launch(self._table(('all',), everything), norm, 1, max_norm)
+        for gi, k, step, ps in work:
+            self._launch(self._table((gi, k), ps), norm, 2, max_norm, self.param_groups[gi], step)
         return norm

@@ -50,6 +50,13 @@ CASES = {
                              multi_speaker=True, speaker_number=5, max_output_length=12),
                         1, 10, 0, dict(infer=True, train=False)),
     'simple_infer': (dict(max_output_length=12), 1, 10, 0, dict(infer=True, train=False)),
+    # T >= 100: the product's decoder schedules work in chunks of 48 steps (csrc/decoder.hip); these two cross 2 chunk
+    # boundaries with a ragged last chunk, so the reference itself pins chunk hand-off and per-chunk gradient accumulation
+    'simple_long_train': (dict(), 3, 12, 110, dict()),
+    'generated_long_train': (dict(encoder_type='generated', multi_language=True, language_number=2, languages=['a', 'b'],
+                                  language_embedding_dimension=0, generator_dim=6, generator_bottleneck_dim=3,
+                                  multi_speaker=True, speaker_number=5, reversal_classifier=True,
+                                  reversal_classifier_w=0.125), 4, 12, 100, dict()),
 }
 
 
@@ -232,7 +239,7 @@ def main():
     defaults = dict(hp.state_dict())
     os.makedirs(args.out, exist_ok=True)
     for name, (ov, B, L, T, flags) in CASES.items():
-        if args.only and name != args.only:
+        if args.only and name not in args.only.split(','):
             continue
         fx = run_case(name, ov, B, L, T, flags, (hp, Tacotron, TacotronLoss, defaults))
         path = os.path.join(args.out, name + '.pt')

@@ -76,9 +76,9 @@ def test_perfect_batches_are_language_ordered_and_sharded(corpus):
     r1 = list(D.PerfectBatchSampler(ds, hp.languages, 12, shuffle=True, drop_last=True, rank=1, world=2, seed=5))
     whole = list(D.PerfectBatchSampler(ds, hp.languages, 12, shuffle=True, drop_last=True, seed=5))
     assert len(r0) == len(r1) == len(whole) == 1
-    assert r0[0] + r1[0] == whole[0]
+    assert [i for i, _ in r0[0] + r1[0]] == whole[0]          # sharded samplers yield (index, global max T) pairs
     for part in (r0[0], r1[0]):
-        assert [ds.items[i]['language'] for i in part] == [0, 1, 2, 0, 1, 2]
+        assert [ds.items[i]['language'] for i, _ in part] == [0, 1, 2, 0, 1, 2]
     with pytest.raises(AssertionError):
         D.PerfectBatchSampler(ds, hp.languages, 9, world=2)       # 9 % (3 * 2) != 0
 
@@ -177,3 +177,100 @@ def test_synthesize_front_end_tokens_speakers_denormalisation():
     assert np.allclose(S.denormalize(mel), 5.0)
     del hp.unique_speakers, hp.mel_normalize_mean, hp.mel_normalize_variance
     reset_defaults()
+
+
+def test_data_parallel_shards_pad_to_the_global_max_frames(corpus):
+    """under DataParallel every replica sees target.size(2) = max T of the GLOBAL batch, so the MSE / BCE
+    means have the same denominator on every replica.  Each rank's shard must therefore be padded to the global max, not to
+    its own."""
+    ds, _ = corpus
+    whole = list(D.PerfectBatchSampler(ds, hp.languages, 12, shuffle=True, drop_last=True, seed=5))[0]
+    t_global = max(ds.frames(i) for i in whole)
+    shapes = []
+    for rank in range(2):
+        shard = list(D.PerfectBatchSampler(ds, hp.languages, 12, shuffle=True, drop_last=True, rank=rank, world=2, seed=5))[0]
+        assert [i for i, _ in shard] == whole[rank * 6:(rank + 1) * 6] and all(t == t_global for _, t in shard)
+        u, ul, mel, _, ml, stop, _, _ = D.Collate(False)([ds[item] for item in shard])
+        shapes.append(mel.shape[2])
+        assert stop.shape[1] == t_global and int(ml.max()) <= t_global
+        for row in range(6):      # padding frames carry stop target 1 like the reference's slice-to-the-end (dataset.py:320)
+            assert stop[row, int(ml[row]) - hp.stop_frames:].min() == 1 and not mel[row, :, int(ml[row]):].any()
+    assert shapes == [t_global, t_global]
+    local_max = [max(ds.frames(i) for i in whole[r * 6:(r + 1) * 6]) for r in range(2)]
+    assert min(local_max) < t_global          # the case is not vacuous: one rank's own maximum is shorter
+
+
+def test_global_batch_sampler_plain_and_balanced(corpus):
+    """Reference train.py:231-236 (non-perfect branch): shuffled global batches / with-replacement language-balanced draws,
+    here cut into per-rank shards that together form the global batch."""
+    ds, counts = corpus
+    n = sum(counts.values())
+    full = list(D.GlobalBatchSampler(ds, 8, shuffle=True, drop_last=True, seed=3))
+    assert len(full) == n // 8 == len(D.GlobalBatchSampler(ds, 8))
+    flat = [i for b in full for i in b]
+    assert len(set(flat)) == len(flat) and flat != sorted(flat)
+    r = [list(D.GlobalBatchSampler(ds, 8, shuffle=True, drop_last=True, rank=k, world=2, seed=3)) for k in range(2)]
+    for b, s0, s1 in zip(full, *r):
+        assert [i for i, _ in s0] + [i for i, _ in s1] == b
+        assert {t for _, t in s0 + s1} == {max(ds.frames(i) for i in b)}
+    ordered = list(D.GlobalBatchSampler(ds, 8, shuffle=False, drop_last=False))
+    assert [i for b in ordered for i in b] == list(range(n)) and len(ordered) == 3
+    s = D.GlobalBatchSampler(ds, 8, balanced=True, seed=1)
+    draws = []
+    for e in range(30):
+        s.set_epoch(e)
+        draws += [i for b in s for i in b]
+    share = np.bincount([ds.items[i]['language'] for i in draws], minlength=3) / len(draws)
+    assert np.abs(share - 1 / 3).max() < 0.06
+
+
+def test_collate_rejects_ids_outside_the_embedding_tables(corpus):
+    ds, _ = corpus
+    hp.speaker_number = 4
+    items = [ds[i] for i in (0, 1)]
+    D.Collate(False)(items)
+    bad = list(items[0]); bad[2] = bad[2][:-1] + [hp.symbols_count() + 3]
+    with pytest.raises(ValueError, match='symbol id'):
+        D.Collate(False)([tuple(bad), items[1]])
+    hp.speaker_number = 2
+    with pytest.raises(ValueError, match='speaker id'):
+        D.Collate(False)([ds[i] for i in range(6)])
+
+
+@pytest.mark.parametrize('preset', ['shared_training', 'generated_switching'])
+def test_train_py_builds_loaders_for_every_encoder_family(corpus, preset):
+    """train.py --data_root: loader construction for a plain (simple/shared/separate) encoder preset and for a grouped one,
+    sampler choice per train.py:225-236, the corpus-derived hyper-parameters of train.py:238-250 and the teacher-forcing
+    schedule of train.py:58-60."""
+    import argparse
+    import train as T
+    from multilingual_text_to_speech_amd.params import presets
+    ds, counts = corpus
+    root = ds.root_dir
+    presets.apply(preset)
+    hp.languages, hp.language_number = ['de', 'fr', 'nl'], 3
+    hp.batch_size = 6
+    args = argparse.Namespace(data_root=root)
+    train_set, val_set = T.open_datasets(args, hp, None)
+    assert val_set is None and hp.speaker_number == (4 if hp.multi_speaker else 0)
+    assert not hp.multi_speaker or hp.unique_speakers == ['spk0', 'spk1', 'spk2', 'spk3']
+    assert np.asarray(hp.mel_normalize_mean).shape == (hp.num_mels, 1)
+    loader, sampler = T.make_loader(hp, train_set, True, 0, 1, 0)
+    grouped = hp.encoder_type in ('generated', 'convolutional')
+    assert isinstance(sampler, D.PerfectBatchSampler if grouped or hp.perfect_sampling else D.GlobalBatchSampler)
+    batches = list(loader)
+    assert len(batches) >= 3
+    u, ul, mel, _, ml, stop, spk, lang = batches[0]
+    assert u.shape[0] == 6 and mel.shape[:2] == (6, hp.num_mels) and (spk is not None) == hp.multi_speaker and lang is not None
+    if grouped:
+        assert lang.tolist() == [0, 1, 2, 0, 1, 2]
+    else:
+        assert ul.tolist() == sorted(ul.tolist(), reverse=True)          # packed BiLSTM needs sorted lengths (encoder.py:41)
+    # 2 ranks: both construct, equal number of batches
+    l0 = list(T.make_loader(hp, train_set, True, 0, 2, 0)[0]); l1 = list(T.make_loader(hp, train_set, True, 1, 2, 0)[0])
+    assert len(l0) == len(l1) >= 1 and l0[0][2].shape == l1[0][2].shape == (3, hp.num_mels, l0[0][2].shape[2])
+    # teacher forcing: constant by default; cosine decay after the start step otherwise
+    assert T.teacher_forcing_ratio(hp, 10 ** 6) == hp.teacher_forcing
+    hp.constant_teacher_forcing, hp.teacher_forcing_start_steps, hp.teacher_forcing_steps = False, 100, 1000
+    assert T.teacher_forcing_ratio(hp, 50) == 1.0
+    assert abs(T.teacher_forcing_ratio(hp, 600) - 0.5) < 1e-9 and T.teacher_forcing_ratio(hp, 5000) < 1e-9

@@ -1,0 +1,77 @@
+"""Parity of the schedules the T = 600 benchmark actually runs: the two-/three-stream 'fast' decoder schedules hand work
+over in chunks of CH = 48 steps (csrc/decoder.hip, csrc/decoder_bwd.hip: chain B trails / leads chain A chunk-wise, weight
+gradients accumulate chunk by chunk with beta = 1 on a third stream).  Every case here crosses chunk boundaries and is
+compared with the CPU oracle (reference Decoder._decode, modules/tacotron2.py:148-209, and its autograd)."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from tests.helpers import golden_names
+from tests.test_gpu_more import run_train_step_case
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# T = 49 / 97 / 150: 1, 2 and 3 chunk boundaries, ragged last chunk (1, 1 and 6 steps); B = 16 / 64 (one / four 16-row MFMA
+# tiles, the benchmark's batch) for shared_training, 15 / 65 (ragged tiles, two 64-row tiles) for the 5-language grouped preset
+@pytest.mark.parametrize('preset,B', [('shared_training', 16), ('shared_training', 64), ('generated_switching', 15),
+                                      ('generated_switching', 65)])
+@pytest.mark.parametrize('T', [49, 97, 150])
+def test_multi_chunk_train_step_matches_oracle(preset, B, T):
+    """Full train step (forward, loss, every parameter gradient) across chunk boundaries at the real layer widths."""
+    run_train_step_case(preset, B, 30, T, {})
+
+
+def test_benchmark_shape_forward_matches_oracle():
+    """The benchmark's own shape - shared_training, batch 64, 120 characters -> 600 frames (13 chunks), train mode with all
+    dropout draws injected - forward only: mel outputs and alignments against the CPU oracle."""
+    run_train_step_case('shared_training', 64, 120, 600, {}, check_grads=False)
+
+
+@pytest.mark.parametrize('chunk', ['2', '5'])
+def test_reference_fixtures_with_tiny_chunks(chunk):
+    """MTTS_CHUNK=2 / 5 pushes the reference-recorded fixtures (T = 5..7, T = 110) through 2-4 (22-55) chunks: chunk hand-off,
+    cross-stream events and beta = 1 weight-gradient accumulation are then pinned by the reference's own outputs and gradients."""
+    env = dict(os.environ, MTTS_CHUNK=chunk)
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', 'tests/test_gpu_forward.py', 'tests/test_gpu_backward.py'],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout
+
+
+def test_long_fixtures_exist():
+    """The reference itself pins a T >= 100 decode (oracle/make_golden.py: *_long_train)."""
+    assert {'simple_long_train', 'generated_long_train'} <= set(golden_names('train'))
+
+
+def test_two_streams_of_one_process_do_not_share_library_state():
+    """Helper streams, ordering events and split-K scratch are looked up per (device, caller stream): two decodes issued from
+    two torch streams of one process must give the same result as each of them alone."""
+    from multilingual_text_to_speech_amd.params import presets, Params as hp
+    from multilingual_text_to_speech_amd.modules.tacotron2 import Tacotron
+    from tests.test_gpu_more import _random_batch
+    presets.apply('shared_training')
+    torch.manual_seed(0)
+    model = Tacotron().cuda().eval()
+    B, L, T = 8, 24, 60
+    text, tl, target, tgl, spk, lang = _random_batch(hp, B, L, T)
+    args = (text.cuda(), tl, target.cuda(), tgl, None, lang.cuda(), 1.0)
+
+    def run():
+        torch.manual_seed(5)                   # identical prenet dropout draws
+        with torch.no_grad():
+            return model(*args)[0]
+    base = run()
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for s in (s1, s2, s1, s2):
+        with torch.cuda.stream(s):
+            outs.append(run())
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o, base)

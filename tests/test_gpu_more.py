@@ -143,13 +143,19 @@ def test_full_size_properties_and_schedule_equivalence():
 def test_train_step_gradients_match_oracle_at_real_widths(preset, B, L, T, over):
     """Full train step (loss + backward) at the real layer widths against the CPU oracle's autograd: exercises the
     MFMA attention kernels, the packed-operand step kernels and the two-stream schedules that the small fixtures bypass."""
+    run_train_step_case(preset, B, L, T, over)
+
+
+def run_train_step_case(preset, B, L, T, over, check_grads=True, ragged=None):
+    """One train-mode step of the product on the GPU against the CPU oracle with identical dropout draws: outputs, loss and
+    (check_grads) the gradient of every parameter.  Shared by the chunk-boundary tests in test_gpu_chunks.py."""
     from multilingual_text_to_speech_amd.params import presets, Params as hp
     from multilingual_text_to_speech_amd.modules.tacotron2 import Tacotron, TacotronLoss
     from multilingual_text_to_speech_amd.masks import provider
     presets.apply(preset, speaker_number=7, **over)
     torch.manual_seed(1)
     model = Tacotron().train()
-    text, tl, target, tgl, spk, lang = _random_batch(hp, B, L, T, seed=9, ragged=L >= 4)
+    text, tl, target, tgl, spk, lang = _random_batch(hp, B, L, T, seed=9, ragged=(L >= 4) if ragged is None else ragged)
     stop_t = torch.zeros(B, T)
     for b in range(B):
         stop_t[b, max(int(tgl[b]) - hp.stop_frames, 0):] = 1.0
@@ -183,9 +189,12 @@ def test_train_step_gradients_match_oracle_at_real_widths(preset, B, L, T, over)
             om[k] = mult(v, 0.05 if hp.encoder_type == 'generated' else hp.dropout).permute(0, 2, 1)
         if k.startswith('post.'):
             om[k] = mult(v, hp.dropout).permute(0, 2, 1)
-    ref = O.tacotron_forward(sd, cfg, text, tl, target, tgl, spk, lang, torch.ones(T, dtype=torch.bool), om, True)
-    rloss, _ = O.tacotron_loss(cfg, ref, tl, tgl, target, stop_t, spk, hp.guided_attention_toleration)
-    rloss.backward()
+    torch.set_flush_denormal(True)               # CPU speed only: identical output (SURVEY 8c recipe 5)
+    with torch.set_grad_enabled(check_grads):
+        ref = O.tacotron_forward(sd, cfg, text, tl, target, tgl, spk, lang, torch.ones(T, dtype=torch.bool), om, True)
+        rloss, _ = O.tacotron_loss(cfg, ref, tl, tgl, target, stop_t, spk, hp.guided_attention_toleration)
+    if check_grads:
+        rloss.backward()
 
     # ---- HIP
     model.cuda()
@@ -197,10 +206,15 @@ def test_train_step_gradients_match_oracle_at_real_widths(preset, B, L, T, over)
         provider.injected = None
     crit = TacotronLoss(hp.guided_attention_steps, hp.guided_attention_toleration, hp.guided_attention_gain)
     loss, _ = crit(tl.cuda(), tgl.cuda(), pre, target.cuda(), post, target.cuda(), stop, stop_t.cuda(), align, to(spk), spk_pred, enc, None)
-    loss.backward()
+    if check_grads:
+        loss.backward()
     torch.cuda.synchronize()
-    assert (post.cpu() - ref['post']).abs().max().item() <= 1e-3
+    for name, a, b in (('post', post, ref['post']), ('pre', pre, ref['pre']), ('alignment', align, ref['alignment'])):
+        err = (a.detach().cpu() - b.detach()).abs().max().item()
+        assert err <= 1e-3, f'{preset} B={B} T={T} {name}: max |delta| = {err:.3e}'
     assert abs(loss.item() - rloss.item()) <= 1e-4 * max(1.0, abs(rloss.item()))
+    if not check_grads:
+        return
     for k, p in model.named_parameters():
         r = sd[k].grad
         assert r is not None and p.grad is not None, k
@@ -403,6 +417,73 @@ def test_data_parallel_train_steps_two_ranks_one_gpu(tmp_path):
     assert r0['losses'] != r1['losses']                         # different shards
     for a, b in zip(r0['params'], r1['params']):
         assert torch.equal(a, b)
+
+
+def _micro_batch_grads(model, crit, hp, rank, G):
+    """Gradients of one micro-batch exactly as data-parallel rank `rank` computes them (same data seed, same dropout keys)."""
+    import os
+    import bench
+    os.environ['RANK'] = str(rank)                    # MaskProvider mixes the rank into its Philox key
+    torch.manual_seed(77)
+    batch = bench.synthetic_batch(hp, 2 * G, 9, 12, torch.device('cuda'), seed=100 + rank)
+    post, pre, stop, align, spk, enc = model(batch['text'], batch['text_length'], batch['target'], batch['target_length'],
+                                             batch['speakers'], batch['languages'], 1.0)
+    loss, _ = crit(batch['text_length'].cuda(), batch['target_length'].cuda(), pre, batch['target'], post, batch['target'], stop,
+                   batch['stop'], align, batch['speakers'], spk, enc, None)
+    loss.backward()
+    return float(loss)
+
+
+def _ddp_grad_worker(rank, world, port, out, fixture):
+    import os
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from multilingual_text_to_speech_amd import dist as D
+    from multilingual_text_to_speech_amd.params import Params as hp
+    from multilingual_text_to_speech_amd.modules.tacotron2 import TacotronLoss
+    from tests.helpers import build_hip_model, load_golden
+    D.init(backend='gloo')
+    model = build_hip_model(load_golden(fixture)).train()
+    crit = TacotronLoss(hp.guided_attention_steps, hp.guided_attention_toleration, hp.guided_attention_gain)
+    buckets = D.GradientBuckets(model.parameters(), bucket_bytes=1 << 16, overlap=True)
+    G = len(hp.languages) if hp.encoder_type in ('generated', 'convolutional') else 1
+    loss = _micro_batch_grads(model, crit, hp, rank, G)
+    buckets.all_reduce()
+    torch.cuda.synchronize()
+    torch.save(dict(loss=loss, grads={k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}), f'{out}/dp{rank}.pt')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradients_equal_the_mean_over_micro_batches(tmp_path, monkeypatch):
+    """the all-reduced gradient of a 2-rank step must equal what ONE rank gets from the same two
+    micro-batches run one after the other and averaged (the reference's loss is a mean over the gathered global batch;
+    equal per-rank B and T make the mean of local means that mean).  Whole Tacotron incl. the adversarial classifier."""
+    import socket
+    import torch.multiprocessing as mp
+    from multilingual_text_to_speech_amd.params import Params as hp
+    from multilingual_text_to_speech_amd.modules.tacotron2 import TacotronLoss
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_ddp_grad_worker, args=(2, port, str(tmp_path), 'generated_train'), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / 'dp0.pt'), torch.load(tmp_path / 'dp1.pt')
+    for k in r0['grads']:
+        assert torch.equal(r0['grads'][k], r1['grads'][k]), k            # both ranks hold the same reduced gradient
+    monkeypatch.setenv('RANK', '0')
+    model = build_hip_model(load_golden('generated_train')).train()
+    crit = TacotronLoss(hp.guided_attention_steps, hp.guided_attention_toleration, hp.guided_attention_gain)
+    G = len(hp.languages)
+    acc, losses = None, []
+    for k in range(2):
+        model.zero_grad(set_to_none=True)
+        losses.append(_micro_batch_grads(model, crit, hp, k, G))
+        g = {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()}
+        acc = g if acc is None else {n: acc[n] + g[n] for n in g}
+    assert abs(losses[0] - r0['loss']) <= 1e-6 * max(1, abs(losses[0])) and abs(losses[1] - r1['loss']) <= 1e-6 * max(1, abs(losses[1]))
+    assert losses[0] != losses[1]
+    for n, ref in acc.items():
+        ref = ref / 2
+        err = (r0['grads'][n] - ref).abs().max().item()
+        assert err <= 1e-5 * ref.abs().max().item() + 1e-7, f'{n}: {err:.3e}'
 
 
 def test_exact_f32_gemm_core_selectable():

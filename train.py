@@ -12,12 +12,46 @@ batches of SURVEY.md section 8(d) or with pre-collated tensors (`--batches file.
 bench.synthetic_batch).  Checkpoints use the reference's dictionary layout (train.py:302-310).
 """
 import argparse
+import math
 import os
 import time
 
 import torch
 
 from bench import synthetic_batch, train_step
+
+
+def cos_decay(global_step, decay_steps):
+    """Teacher-forcing schedule of the reference (train.py:18-26)."""
+    global_step = min(global_step, decay_steps)
+    return 0.5 * (1 + math.cos(math.pi * global_step / decay_steps))
+
+
+def teacher_forcing_ratio(hp, global_step):
+    """train.py:58-60: constant, or cosine decay that starts after hp.teacher_forcing_start_steps."""
+    if hp.constant_teacher_forcing:
+        return hp.teacher_forcing
+    return cos_decay(max(global_step - hp.teacher_forcing_start_steps, 0), hp.teacher_forcing_steps)
+
+
+def make_optimizer(hp, model):
+    """Adam (L2-coupled decay); with hp.encoder_optimizer the encoder gets its own learning rate (train.py:260-270)."""
+    from multilingual_text_to_speech_amd.optim import FusedAdam     # torch.optim.Adam's state_dict, fused clip + update
+    if not hp.encoder_optimizer:
+        return FusedAdam(model.parameters(), lr=hp.learning_rate, weight_decay=hp.weight_decay)
+    encoder_params = list(model._encoder.parameters())
+    other_params = list(model._decoder.parameters()) + list(model._postnet.parameters()) + list(model._prenet.parameters()) + \
+        list(model._embedding.parameters()) + list(model._attention.parameters())
+    if hp.reversal_classifier:
+        other_params += list(model._reversal_classifier.parameters())
+    seen, unique_other = set(id(p) for p in encoder_params), []
+    for p in other_params:          # _decoder aliases the prenet / attention modules: every tensor once
+        if id(p) not in seen:
+            seen.add(id(p))
+            unique_other.append(p)
+    opt = FusedAdam([{'params': unique_other}, {'params': encoder_params, 'lr': hp.learning_rate_encoder}],
+                    lr=hp.learning_rate, weight_decay=hp.weight_decay)
+    return opt
 
 
 def main():
@@ -52,13 +86,16 @@ def main():
             presets.apply(args.hyper_parameters, reset=state is None)
         else:
             hp.load(args.hyper_parameters)
-    if hp.multi_speaker and not hp.speaker_number:
-        hp.speaker_number = 91
     hp.language_number = len(hp.languages) if hp.multi_language else 0
+    datasets = None
+    if args.data_root:
+        # the corpus sizes the model (train.py:238-250): speaker table / classifier width, speaker names, mel statistics
+        datasets = open_datasets(args, hp, state)
+    elif hp.multi_speaker and not getattr(hp, 'speaker_number', 0):
+        hp.speaker_number = 91          # synthetic batches: the speaker count of data/css_comvoi
     device = torch.device('cuda', local)
     model = Tacotron().to(device).train()
-    from multilingual_text_to_speech_amd.optim import FusedAdam     # torch.optim.Adam's state_dict, one fused clip+update launch set
-    opt = FusedAdam(model.parameters(), lr=hp.learning_rate, weight_decay=hp.weight_decay)
+    opt = make_optimizer(hp, model)
     crit = TacotronLoss(hp.guided_attention_steps, hp.guided_attention_toleration, hp.guided_attention_gain)
     epoch0 = 0
     if state is not None:
@@ -73,14 +110,16 @@ def main():
     G = hp.language_number if hp.encoder_type in ('generated', 'convolutional') else 1
     per = hp.batch_size // world
     D.shard_bounds(per * world, rank, world, G)
-    if args.data_root:
-        return train_on_dataset(args, hp, model, opt, crit, buckets, rank, world, device, epoch0, ckpt_dir, state)
+    if datasets is not None:
+        return train_on_dataset(args, hp, datasets, model, opt, crit, buckets, rank, world, device, epoch0, ckpt_dir, state)
+    from multilingual_text_to_speech_amd.kernels import check_device_errors
     batches = torch.load(args.batches) if args.batches else None
     for step in range(args.steps):
         batch = batches[step % len(batches)] if batches else synthetic_batch(hp, per, args.chars, args.frames, device, seed=step * world + rank)
         t0 = time.time()
-        loss = train_step(model, crit, opt, buckets, batch, hp)
+        loss = train_step(model, crit, opt, buckets, batch, hp, teacher_forcing_ratio(hp, step))
         torch.cuda.synchronize()
+        check_device_errors(device)
         if rank == 0:
             print(f'step {step}: loss {loss.item():.4f}  {per * world * args.frames / (time.time() - t0):.0f} frames/s', flush=True)
     if rank == 0:
@@ -90,28 +129,70 @@ def main():
         print('saved', path)
 
 
-def train_on_dataset(args, hp, model, opt, crit, buckets, rank, world, device, epoch0, ckpt_dir, state):
-    """Epoch loop of the reference (train.py:218-310) over cached spectrograms, one process per GPU."""
-    from torch.utils.data import DataLoader
+def open_datasets(args, hp, state):
+    """Train / validation collections and the hyper-parameters the reference derives from them BEFORE building the model
+    (train.py:238-250): speaker count, speaker names (kept from the checkpoint on resume), mel normalisation constants."""
     from multilingual_text_to_speech_amd import data as DT
-    train_set = DT.MelDataset(os.path.join(args.data_root, 'train.txt'), args.data_root)
+    known = list(getattr(hp, 'unique_speakers', [])) if state is not None else []
+    train_set = DT.MelDataset(os.path.join(args.data_root, 'train.txt'), args.data_root, known)
     val_path = os.path.join(args.data_root, 'val.txt')
     val_set = DT.MelDataset(val_path, args.data_root, train_set.unique_speakers) if os.path.exists(val_path) else None
-    grouped = hp.encoder_type in ('generated', 'convolutional')
-    if hp.normalize_spectrogram and state is None:      # train.py:246-250; restored from the checkpoint's parameters otherwise
+    hp.speaker_number = 0 if not hp.multi_speaker else train_set.get_num_speakers()
+    if hp.multi_speaker and state is None:
+        hp.unique_speakers = list(train_set.unique_speakers)
+    if state is not None and hp.multi_speaker and train_set.get_num_speakers() != len(known):
+        raise SystemExit(f'the corpus has {train_set.get_num_speakers()} speakers but the checkpoint was trained with {len(known)}')
+    if hp.normalize_spectrogram and state is None:      # restored from the checkpoint's parameters otherwise
         hp.mel_normalize_mean, hp.mel_normalize_variance = train_set.get_normalization_constants()
+    return train_set, val_set
 
-    def loader(ds, shuffle, drop_last):
-        if grouped:
-            sampler = DT.PerfectBatchSampler(ds, hp.languages, hp.batch_size, shuffle=shuffle, drop_last=drop_last, rank=rank, world=world)
-        else:       # one "language" bucket = plain (optionally balanced) batches, sharded the same way
-            class _Flat:
-                items = [{'language': 0}] * len(ds)
-            sampler = DT.PerfectBatchSampler(_Flat(), [None], hp.batch_size, shuffle=shuffle, drop_last=drop_last, rank=rank, world=world)
-        return DataLoader(ds, batch_sampler=sampler, collate_fn=DT.Collate(not grouped), num_workers=args.loader_workers), sampler
 
-    train_data, train_sampler = loader(train_set, True, True)
-    # StepLR counted in epochs like the reference (train.py:266-271,296-297)
+def make_loader(hp, ds, train, rank, world, workers):
+    """Sampler selection of train.py:225-236.  Perfect (language-ordered) batches when hp.perfect_sampling (or a grouped encoder,
+    which cannot run on anything else); with-replacement language-balanced draws when hp.balanced_sampling; plain shuffled
+    batches otherwise.  Every sampler yields this rank's contiguous shard of the GLOBAL batch, padded to the global max T."""
+    from torch.utils.data import DataLoader
+    from multilingual_text_to_speech_amd import data as DT
+    grouped = hp.encoder_type in ('generated', 'convolutional')
+    balanced = bool(hp.multi_language and hp.balanced_sampling)
+    if grouped or (balanced and hp.perfect_sampling):
+        sampler = DT.PerfectBatchSampler(ds, hp.languages, hp.batch_size, shuffle=train, drop_last=train, rank=rank, world=world)
+        collate = DT.Collate(False)
+    else:
+        sampler = DT.GlobalBatchSampler(ds, hp.batch_size, shuffle=train and not balanced, balanced=train and balanced,
+                                        drop_last=train, rank=rank, world=world)
+        collate = DT.Collate(True)
+    return DataLoader(ds, batch_sampler=sampler, collate_fn=collate, num_workers=workers), sampler
+
+
+def evaluate(hp, data, model, crit, device):
+    """Validation loss with teacher forcing (train.py:100-126,155-160): mean of the per-batch loss terms.  The reference also
+    reports mel-cepstral distortion of a free-running pass and alignment plots; both need its audio stack (absent here)."""
+    from multilingual_text_to_speech_amd import data as DT
+    model.eval()
+    sums, n = {}, 0
+    with torch.no_grad():
+        for collated in data:
+            b = DT.batch_to_device(collated, device)
+            post, pre, stop, align, spk, enc = model(b['text'], b['text_length'], b['target'], b['target_length'], b['speakers'],
+                                                     b['languages'], 1.0)
+            _, parts = crit(b['text_length'].to(device), b['target_length'].to(device), pre, b['target'], post, b['target'], stop,
+                            b['stop'], align, b['speakers'], spk, enc, None)
+            for k, v in parts.items():
+                sums[k] = sums.get(k, 0.0) + float(v)
+            n += 1
+    model.train()
+    return {k: v / max(n, 1) for k, v in sums.items()}
+
+
+def train_on_dataset(args, hp, datasets, model, opt, crit, buckets, rank, world, device, epoch0, ckpt_dir, state):
+    """Epoch loop of the reference (train.py:29-97,289-310) over cached spectrograms, one process per GPU."""
+    from multilingual_text_to_speech_amd import data as DT
+    from multilingual_text_to_speech_amd.kernels import check_device_errors
+    train_set, val_set = datasets
+    train_data, train_sampler = make_loader(hp, train_set, True, rank, world, args.loader_workers)
+    eval_data = make_loader(hp, val_set, False, 0, 1, args.loader_workers)[0] if val_set is not None and len(val_set) else None
+    # StepLR counted in epochs like the reference (train.py:271,296-297)
     step_size = max(1, hp.learning_rate_decay_each // max(1, len(train_data)))
     sched = torch.optim.lr_scheduler.StepLR(opt, step_size, hp.learning_rate_decay)
     if state is not None and state.get('scheduler'):
@@ -119,18 +200,27 @@ def train_on_dataset(args, hp, model, opt, crit, buckets, rank, world, device, e
     for epoch in range(epoch0, args.epochs if args.epochs is not None else hp.epochs):
         train_sampler.set_epoch(epoch)
         model.train()
-        t0, frames = time.time(), 0
+        t0, frames, done = time.time(), 0, 0
         for collated in train_data:
             batch = DT.batch_to_device(collated, device)
-            loss = train_step(model, crit, opt, buckets, batch, hp)
+            global_step = done + epoch * len(train_data)
+            loss = train_step(model, crit, opt, buckets, batch, hp, teacher_forcing_ratio(hp, global_step))
             frames += int(batch['target_length'].sum())
+            done += 1
         torch.cuda.synchronize()
+        check_device_errors(device)
         if hp.learning_rate_decay_start - hp.learning_rate_decay_each < epoch * len(train_data):
             sched.step()
         if rank == 0:
-            print(f'epoch {epoch}: loss {loss.item():.4f}  {frames * world / (time.time() - t0):.0f} frames/s', flush=True)
+            # validation on rank 0 with the full (unsharded) batches, like the reference's single-process evaluate()
+            eval_losses = evaluate(hp, eval_data, model, crit, device) if eval_data is not None else {}
+            eval_loss = sum(eval_losses.values()) if eval_losses else float(loss.item())
+            print(f'epoch {epoch}: train loss {loss.item():.4f}  eval loss {eval_loss:.4f}  '
+                  f'{frames * world / (time.time() - t0):.0f} frames/s', flush=True)
             if (epoch + 1) % hp.checkpoint_each_epochs == 0:
-                DT.save_checkpoint(os.path.join(ckpt_dir, f'{hp.version}_loss-{epoch}-{loss.item():2.3f}'), epoch, model, opt, sched, crit)
+                DT.save_checkpoint(os.path.join(ckpt_dir, f'{hp.version}_loss-{epoch}-{eval_loss:2.3f}'), epoch, model, opt, sched, crit)
+        if world > 1:
+            torch.distributed.barrier()
 
 
 if __name__ == '__main__':
