@@ -8,11 +8,19 @@ embedding, Dm = 544), per-GPU batch 64, 120 characters -> 600 mel frames, fp32, 
 random-init weights.  One step = forward + TacotronLoss + backward + gradient all-reduce (N > 1) +
 clip_grad_norm_(0.25) + Adam step.  Prints ONE JSON line (rank 0).
 
-Extra objects on the line:
-  roofline     - the dominant kernel (skinny_kernel<4>: the attention-LSTM recurrent step, 1 launch per frame):
-                 algorithmic FLOP per launch / its average duration sampled live with HIP events on its stream.
-  cpu_baseline - the CPU oracle (oracle/tacotron_oracle.py, a torch-CPU port of the reference's arithmetic) timed on
-                 this host's cores on a bounded sample of the same workload (smaller batch / fewer frames).
+Extra objects on the line (N = 1):
+  roofline     - SURVEY 8(d)'s quantity for the workload's batch: the attention+decoder FORWARD step (everything one output
+                 frame costs in the teacher-forced decoder: prenet, attention LSTM, query, attention, generator LSTM,
+                 frame/stop projection).  achieved = algorithmic bytes per step 4*(W + B*act) / measured time per step
+                 (HIP events on the launch stream around the whole 600-step decoder forward); peak 8 TB/s.
+                 `traffic` = HBM bytes per step from live rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate passes,
+                 difference of a long and a short decode so that everything not proportional to the frame count cancels).
+                 `kernels` keeps the per-launch figures of the dominant kernel (attention-LSTM step) as a sub-field.
+  roofline_b240 - the same quantity for params/generated_switching at batch 240 (the valid batch next to the north star's 256).
+  inference    - BASELINE configs[4]: batched synthesis, 128 utterances x 201 tokens -> 600 frames, with its own step roofline.
+  cpu_baseline - the CPU oracle (oracle/tacotron_oracle.py, a torch-CPU port of the reference's arithmetic, kind "port") timed
+                 on this host's cores on a bounded sample of the same workload, plus `reference_recorded`: the reference
+                 itself (kind "reference") as recorded in the build container by scripts/cpu_reference_baseline.py.
 """
 import argparse
 import ctypes
@@ -66,18 +74,202 @@ def train_step(model, crit, opt, buckets, batch, hp, teacher_forcing=1.0):
     return loss
 
 
-def pmc_traffic(preset, B):
-    """HBM bytes per launch of the roofline kernel from the committed PMC measurement (rocprofv3 --pmc cannot run inside the
-    timed process); None when this workload was not measured."""
+def model_dims(hp):
+    Dm = hp.encoder_dimension + (hp.speaker_embedding_dimension if hp.multi_speaker else 0) + \
+        (hp.language_embedding_dimension if hp.multi_language else 0)
+    return dict(H=hp.decoder_dimension, P=hp.prenet_dimension, A=hp.attention_dimension, M=hp.num_mels,
+                C=hp.attention_location_dimension, ks=hp.attention_kernel_size, Dm=Dm)
+
+
+def step_algorithmic(hp, B, L, elem_bytes=4):
+    """algorithmic bytes and FLOPs of ONE forward decoder step of B samples (weights read once per step)."""
+    d = model_dims(hp)
+    H, P, A, M, C, ks, Dm = d['H'], d['P'], d['A'], d['M'], d['C'], d['ks'], d['Dm']
+    W = 4 * H * (P + Dm + H) + 4 * H * (H + Dm + H) + 16 * H + A * H + C * ks + A * C + 2 * A + (M + 1) * (H + Dm + 1)
+    act = L * A + L * Dm + 3 * L + 8 * H + P + 2 * Dm + M + 1
+    flop = 2.0 * B * (4 * H * (P + Dm + H) + 4 * H * (H + Dm + H) + A * H + L * (C * ks + A * C + A + Dm) + (M + 1) * (H + Dm))
+    return dict(weights=W, act_per_sample=act, bytes=float(elem_bytes) * (W + B * act), flop=flop, Dm=Dm)
+
+
+def decoder_forward_us(model, hp, batch, L, repeats=3):
+    """Median time (us) of the whole teacher-forced decoder forward, bracketed by HIP events on the launch stream (the helper
+    streams join the caller's stream before mtts_decoder_fwd returns, so the bracket covers them)."""
+    import multilingual_text_to_speech_amd.kernels as K
+    with torch.no_grad():
+        langs = batch['languages']
+        lang = langs.unsqueeze(1).expand(-1, L) if langs is not None else None
+        spk = batch['speakers'].unsqueeze(1).expand(-1, L) if batch['speakers'] is not None else None
+        emb = K.embedding(model._embedding.weight, batch['text'], 0)
+        enc = model._encoder(emb, batch['text_length'], lang)
+        times = []
+        for _ in range(repeats + 1):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            model._decoder(enc, batch['text_length'], batch['target'], 1.0, spk, lang)
+            e1.record()
+            e1.synchronize()
+            times.append(e0.elapsed_time(e1) * 1e3)
+    steady = sorted(times[1:])
+    return steady[len(steady) // 2], enc, spk, lang
+
+
+def step_roofline(model, hp, batch, B, L, T, preset):
+    """The north star's quantity: attention+decoder forward step against the HBM roofline."""
+    us, _, _, _ = decoder_forward_us(model, hp, batch, L)
+    us_step = us / T
+    alg = step_algorithmic(hp, B, L)
+    gbps = alg['bytes'] / (us_step * 1e-6) / 1e9
+    return {'bound': 'hbm', 'what': f'attention+decoder forward step (teacher forced), params/{preset}, batch {B}, L={L}, Dm={alg["Dm"]}: '
+                                    'prenet + attention LSTM + query + location-sensitive attention + generator LSTM + frame/stop projection',
+            'achieved': round(gbps, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(gbps / 8000.0, 4),
+            'us_per_step': round(us_step, 2), 'bytes_per_step': alg['bytes'], 'flop_per_step': alg['flop'],
+            'frac_of_measured_copy_6290GBps': round(gbps / 6290.0, 4),
+            'fp32_mfma_frac_of_157TF': round(alg['flop'] / (us_step * 1e-6) / 157.3e12, 4),
+            'frames_timed': T, 'traffic': None}
+
+
+def secondary_step_roofline(preset, B, L, T, device):
+    """Same quantity for another preset / batch (fresh random-init model; BASELINE north star: batch 256 -> nearest valid 240)."""
+    from multilingual_text_to_speech_amd.params import presets, Params as hp
+    from multilingual_text_to_speech_amd.modules.tacotron2 import Tacotron
+    presets.apply(preset, speaker_number=91)
+    torch.manual_seed(0)
+    model = Tacotron().to(device).train()
+    batch = synthetic_batch(hp, B, L, T, device)
+    out = step_roofline(model, hp, batch, B, L, T, preset)
+    del model
+    return out
+
+
+def inference_bench(device, preset='generated_switching', utterances=128, chars=200, frames=600, repeats=2):
+    """BASELINE configs[4]: batched autoregressive synthesis (encoder + free-running decoder + post-net), frame count pinned
+    (stop rule disabled), plus the free-running decoder step against its HBM roofline (L = 201)."""
+    from multilingual_text_to_speech_amd.params import presets, Params as hp
+    from multilingual_text_to_speech_amd.modules.tacotron2 import Tacotron
+    presets.apply(preset, speaker_number=91)
+    hp.max_output_length = frames
+    torch.manual_seed(0)
+    model = Tacotron().to(device).eval()
+    g = torch.Generator().manual_seed(1)
+    L = chars + 1
+    texts = [torch.cat([torch.randint(3, hp.symbols_count() + 3, (chars,), generator=g), torch.tensor([1])]) for _ in range(utterances)]
+    n_lang = len(hp.languages)
+    langs = None
+    if hp.multi_language:
+        langs = []
+        for i in range(utterances):
+            w = torch.zeros(L, n_lang); w[:, i % n_lang] = 1.0
+            langs.append(w)
+    spks = [i % hp.speaker_number for i in range(utterances)] if hp.multi_speaker else None
+    times = []
+    for _ in range(repeats + 1):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        out = model.inference_batch(texts, spks, langs, stop_threshold=2.0)
+        torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
+    assert all(o.shape == (hp.num_mels, frames) for o in out), out[0].shape
+    dt = sorted(times[1:])[len(times[1:]) // 2]
+    alg = step_algorithmic(hp, utterances, L)
+    us_step = dt / frames * 1e6
+    gbps = alg['bytes'] / (us_step * 1e-6) / 1e9
+    return {'metric': 'mel-frames/sec (batched synthesis: encoder + free-running decoder + post-net)',
+            'value': round(utterances * frames / dt, 1), 'unit': 'mel-frames/s', 'seconds_per_batch': round(dt, 4),
+            'workload': f'params/{preset} synthesis (BASELINE configs[4]), {utterances} utterances x {L} tokens -> {frames} frames, '
+                        'stop rule disabled, random-init weights, fp32',
+            'roofline': {'bound': 'hbm', 'what': 'free-running decoder step (whole-call time / frames: includes encoder and post-net)',
+                         'achieved': round(gbps, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(gbps / 8000.0, 4),
+                         'us_per_step': round(us_step, 2), 'bytes_per_step': alg['bytes']}}
+
+
+# ---- live HBM traffic (rocprofv3 PMC) -------------------------------------------------------------------------------------
+TRAFFIC_T = (48, 240)
+
+
+def traffic_probe(args):
+    """Child process run under `rocprofv3 --kernel-trace --pmc X`: marker | decode(T1) | marker | decode(T2) | marker."""
+    from multilingual_text_to_speech_amd import _C
+    from multilingual_text_to_speech_amd.params import presets, Params as hp
+    from multilingual_text_to_speech_amd.modules.tacotron2 import Tacotron
+    import multilingual_text_to_speech_amd.kernels as K
+    device = torch.device('cuda', 0)
+    presets.apply(args.preset, speaker_number=91)
+    torch.manual_seed(0)
+    model = Tacotron().to(device).train()
+    B, L = args.batch, L_CHARS
+    lib = _C.lib()
+    with torch.no_grad():
+        batches = {T: synthetic_batch(hp, B, L, T, device) for T in TRAFFIC_T}
+        b0 = batches[TRAFFIC_T[0]]
+        langs = b0['languages']
+        lang = langs.unsqueeze(1).expand(-1, L) if langs is not None else None
+        spk = b0['speakers'].unsqueeze(1).expand(-1, L) if b0['speakers'] is not None else None
+        enc = model._encoder(K.embedding(model._embedding.weight, b0['text'], 0), b0['text_length'], lang)
+        model._decoder(enc, b0['text_length'], b0['target'], 1.0, spk, lang)          # warm-up (allocator, stream creation)
+        torch.cuda.synchronize()
+        for k, T in enumerate(TRAFFIC_T):
+            _C.check(lib.mtts_prof_marker(k + 1, _C.stream_ptr()), 'marker')
+            model._decoder(enc, b0['text_length'], batches[T]['target'], 1.0, spk, lang)
+            torch.cuda.synchronize()
+        _C.check(lib.mtts_prof_marker(len(TRAFFIC_T) + 1, _C.stream_ptr()), 'marker')
+        torch.cuda.synchronize()
+
+
+def measure_traffic(preset, B, timeout=240):
+    """HBM bytes per forward decoder step from two rocprofv3 PMC passes over a child process (FETCH_SIZE, WRITE_SIZE; both
+    in KB; gfx950: FETCH_SIZE counts 64 B per 128-B request of wide coalesced reads -> x2, MI355X_MICROARCH.md HBM section).
+    Per step = (bytes of the long decode - bytes of the short one) / (difference of frame counts)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which('rocprofv3') is None:
+        return None, 'rocprofv3 not found'
+    totals = {}
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = tempfile.mkdtemp(prefix='mtts_pmc_', dir='/tmp')
+        try:
+            cmd = ['rocprofv3', '--kernel-trace', '--pmc', counter, '-d', d, '-o', 'p', '--output-format', 'csv', '--',
+                   sys.executable, os.path.abspath(__file__), '--traffic-probe', '--preset', preset, '--batch', str(B)]
+            r = subprocess.run(cmd, cwd='/tmp', env={**os.environ, 'TMPDIR': '/tmp'}, capture_output=True, text=True, timeout=timeout)
+            files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f'rocprofv3 {counter} pass failed (rc {r.returncode}): {(r.stderr or r.stdout)[-200:]}'
+            rows = []
+            with open(files[0], newline='') as f:
+                for row in csv.DictReader(f):
+                    if row['Counter_Name'] == counter:
+                        rows.append((int(row['Dispatch_Id']), row['Kernel_Name'], float(row['Counter_Value'])))
+            rows.sort()
+            marks = [i for i, (_, name, _) in enumerate(rows) if 'mtts_marker_kernel' in name]
+            if len(marks) != len(TRAFFIC_T) + 1:
+                return None, f'{len(marks)} marker dispatches in the {counter} pass'
+            totals[counter] = [sum(v for _, _, v in rows[marks[k] + 1:marks[k + 1]]) * 1024.0 for k in range(len(TRAFFIC_T))]
+        except Exception as exc:       # reporting only
+            return None, repr(exc)[:200]
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    dT = TRAFFIC_T[1] - TRAFFIC_T[0]
+    fetch = 2.0 * (totals['FETCH_SIZE'][1] - totals['FETCH_SIZE'][0]) / dT
+    write = (totals['WRITE_SIZE'][1] - totals['WRITE_SIZE'][0]) / dT
+    return {'bytes_per_step': round(fetch + write), 'fetch_bytes_x2': round(fetch), 'write_bytes': round(write),
+            'method': f'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), decode of {TRAFFIC_T[1]} minus {TRAFFIC_T[0]} frames'}, None
+
+
+def recorded_reference_baseline():
+    """The reference itself, timed in the build container (scripts/cpu_reference_baseline.py -> profiles/cpu_reference.json)."""
     try:
-        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
-            return json.load(f).get(f'{preset}/B{B}', {}).get('traffic_bytes')
-    except OSError:
+        with open(os.path.join(ROOT, 'profiles', 'cpu_reference.json')) as f:
+            doc = json.load(f)
+    except (OSError, ValueError):
         return None
+    keep = [dict(config=r['config'], batch=r['batch'], frames=r['frames'], flush_denormal=r['flush_denormal'],
+                 value=r['mel_frames_per_s'], seconds_per_step=r['seconds_per_step']) for r in doc.get('results', [])]
+    return dict(kind='reference', unit=doc.get('unit'), cores=doc.get('cores'), cpu=doc.get('cpu'), where='build container (the '
+                'reference does not exist on the GPU box)', results=keep, source='profiles/cpu_reference.json')
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """Time the CPU oracle (port of the reference) on a bounded sample: same config, batch 8, 40 frames."""
+def cpu_baseline(seconds_budget=30.0):
+    """Time the CPU oracle (port of the reference) on a bounded sample of the same workload: batch 16, 120 chars -> 200 frames."""
     from oracle import tacotron_oracle as O
     from multilingual_text_to_speech_amd.params import presets, Params as hp
     from multilingual_text_to_speech_amd.modules.tacotron2 import Tacotron
@@ -85,7 +277,7 @@ def cpu_baseline(seconds_budget=25.0):
     cores = min(os.cpu_count() or 1, 16)      # small-op oracle: more threads only add synchronisation cost
     torch.set_num_threads(cores)
     torch.set_flush_denormal(True)
-    B, L, T = 8, L_CHARS, 40
+    B, L, T = 16, L_CHARS, 200
     torch.manual_seed(0)
     model = Tacotron()
     sd = {k: v.detach().clone().requires_grad_(v.is_floating_point() and not k.endswith(('running_mean', 'running_var')))
@@ -105,7 +297,7 @@ def cpu_baseline(seconds_budget=25.0):
     teacher = torch.ones(T, dtype=torch.bool)
     times = []
     t_start = time.time()
-    for it in range(4):
+    for it in range(3):
         t0 = time.time()
         opt.zero_grad()
         out = O.tacotron_forward(sd, cfg, b['text'], b['text_length'], b['target'], b['target_length'], b['speakers'],
@@ -132,11 +324,15 @@ def main():
     ap.add_argument('--frames', type=int, default=T_FRAMES)
     ap.add_argument('--preset', default=PRESET)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the batch-240 step roofline, the inference object and the PMC traffic passes')
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--traffic-probe', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline()), flush=True)
         return
+    if args.traffic_probe:
+        return traffic_probe(args)
 
     from multilingual_text_to_speech_amd import _C, dist as D
     from multilingual_text_to_speech_amd.params import presets, Params as hp
@@ -181,12 +377,13 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(t_max, op=torch.distributed.ReduceOp.MAX)
     dt = float(t_max.item())
+    from multilingual_text_to_speech_amd.kernels import check_device_errors
+    check_device_errors(device)
 
     if rank == 0:
         frames = B * T * world * args.steps
-        H, P = hp.decoder_dimension, hp.prenet_dimension
-        Dm = hp.encoder_dimension + (hp.speaker_embedding_dimension if hp.multi_speaker else 0) + \
-            (hp.language_embedding_dimension if hp.multi_language else 0)
+        d = model_dims(hp)
+        H, Dm = d['H'], d['Dm']
         # dominant kernel: attention-LSTM recurrent step, [B, Dm+H] x [4H, Dm+H]^T + fused cell (prenet part hoisted)
         k_rec = Dm + H
         flop = 2.0 * B * k_rec * 4 * H
@@ -198,6 +395,13 @@ def main():
         empty_s = (float(lib.mtts_prof_empty_ms()) / max(cnt.value, 1)) * 1e-3
         avg_s = max(raw_s - empty_s, 1e-9)
         achieved = flop / avg_s / 1e12 if avg_s > 0 else 0.0
+        roof = step_roofline(model, hp, batch, B, L, T, args.preset)
+        roof['kernels'] = {'attention_lstm_step': {
+            'kernel': 'attention-LSTM step: [B,Dm+H]x[4H,Dm+H]^T + LSTM cell (1 launch per frame, largest total time)', 'bound': 'mfma',
+            'achieved_TFLOPs': round(achieved, 2), 'peak_TFLOPs': 157.3, 'frac': round(achieved / 157.3, 4), 'flop_per_launch': flop,
+            'bytes_per_launch': bytes_alg, 'avg_launch_us': round(avg_s * 1e6, 2), 'event_bracket_us': round(raw_s * 1e6, 2),
+            'empty_bracket_us': round(empty_s * 1e6, 2), 'hbm_frac_of_8TBps': round(bytes_alg / avg_s / 8e12, 4) if avg_s > 0 else 0.0,
+            'samples': cnt.value, 'sampled_in': 'the timed train steps (side streams active)'}}
         line = {
             'metric': 'mel-frames/sec (train, fwd+bwd+optimizer, batch 64/GPU, 120 chars -> 600 frames)',
             'value': round(frames / dt, 1), 'unit': 'mel-frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -207,21 +411,37 @@ def main():
                                    f'fp32, random-init weights', 'gemm_core': 'fp32 in/out; products as 6 bf16x bf16 MFMA terms of exact 3-way operand splits, fp32 accumulate (error <= fp32 chain)',
                        'global_batch': B * world, 'parallelism': f'dp{world}',
                        'loss': float(loss.item())},
-            'roofline': {'bound': 'mfma', 'kernel': 'skinny_kernel<4> (attention-LSTM step: [B,Dm+H]x[4H,Dm+H]^T + LSTM cell)',
-                         'achieved': round(achieved, 2), 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': round(achieved / 157.3, 4),
-                         'flop_per_launch': flop, 'bytes_per_launch': bytes_alg, 'avg_launch_us': round(avg_s * 1e6, 2),
-                         'event_bracket_us': round(raw_s * 1e6, 2), 'empty_bracket_us': round(empty_s * 1e6, 2),
-                         'hbm_frac_of_8TBps': round(bytes_alg / avg_s / 8e12, 4) if avg_s > 0 else 0.0, 'samples': cnt.value,
-                         'traffic': pmc_traffic(args.preset, B)},
+            'roofline': roof,
         }
+        if world == 1 and not args.no_secondary:
+            # free the training step's memory first; each leg is reporting only and must never cost the headline number
+            del model, opt, crit, batch
+            torch.cuda.empty_cache()
+            try:
+                traffic, why = measure_traffic(args.preset, B)
+                roof['traffic'] = traffic['bytes_per_step'] if traffic else None
+                roof['traffic_detail'] = traffic if traffic else {'error': why}
+            except Exception as exc:
+                roof['traffic_detail'] = {'error': repr(exc)[:200]}
+            try:
+                line['roofline_b240'] = secondary_step_roofline('generated_switching', 240, L_CHARS, 300, device)
+            except Exception as exc:
+                line['roofline_b240'] = {'error': repr(exc)[:200]}
+            try:
+                line['inference'] = inference_bench(device)
+            except Exception as exc:
+                line['inference'] = {'error': repr(exc)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             try:      # separate process + hard timeout: the baseline is reporting only, never lose the GPU number over it
                 import subprocess
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-only'], capture_output=True,
-                                   text=True, timeout=180, env={**os.environ, 'HIP_VISIBLE_DEVICES': ''})
+                                   text=True, timeout=240, env={**os.environ, 'HIP_VISIBLE_DEVICES': ''})
                 line['cpu_baseline'] = json.loads(r.stdout.strip().splitlines()[-1])
             except Exception as exc:
                 line['cpu_baseline'] = {'error': repr(exc)[:200]}
+            rec = recorded_reference_baseline()
+            if rec is not None:
+                line['cpu_baseline']['reference_recorded'] = rec
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

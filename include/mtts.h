@@ -547,6 +547,8 @@ int mtts_grad_reverse_clamp(const float* g, float* out, long n, float l, float c
 int mtts_dropout_keep_mask(uint8_t* out, long n, float p, uint64_t seed, uint64_t offset, void* stream);
 
 int mtts_prof_begin(int max_samples, int stride);
+/* Launches the no-op `mtts_marker_kernel` on `stream`: region boundaries for rocprofv3 traces / PMC passes (bench.py). */
+int mtts_prof_marker(int tag, void* stream);
 int mtts_prof_end(float* total_ms, int* count);
 /* summed duration (ms) of the EMPTY event brackets recorded in front of every sample: the cost of an event pair with nothing
  * between, subtracted by bench.py from the kernel brackets */
