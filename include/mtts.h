@@ -190,6 +190,65 @@ int mtts_skinny_gemm(const SkinnyArgs* args, void* stream);
 int mtts_pack_weight(const float* src, int ld, int N, int K, int lstm_H, float* dst, void* stream);
 int mtts_pack_rows(const float* src, int ld, int rows, int K, float* dst, void* stream);
 
+/* ---- recurrent LSTM step without operand re-reads: K-split gate GEMM + (partial sum, cell, query partials) --------------
+ * Replaces torch.nn.LSTMCell + dropout / zoneout (modules/layers.py:18-47, call site modules/tacotron2.py:185) and the
+ * attention query projection of the SAME step (modules/attention.py:68) by two launches:
+ *   G: P[ks][B][4H] = X[:, k-slice ks] W[:, k-slice ks]^T   (weights streamed once from the packed copy, X staged once per
+ *      workgroup through LDS; 4H/128 column tiles x KS slices = 256 workgroups at H = 1024)
+ *   C: gates = sum_ks P + pre + bias -> cell -> h, c, saved gates;  q_part[ut][B][A] = h[:, 16 ut..] W_q[:, 16 ut..]^T
+ * Gate columns of P / pre / bias_u are UNIT-MAJOR: column 4u + g holds gate g (i,f,g,o) of unit u.
+ * precision 0: fp32 operands, every product as six bf16 MFMA terms of exact 3-way splits (fp32-accurate);
+ * precision 1: operands rounded to bf16 (weights stored as bf16 in the packed copy), fp32 accumulation and cell state. */
+typedef struct LstmPackArgs {
+    const float* w[3];     /* up to 3 K-segments of the [4H, K_s] weight (row stride ldw[s]); K_s % 32 == 0 */
+    int K[3];
+    int ldw[3];
+    int nseg;
+    int H;
+    int precision;
+    void* dst;             /* mtts_lstm_packed_weight_bytes(H, sum K, precision) bytes */
+    const float* b_ih;     /* optional: bias_u[4u + g] = b_ih[gH + u] + b_hh[gH + u] */
+    const float* b_hh;
+    float* bias_u;
+} LstmPackArgs;
+
+typedef struct LstmStepArgs {
+    const float* x[3];     /* row-major [B, K_s] segments in the order of the packed weight */
+    int K[3];
+    int ldx[3];
+    int nseg;
+    const void* w_packed;
+    int precision;
+    int B;
+    int H;
+    float* partials;       /* mtts_lstm_step_partial_floats(B, H, sum K) floats */
+    const float* pre;      /* unit-major [B, 4H] addend (hoisted input projection) or NULL */
+    int ldpre;
+    const float* bias_u;   /* unit-major [4H] or NULL */
+    const float* h_prev;   /* [B,H] (zoneout only) */
+    const float* c_prev;
+    float* h_out;
+    float* c_out;
+    float* gates_out;      /* [B,4H] activated gates, GATE-major (column gH + u) like mtts_skinny_gemm's, or NULL */
+    const uint8_t* hmask;
+    const uint8_t* cmask;
+    float hscale;
+    int zone;              /* 0 dropout on h; 1 zoneout training; 2 zoneout eval */
+    float zh;
+    float zc;
+    const float* w_query;  /* [A, H] row-major or NULL */
+    int A;
+    float* qpart;          /* [H/16][B][A] query-projection partials (summed by mtts_attn_step_fwd with kq = H/16) or NULL */
+} LstmStepArgs;
+
+int mtts_lstm_step_ksplit(int k_total);
+long mtts_lstm_step_partial_floats(int B, int H, int k_total);
+long mtts_lstm_packed_weight_bytes(int H, int k_total, int precision);
+int mtts_lstm_pack_weights(const LstmPackArgs* args, void* stream);
+/* dst[(4u + g) K + k] = src[(gH + u) ld + k]: rows of a [4H, K] LSTM matrix into unit-major order (for the hoisted projection) */
+int mtts_lstm_rows_unit_major(const float* src, int ld, int H, int K, float* dst, void* stream);
+int mtts_lstm_step_fwd(const LstmStepArgs* args, void* stream);
+
 /* ---- location-sensitive attention step -------------------------------------------------------------------
  * Replaces LocationSensitiveAttention.forward for one decoder step: modules/attention.py:39-45,67-86.
  * The location Conv1d(1->C,k) followed by Linear(C->A) is applied as ONE k-tap filter bank U = W_loc * W_conv
@@ -305,6 +364,18 @@ typedef struct DecoderArgs {
     float* gen_w_hh_p;
     float* w_query_p;      /* packed W_query      (A x H) */
     int fast;              /* 1: all steps teacher forced -> hoisted projections + deferred generator chain */
+    /* optional K-split step path of the attention LSTM (fast schedule only; see LstmStepArgs).  All NULL -> skinny kernels.
+       Needs Dm % 32 == 0, H % 32 == 0, A % 16 == 0 and qpart sized [max(kq, H/16)][B][A]. */
+    void* att_w2p;         /* mtts_lstm_packed_weight_bytes(H, Dm + H, precision) bytes: packed [W_ih[:, P:] | W_hh] */
+    float* att_bias_u;     /* [4H] unit-major b_ih + b_hh */
+    float* att_w_pre_u;    /* [4H, P] rows of W_ih[:, :P] in unit-major order (pre_att is then unit-major) */
+    float* gate_part;      /* mtts_lstm_step_partial_floats(B, H, Dm + H) floats */
+    /* the same for the generator LSTM's recurrent step (its [h_att, ctx] input projection is hoisted per chunk) */
+    void* gen_w2p;         /* mtts_lstm_packed_weight_bytes(H, H, precision) bytes: packed W_hh */
+    float* gen_bias_u;     /* [4H] */
+    float* gen_w_ih_u;     /* [4H, H + Dm] rows of W_ih in unit-major order (pre_gen is then unit-major) */
+    float* gate_part_gen;  /* mtts_lstm_step_partial_floats(B, H, H) floats */
+    int precision;         /* 0: fp32 (3-way bf16 split products); 1: bf16 operands in the step GEMMs */
 } DecoderArgs;
 
 int mtts_decoder_fwd(const DecoderArgs* args, void* stream);
@@ -556,7 +627,7 @@ float mtts_prof_empty_ms(void);
 
 const char* mtts_last_error(void);
 int mtts_version(void);
-/* sizeof() of the structs above in declaration order (0 = GemmArgs ... 6 = BiLstmArgs, 7 = AttnBwdArgs, 8 = DecoderGradArgs, 9 = BiLstmGradArgs, 10 = TacoLossArgs, 11 = AdamArgs); -1 when out of range */
+/* sizeof() of the structs above in declaration order (0 = GemmArgs ... 6 = BiLstmArgs, 7 = AttnBwdArgs, 8 = DecoderGradArgs, 9 = BiLstmGradArgs, 10 = TacoLossArgs, 11 = AdamArgs, 12 = LstmPackArgs, 13 = LstmStepArgs); -1 when out of range */
 int mtts_sizeof_struct(int which);
 
 #ifdef __cplusplus

@@ -17,7 +17,7 @@
 constexpr int ATT_THREADS = 512;
 constexpr int NC_MAX = 8;     // memory float4 per thread   (ceil(L/ng) <= NC_MAX)
 constexpr int NU_MAX = 8;     // U elements per thread      (A*ksz    <= NU_MAX * ATT_THREADS)
-constexpr int KQ_MAX = 8;
+constexpr int KQ_PER = 16;   // query partial slabs per thread: kq <= KQ_PER * (ATT_THREADS / A)
 
 struct AttLds {
     float *q, *vv, *bias, *w, *cumw, *Us, *part;
@@ -70,11 +70,13 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_kernel(AttnStepArgs p) 
 
     // ---- burst of independent loads
     const int len = min(p.lengths[b], L);
-    float qp[KQ_MAX];
-    {
-        const int a = min(tid, A - 1);
+    // query partials: thread (group g = tid / A, channel a = tid % A) takes slabs g, g + ngrp, ...
+    const int q_ngrp = ATT_THREADS / A, q_g = tid / A, q_a = tid - q_g * A;
+    float qp[KQ_PER];
 #pragma unroll
-        for (int k = 0; k < KQ_MAX; ++k) qp[k] = (k < p.kq) ? p.qpart[(long)k * p.q_ks + (long)b * A + a] : 0.f;
+    for (int k = 0; k < KQ_PER; ++k) {
+        const int kk = q_g + k * q_ngrp;
+        qp[k] = (kk < p.kq) ? p.qpart[(long)kk * p.q_ks + (long)b * A + q_a] : 0.f;
     }
     const float v_r = p.v[min(tid, A - 1)];
     const float bias_r = p.bias[min(tid, A - 1)];
@@ -108,14 +110,14 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_kernel(AttnStepArgs p) 
         for (int j = 0; j < NU_MAX; ++j) us[j] = p.U[min(tid + j * ATT_THREADS, A * ksz - 1)];
     }
 
-    // ---- q, v, bias, filter bank -> LDS; energy accumulators cleared
-    if (tid < A) {
+    // ---- q partial sums, v, bias, filter bank -> LDS
+    {
         float qs = 0.f;
 #pragma unroll
-        for (int k = 0; k < KQ_MAX; ++k) qs += qp[k];
-        q[tid] = qs; vv[tid] = v_r; bias[tid] = bias_r;
-        if (ch == 0 && p.q_out) p.q_out[(long)b * A + tid] = qs;
+        for (int k = 0; k < KQ_PER; ++k) qs += qp[k];
+        part[tid] = qs;
     }
+    if (tid < A) { vv[tid] = v_r; bias[tid] = bias_r; }
     if (p.PL_next) {
 #pragma unroll
         for (int j = 0; j < NU_MAX; ++j) {
@@ -123,6 +125,13 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_kernel(AttnStepArgs p) 
             if (i < A * ksz) { const int a = i / ksz, jj = i - a * ksz; Up[a * UP_LD + jj] = us[j]; }
         }
         for (int i = tid; i < A * (UP_LD - ksz); i += ATT_THREADS) { const int a = i / (UP_LD - ksz), jj = ksz + i % (UP_LD - ksz); Up[a * UP_LD + jj] = 0.f; }
+    }
+    __syncthreads();
+    if (tid < A) {
+        float qs = 0.f;
+        for (int g = 0; g < q_ngrp; ++g) qs += part[g * A + tid];
+        q[tid] = qs;
+        if (ch == 0 && p.q_out) p.q_out[(long)b * A + tid] = qs;
     }
     __syncthreads();
 
@@ -335,7 +344,7 @@ int attn_step_launch(const AttnStepArgs& p, hipStream_t s) {
     const long la4 = (long)p.L * p.A / 4;
     const bool fast = (p.A == 64 || p.A == 128) && p.L <= ATT_THREADS && la4 <= 16L * ATT_THREADS &&
                       (p.L + ng - 1) / ng <= NC_MAX && lc <= 64 && p.ksz <= 32 && lds_fast <= 64 * 1024 &&
-                      (long)p.A * p.ksz <= (long)NU_MAX * ATT_THREADS && p.kq <= KQ_MAX;
+                      (long)p.A * p.ksz <= (long)NU_MAX * ATT_THREADS && p.kq <= KQ_PER * (ATT_THREADS / p.A);
     const bool small = la4 <= 8L * ATT_THREADS && lc <= 32;
     const dim3 grid(p.B, p.nch), blk(ATT_THREADS);
     if (fast && G == 32 && small) hipLaunchKernelGGL((attn_step_kernel<32, 8>), grid, blk, lds_fast, s, p);

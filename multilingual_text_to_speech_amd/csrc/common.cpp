@@ -31,6 +31,8 @@ MTTS_API int mtts_sizeof_struct(int which) {
         case 9: return (int)sizeof(BiLstmGradArgs);
         case 10: return (int)sizeof(TacoLossArgs);
         case 11: return (int)sizeof(AdamArgs);
+        case 12: return (int)sizeof(LstmPackArgs);
+        case 13: return (int)sizeof(LstmStepArgs);
         default: return -1;
     }
 }

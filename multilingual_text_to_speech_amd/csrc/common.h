@@ -113,3 +113,4 @@ __device__ __forceinline__ float group_sum(float x) {
 int add3(float* out, int ldo, const float* a, int lda, const float* b, int ldb, const float* c3, int ldc, int rows, int cols,
          bool accumulate, hipStream_t s);
 int attn_bwd_plus_skinny(const AttnBwdArgs& a, const SkinnyArgs& k, hipStream_t s);
+int lstm_step_launch(const LstmStepArgs& a, hipStream_t s);

@@ -37,19 +37,39 @@ static SkSeg seg_h(const float* rowmajor, const float* packed, int t, int B, int
 
 // Chain B of the fast schedule for steps [c0, c1): generator-LSTM input gates (batched), the recurrent steps and the
 // frame/stop projection (batched).  Runs on its own low-priority stream behind chain A (see side_stream()).
+static bool gen_uses_lstep(const DecoderArgs& a) {
+    return a.fast && a.gen_w2p && a.gen_bias_u && a.gen_w_ih_u && a.gate_part_gen && (a.H & 31) == 0;
+}
+
 static int gen_chunk(const DecoderArgs& a, int c0, int c1, hipStream_t s) {
     const int B = a.B, M = a.M, H = a.H, Dm = a.Dm;
+    const bool use_ls = gen_uses_lstep(a);
+    const float* w_ih = use_ls ? a.gen_w_ih_u : a.gen_w_ih;      // unit-major rows -> unit-major pre_gen
     const int Mo = round4(M + 1), n = c1 - c0;
     const long BH = (long)B * H, BD = (long)B * Dm, B4H = 4 * BH;
     GemmArgs g; memset(&g, 0, sizeof(g));
     g.taps = 1; g.batch = 1; g.zt = 1; g.alpha = 1.f; g.mask_scale = 1.f; g.nosplit = 1;
     // pre_gen = [h_att, ctx] W_ih^T
-    g.A = a.h_att + (c0 + 1) * BH; g.B = a.gen_w_ih; g.C = a.pre_gen + c0 * B4H;
+    g.A = a.h_att + (c0 + 1) * BH; g.B = w_ih; g.C = a.pre_gen + c0 * B4H;
     g.M = n * B; g.N = 4 * H; g.K = H; g.Kc = H; g.lda = H; g.ldb = H + Dm; g.ldc = 4 * H; g.beta = 0.f;
     MTTS_TRY(mtts_gemm_ex(&g, s));
-    g.A = a.ctx + (c0 + 1) * BD; g.B = a.gen_w_ih + H; g.K = Dm; g.Kc = Dm; g.lda = Dm; g.beta = 1.f;
+    g.A = a.ctx + (c0 + 1) * BD; g.B = w_ih + H; g.K = Dm; g.Kc = Dm; g.lda = Dm; g.beta = 1.f;
     MTTS_TRY(mtts_gemm_ex(&g, s));
     for (int t = c0; t < c1; ++t) {
+        if (use_ls) {
+            LstmStepArgs k; memset(&k, 0, sizeof(k));
+            k.x[0] = a.h_gen + t * BH; k.K[0] = H; k.ldx[0] = H; k.nseg = 1;
+            k.w_packed = a.gen_w2p; k.precision = a.precision; k.B = B; k.H = H; k.partials = a.gate_part_gen;
+            k.pre = a.pre_gen + t * B4H; k.ldpre = 4 * H; k.bias_u = a.gen_bias_u;
+            k.h_prev = a.h_gen + t * BH; k.c_prev = a.c_gen + t * BH;
+            k.h_out = a.h_gen + (t + 1) * BH; k.c_out = a.c_gen + (t + 1) * BH;
+            k.gates_out = a.gates_gen ? a.gates_gen + t * B4H : nullptr;
+            SkinnyArgs r; memset(&r, 0, sizeof(r));
+            lstm_reg(a, r, a.gen_hmask, a.gen_cmask, t);
+            k.hmask = r.hmask; k.cmask = r.cmask; k.hscale = r.hscale; k.zone = r.zone; k.zh = r.zh; k.zc = r.zc;
+            MTTS_TRY(lstm_step_launch(k, s));
+            continue;
+        }
         SkinnyArgs k; memset(&k, 0, sizeof(k));
         k.B = B; k.N = 4 * H; k.ksplit = 1; k.lstm = 1; k.H = H; k.nseg = 1;
         k.seg[0] = seg_h(a.h_gen, a.h_gen_p, t, B, H, a.gen_w_hh, a.gen_w_hh_p, H);
@@ -84,6 +104,9 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
     const float pscale = a.p_prenet > 0.f ? 1.f / (1.f - a.p_prenet) : 1.f;
     const int nsteps = a.t1 - a.t0;
     if (nsteps == 0) return 0;
+    // attention LSTM as K-split gate GEMM + (cell, query partials): see lstm_step.hip
+    const bool use_ls = a.fast && a.att_w2p && a.att_bias_u && a.att_w_pre_u && a.gate_part && (Dm & 31) == 0 && (H & 31) == 0 &&
+                        (A & 15) == 0 && A <= 256;
 
     if (a.t0 == 0) {
         // U = W_loc [A,C] * W_conv [C,ksz];  Mt = memory W_memory^T;  PL[0] = Mt + bias   (attention.py:23-28)
@@ -94,6 +117,22 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
         if (a.att_w_hh_p) MTTS_TRY(mtts_pack_weight(a.att_w_hh, H, 4 * H, H, H, a.att_w_hh_p, s));
         if (a.gen_w_hh_p) MTTS_TRY(mtts_pack_weight(a.gen_w_hh, H, 4 * H, H, H, a.gen_w_hh_p, s));
         if (a.w_query_p) MTTS_TRY(mtts_pack_weight(a.w_query, H, A, H, 0, a.w_query_p, s));
+        if (use_ls) {     // K-split step path: packed [W_ih[:, P:] | W_hh], unit-major bias and hoisted-projection rows
+            LstmPackArgs k; memset(&k, 0, sizeof(k));
+            k.w[0] = a.att_w_ih + P; k.K[0] = Dm; k.ldw[0] = P + Dm;
+            k.w[1] = a.att_w_hh; k.K[1] = H; k.ldw[1] = H;
+            k.nseg = 2; k.H = H; k.precision = a.precision; k.dst = a.att_w2p;
+            k.b_ih = a.att_b_ih; k.b_hh = a.att_b_hh; k.bias_u = a.att_bias_u;
+            MTTS_TRY(mtts_lstm_pack_weights(&k, s));
+            MTTS_TRY(mtts_lstm_rows_unit_major(a.att_w_ih, P + Dm, H, P, a.att_w_pre_u, s));
+        }
+        if (gen_uses_lstep(a)) {
+            LstmPackArgs k; memset(&k, 0, sizeof(k));
+            k.w[0] = a.gen_w_hh; k.K[0] = H; k.ldw[0] = H; k.nseg = 1; k.H = H; k.precision = a.precision; k.dst = a.gen_w2p;
+            k.b_ih = a.gen_b_ih; k.b_hh = a.gen_b_hh; k.bias_u = a.gen_bias_u;
+            MTTS_TRY(mtts_lstm_pack_weights(&k, s));
+            MTTS_TRY(mtts_lstm_rows_unit_major(a.gen_w_ih, H + Dm, H, H + Dm, a.gen_w_ih_u, s));
+        }
     }
 
     // prenet over the teacher frames of this range (tacotron2.py:126-133)
@@ -113,8 +152,8 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
 
     if (a.fast) {
         MTTS_REQUIRE(a.pre_att && a.pre_gen && a.frames_in, "decoder fast path needs pre_att/pre_gen workspaces and frames_in");
-        MTTS_TRY(gemm_plain(pren + a.t0 * BP, a.att_w_ih, a.pre_att + a.t0 * B4H, nsteps * B, 4 * H, P, P, P + Dm, 4 * H, false,
-                            false, 1.f, 0.f, nullptr, 0, s));
+        MTTS_TRY(gemm_plain(pren + a.t0 * BP, use_ls ? a.att_w_pre_u : a.att_w_ih, a.pre_att + a.t0 * B4H, nsteps * B, 4 * H, P, P,
+                            use_ls ? P : P + Dm, 4 * H, false, false, 1.f, 0.f, nullptr, 0, s));
     }
 
     // fast schedule: chain B trails chain A chunk by chunk on the side stream
@@ -135,7 +174,25 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
                 MTTS_TRY(skinny_launch(k, s));
             }
         }
-        {   // attention LSTM (tacotron2.py:184-185)
+        if (use_ls) {   // attention LSTM + query partials (tacotron2.py:184-185, attention.py:68) in two launches
+            LstmStepArgs k; memset(&k, 0, sizeof(k));
+            k.x[0] = a.ctx + t * BD; k.K[0] = Dm; k.ldx[0] = Dm;
+            k.x[1] = a.h_att + t * BH; k.K[1] = H; k.ldx[1] = H;
+            k.nseg = 2; k.w_packed = a.att_w2p; k.precision = a.precision; k.B = B; k.H = H; k.partials = a.gate_part;
+            k.pre = a.pre_att + t * B4H; k.ldpre = 4 * H; k.bias_u = a.att_bias_u;
+            k.h_prev = a.h_att + t * BH; k.c_prev = a.c_att + t * BH;
+            k.h_out = a.h_att + (t + 1) * BH; k.c_out = a.c_att + (t + 1) * BH;
+            k.gates_out = a.gates_att ? a.gates_att + t * B4H : nullptr;
+            {
+                SkinnyArgs r; memset(&r, 0, sizeof(r));
+                lstm_reg(a, r, a.att_hmask, a.att_cmask, t);
+                k.hmask = r.hmask; k.cmask = r.cmask; k.hscale = r.hscale; k.zone = r.zone; k.zh = r.zh; k.zc = r.zc;
+            }
+            k.w_query = a.w_query; k.A = A; k.qpart = a.qpart;
+            const bool sampled = prof_sample(t, s, 0);
+            MTTS_TRY(lstm_step_launch(k, s));
+            if (sampled) prof_sample(t, s, 1);
+        } else {   // attention LSTM (tacotron2.py:184-185)
             SkinnyArgs k; memset(&k, 0, sizeof(k));
             k.B = B; k.N = 4 * H; k.ksplit = 1; k.lstm = 1; k.H = H;
             if (a.fast) {
@@ -159,7 +216,7 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
             MTTS_TRY(skinny_launch(k, s));
             if (sampled) prof_sample(t, s, 1);
         }
-        {   // query projection partials (attention.py:68)
+        if (!use_ls) {   // query projection partials (attention.py:68)
             SkinnyArgs k; memset(&k, 0, sizeof(k));
             k.nseg = 1; k.B = B; k.N = A; k.ksplit = a.kq;
             k.seg[0] = seg_h(a.h_att, a.h_att_p, t + 1, B, H, a.w_query, a.w_query_p, H);
@@ -168,7 +225,7 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
         }
         {   // energies -> softmax -> context, PL for the next step (attention.py:39-45,67-86)
             AttnStepArgs q; memset(&q, 0, sizeof(q));
-            q.qpart = a.qpart; q.kq = a.kq; q.q_ks = (long)B * A;
+            q.qpart = a.qpart; q.kq = use_ls ? H / 16 : a.kq; q.q_ks = (long)B * A;
             q.PL = a.PL + (long)(t & 1) * BL * A; q.PL_next = a.PL + (long)((t + 1) & 1) * BL * A;
             q.Mt = a.Mt; q.U = a.U; q.bias = a.att_bias; q.v = a.w_energy; q.memory = a.memory; q.lengths = a.lengths;
             q.cum_in = a.cum + t * BL; q.cum_out = a.cum + (t + 1) * BL; q.w_out = a.align + t * BL;

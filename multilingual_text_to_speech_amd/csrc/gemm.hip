@@ -497,7 +497,12 @@ MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
     // latency-critical step kernels of the main stream always find room next to it
     static const bool exact_f32 = [] { const char* e = getenv("MTTS_GEMM_EXACT_F32"); return e && e[0] == '1'; }();
     const size_t lds_base = exact_f32 ? 4 * LDS_A * sizeof(float) : (size_t)SP_LDS_B;
-    const size_t lds = p.nosplit ? (size_t)96 * 1024 : lds_base;
+    // Round 1 reserved 96 KiB of LDS for helper-stream launches (one GEMM workgroup per CU, "room" for the step kernels).  Kernel
+    // traces show the step kernels and these GEMMs do not overlap anyway (every step kernel fills all 256 CUs; overlapped time is
+    // < 5 % of the decoder forward), so the reservation only halved the GEMMs' throughput: 92.1 -> 89.5 ms per train step without
+    // it.  MTTS_GEMM_RESERVE_CU=1 restores it for A/B runs.
+    static const bool reserve_cu = [] { const char* e = getenv("MTTS_GEMM_RESERVE_CU"); return e && e[0] == '1'; }();
+    const size_t lds = (p.nosplit && reserve_cu) ? (size_t)96 * 1024 : lds_base;
     hipStream_t s = (hipStream_t)stream;
     static bool attr_done = false;
     if (!attr_done) {   // > 64 KiB of dynamic LDS needs the opt-in attribute

@@ -1,0 +1,409 @@
+// Recurrent LSTM step of the decoder as TWO launches that never re-read the batch operand:
+//
+//   G  lstm_gates_kernel   partial gate pre-activations  P[ks][B][4H] = X[:, kslice] W[:, kslice]^T
+//                          grid = (4H / 128 column tiles) x (KS K-slices); 256 workgroups at H = 1024, KS = 8
+//   C  lstm_cell_q_kernel  sum of the KS partials + hoisted addend + biases -> LSTM cell (dropout / zoneout on h)
+//                          -> h, c, saved gates, and the query projection partials  q_part[ut] = h[:, tile ut] W_q[:, tile ut]^T
+//
+// Replaces, for the attention LSTM of the teacher-forced ("fast") schedule, one skinny_kernel launch (16 gate columns x all
+// rows x the full K per workgroup: every one of 256 workgroups re-read the whole [B, Dm+H] operand from L2, 1.57x the
+// algorithmic bytes on the fabric) plus the separate query-projection launch.  Reference: DropoutLSTMCell / ZoneoutLSTMCell
+// modules/layers.py:18-47 called at modules/tacotron2.py:185, query projection modules/attention.py:68.
+//
+// G is W-stationary and K-split: a workgroup streams its [128 columns x K/KS] weight slice HBM -> VGPR exactly once (packed
+// per call into wave-tile order by mtts_lstm_pack_weights: 1 KiB contiguous per wave instruction), stages the matching
+// [64 rows x K/KS] slice of X through LDS once for all eight waves, and for batches above 64 rows loops over row tiles with
+// the weights still in registers.  Workgroups that share a K-slice have the same blockIdx % 8, i.e. sit on one XCD and
+// share that slice of X in its L2.
+// Arithmetic: fp32 operands are split exactly into three bf16 planes (x = x1 + x2 + x3, see gemm.hip) and every product is
+// evaluated as six v_mfma_f32_16x16x32_bf16 terms with fp32 accumulation (precision 0), or operands are rounded to one
+// bf16 plane (precision 1: the bf16 path, weights stored as bf16).
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+constexpr int LS_THREADS = 512;
+constexpr int LS_COLS = 128;         // gate columns per workgroup = 8 waves x 16
+constexpr int LS_MAXKB = 7;          // 32-wide k-blocks per K-slice (weights of a slice stay in registers)
+constexpr int LS_PLANE_B = 64 * 64;  // one k-block of one plane in LDS: 64 rows x 32 bf16
+constexpr int LS_MIN_KS = 8;
+
+static inline int ls_ksplit(int nkb) { const int need = (nkb + LS_MAXKB - 1) / LS_MAXKB; return need > LS_MIN_KS ? need : LS_MIN_KS; }
+
+__device__ __forceinline__ unsigned bf16_rne(float x) {      // upper 16 bits of the RNE-rounded value
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+// exact 3-way split of two floats into three packed bf16 pairs (truncation; residuals are exact in fp32)
+__device__ __forceinline__ void ls_split_pair(float x, float y, unsigned& p1, unsigned& p2, unsigned& p3) {
+    const unsigned ux = __float_as_uint(x), uy = __float_as_uint(y);
+    const float rx = x - __uint_as_float(ux & 0xffff0000u), ry = y - __uint_as_float(uy & 0xffff0000u);
+    const unsigned vx = __float_as_uint(rx), vy = __float_as_uint(ry);
+    const float sx = rx - __uint_as_float(vx & 0xffff0000u), sy = ry - __uint_as_float(vy & 0xffff0000u);
+    p1 = __builtin_amdgcn_perm(uy, ux, 0x07060302u);
+    p2 = __builtin_amdgcn_perm(vy, vx, 0x07060302u);
+    p3 = __builtin_amdgcn_perm(__float_as_uint(sy), __float_as_uint(sx), 0x07060302u);
+}
+
+union Frag8 { bf16x8 v; unsigned u[4]; };
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// weight packing (once per decoder call)
+// fp32 layout:  [col tile j][wave w][k-block kb][half h][lane][4]   lane = 16 q + i holds W[col(j, w, i)][32 kb + 8 q + 4 h + e]
+// bf16 layout:  [col tile j][wave w][k-block kb][lane][8]           lane = 16 q + i holds W[col(j, w, i)][32 kb + 8 q + e]
+// LSTM column order (unit-major): col(j, w, i) = gate (i & 3) of unit 32 j + 4 w + (i >> 2)  ->  source row (i & 3) H + unit
+// ---------------------------------------------------------------------------------------------------------------------------
+struct LsPack {
+    const float* w0; const float* w1; const float* w2;
+    int K0, K1, K2, ld0, ld1, ld2;
+    int H, nkb, precision;
+    void* dst;
+};
+
+__device__ __forceinline__ float ls_pack_src(const LsPack& p, int row, int k) {
+    if (k < p.K0) return p.w0[(long)row * p.ld0 + k];
+    k -= p.K0;
+    if (k < p.K1) return p.w1[(long)row * p.ld1 + k];
+    k -= p.K1;
+    return p.w2[(long)row * p.ld2 + k];
+}
+
+__global__ void lstm_pack_kernel(LsPack p) {
+    const long total = (long)4 * p.H * p.nkb * 32;
+    const long n = p.precision ? total / 8 : total / 4;          // one lane-quantum (16 B) per thread
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+        int lane, h = 0; long rest;
+        if (p.precision) { lane = (int)(t & 63); rest = t >> 6; }
+        else { lane = (int)(t & 63); h = (int)((t >> 6) & 1); rest = t >> 7; }
+        const int kb = (int)(rest % p.nkb); const long jw = rest / p.nkb;
+        const int w = (int)(jw & 7), j = (int)(jw >> 3);
+        const int i = lane & 15, q = lane >> 4;
+        const int row = (i & 3) * p.H + 32 * j + 4 * w + (i >> 2);
+        const int k = 32 * kb + 8 * q + 4 * h;
+        if (p.precision) {
+            unsigned o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = bf16_rne(ls_pack_src(p, row, k + 2 * e)) | (bf16_rne(ls_pack_src(p, row, k + 2 * e + 1)) << 16);
+            reinterpret_cast<uint4*>(p.dst)[t] = make_uint4(o[0], o[1], o[2], o[3]);
+        } else {
+            reinterpret_cast<float4*>(p.dst)[t] = make_float4(ls_pack_src(p, row, k), ls_pack_src(p, row, k + 1), ls_pack_src(p, row, k + 2),
+                                                               ls_pack_src(p, row, k + 3));
+        }
+    }
+}
+
+// dst[(4 u + g) * K + k] = src[(g H + u) * ld + k]   (rows of a [4H, K] LSTM matrix into unit-major order; K = 1: a bias vector,
+// optionally the sum of two)
+__global__ void lstm_rows_unit_major_kernel(const float* __restrict__ src, const float* __restrict__ src2, int ld, int H, int K,
+                                            float* __restrict__ dst) {
+    const long total = (long)4 * H * K;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const long r = t / K; const int k = (int)(t - r * K);
+        const int u = (int)(r >> 2), g = (int)(r & 3);
+        const long s = ((long)g * H + u) * ld + k;
+        dst[t] = src[s] + (src2 ? src2[s] : 0.f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// G: partial gate GEMM
+// ---------------------------------------------------------------------------------------------------------------------------
+struct LsGates {
+    const float* x0; const float* x1; const float* x2;
+    int K0, K1, K2, ld0, ld1, ld2;
+    const void* wp;
+    int nkb, KS, B, N;
+    float* part;          // [KS][B][N]
+};
+
+template <int PREC>
+__global__ __launch_bounds__(LS_THREADS) void lstm_gates_kernel(LsGates p) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    constexpr int NPL = PREC ? 1 : 3;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s = blockIdx.x % p.KS, j = blockIdx.x / p.KS;
+    const int kb0 = (int)((long)s * p.nkb / p.KS), kb1 = (int)((long)(s + 1) * p.nkb / p.KS);
+    const int nb = kb1 - kb0;
+    const int i16 = lane & 15, q4 = lane >> 4;
+
+    const int srow = tid >> 3, sk4 = tid & 7;           // staging: 8 threads cover the 32 k of one row
+    const int n_row_tiles = (p.B + 63) >> 6;
+    // X slice of a row tile: one float4 per thread and k-block (row-major fp32 in global memory; mostly L2 hits)
+    auto load_x = [&](int row0, float4 (&xv)[LS_MAXKB]) {
+        const int rowc = min(row0 + srow, p.B - 1);
+#pragma unroll
+        for (int kb = 0; kb < LS_MAXKB; ++kb) {
+            int kg = 32 * (kb0 + (kb < nb ? kb : 0));
+            const float* xs; int ld;
+            if (kg < p.K0) { xs = p.x0; ld = p.ld0; }
+            else if (kg < p.K0 + p.K1) { xs = p.x1; ld = p.ld1; kg -= p.K0; }
+            else { xs = p.x2; ld = p.ld2; kg -= p.K0 + p.K1; }
+            xv[kb] = *reinterpret_cast<const float4*>(xs + (long)rowc * ld + kg + 4 * sk4);
+        }
+    };
+    float4 xv[LS_MAXKB];
+    load_x(0, xv);                                      // requested BEFORE the weights: it gates the first MFMA
+
+    // ---- this wave's weight slice -> registers (one or two 16-byte loads per lane and k-block, 1 KiB contiguous per
+    //      instruction); requested in k order and consumed in k order, so block kb's MFMAs start while later blocks still stream
+    float4 wr[LS_MAXKB][PREC ? 1 : 2];
+    {
+        const float4* src = reinterpret_cast<const float4*>(p.wp) + ((long)(j * 8 + wave) * p.nkb + kb0) * (PREC ? 64 : 128) + lane;
+#pragma unroll
+        for (int kb = 0; kb < LS_MAXKB; ++kb) {
+            const int kc = kb < nb ? kb : 0;        // clamped: unused blocks re-read block 0 (never consumed)
+            wr[kb][0] = src[(long)kc * (PREC ? 64 : 128)];
+            if (!PREC) wr[kb][1] = src[(long)kc * 128 + 64];
+        }
+    }
+
+    for (int rt = 0; rt < n_row_tiles; ++rt) {
+        const int row0 = rt * 64;
+        // ---- X slice of this row tile -> bf16 plane(s) in LDS
+        {
+            if (rt > 0) { load_x(row0, xv); __syncthreads(); }     // the previous row tile's fragments have been consumed
+            char* dst = sm + srow * 64 + (((sk4 >> 1) ^ ((srow >> 2) & 3)) * 16) + (sk4 & 1) * 8;
+#pragma unroll
+            for (int kb = 0; kb < LS_MAXKB; ++kb) {
+                if (kb >= nb) break;
+                if (PREC) {
+                    const unsigned a = bf16_rne(xv[kb].x) | (bf16_rne(xv[kb].y) << 16), b = bf16_rne(xv[kb].z) | (bf16_rne(xv[kb].w) << 16);
+                    *reinterpret_cast<uint2*>(dst + kb * LS_PLANE_B) = make_uint2(a, b);
+                } else {
+                    unsigned a1, a2, a3, b1, b2, b3;
+                    ls_split_pair(xv[kb].x, xv[kb].y, a1, a2, a3);
+                    ls_split_pair(xv[kb].z, xv[kb].w, b1, b2, b3);
+                    *reinterpret_cast<uint2*>(dst + (0 * LS_MAXKB + kb) * LS_PLANE_B) = make_uint2(a1, b1);
+                    *reinterpret_cast<uint2*>(dst + (1 * LS_MAXKB + kb) * LS_PLANE_B) = make_uint2(a2, b2);
+                    *reinterpret_cast<uint2*>(dst + (2 * LS_MAXKB + kb) * LS_PLANE_B) = make_uint2(a3, b3);
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- 16 columns x up to 64 rows per wave
+        const int mt_n = min(4, (p.B - row0 + 15) >> 4);
+        f32x4 acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int a_off = i16 * 64 + ((q4 ^ ((i16 >> 2) & 3)) * 16);
+#pragma unroll
+        for (int kb = 0; kb < LS_MAXKB; ++kb) {
+            if (kb >= nb) break;
+            Frag8 wb[NPL];
+            if (PREC) {
+                wb[0].u[0] = __float_as_uint(wr[kb][0].x); wb[0].u[1] = __float_as_uint(wr[kb][0].y);
+                wb[0].u[2] = __float_as_uint(wr[kb][0].z); wb[0].u[3] = __float_as_uint(wr[kb][0].w);
+            } else {
+                ls_split_pair(wr[kb][0].x, wr[kb][0].y, wb[0].u[0], wb[1].u[0], wb[2].u[0]);
+                ls_split_pair(wr[kb][0].z, wr[kb][0].w, wb[0].u[1], wb[1].u[1], wb[2].u[1]);
+                ls_split_pair(wr[kb][1].x, wr[kb][1].y, wb[0].u[2], wb[1].u[2], wb[2].u[2]);
+                ls_split_pair(wr[kb][1].z, wr[kb][1].w, wb[0].u[3], wb[1].u[3], wb[2].u[3]);
+            }
+            // two row tiles at a time: their accumulators alternate, so no MFMA waits for the one issued just before it
+#pragma unroll
+            for (int mp = 0; mp < 4; mp += 2) {
+                if (mp >= mt_n) break;
+                bf16x8 a[2][NPL];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int pl = 0; pl < NPL; ++pl)
+                        a[m][pl] = *reinterpret_cast<const bf16x8*>(sm + (pl * LS_MAXKB + kb) * LS_PLANE_B + min(mp + m, mt_n - 1) * 1024 + a_off);
+#define LS_MM(PA, PB)                                                                                            \
+    _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                               \
+        acc[mp + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][PA], wb[PB].v, acc[mp + m], 0, 0, 0);
+                if (PREC) { LS_MM(0, 0) }
+                else { LS_MM(2, 0) LS_MM(0, 2) LS_MM(1, 1) LS_MM(1, 0) LS_MM(0, 1) LS_MM(0, 0) }      // small terms first
+            }
+#undef LS_MM
+        }
+        // ---- partial slab: D layout col = lane & 15, row = 4 (lane >> 4) + r
+        const int col = j * LS_COLS + wave * 16 + i16;
+        if (col < p.N) {
+            float* out = p.part + ((long)s * p.B) * p.N + col;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = row0 + 16 * m + 4 * q4 + r;
+                    if (row < p.B) out[(long)row * p.N] = acc[m][r];
+                }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// C: partial sum + LSTM cell + query partials.  Workgroup = 16 units x 16 rows, thread = one (row, unit).
+// ---------------------------------------------------------------------------------------------------------------------------
+struct LsCell {
+    const float* part; int KS, B, H;
+    const float* pre; int ldpre;          // unit-major [B, 4H] or NULL
+    const float* bias_u;                  // unit-major [4H] (b_ih + b_hh) or NULL
+    const float* h_prev; const float* c_prev;
+    float* h_out; float* c_out; float* gates_out;
+    const uint8_t* hmask; const uint8_t* cmask;
+    float hscale; int zone; float zh, zc;
+    const float* wq; int A; float* qpart;  // [H/16][B][A] or NULL
+};
+
+constexpr int LC_MAXCT = 4;      // query column tiles per wave: A <= 4 waves x 4 x 16 = 256
+
+__global__ __launch_bounds__(256) void lstm_cell_q_kernel(LsCell p) {
+    __shared__ float hs[16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ut = blockIdx.x, rt = blockIdx.y;
+    const int r = tid >> 4, uu = tid & 15;
+    const int row = 16 * rt + r, u = 16 * ut + uu;
+    const bool valid = row < p.B;
+    const int rowc = valid ? row : p.B - 1;
+    const int N = 4 * p.H;
+    const int i16 = lane & 15, q4 = lane >> 4;
+
+    // query-projection operand of this wave (independent of everything else: requested first)
+    float4 wq4[LC_MAXCT];
+    const int nct = p.wq ? p.A >> 4 : 0;
+#pragma unroll
+    for (int c = 0; c < LC_MAXCT; ++c) {
+        const int ct = wave + 4 * c;
+        wq4[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ct < nct) wq4[c] = *reinterpret_cast<const float4*>(p.wq + (long)(16 * ct + i16) * p.H + 16 * ut + 4 * q4);
+    }
+
+    const long hi = (long)rowc * p.H + u;
+    float4 g4 = p.bias_u ? *reinterpret_cast<const float4*>(p.bias_u + 4 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 pre4 = p.pre ? *reinterpret_cast<const float4*>(p.pre + (long)rowc * p.ldpre + 4 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float cp = p.c_prev[hi];
+    const float hp = p.h_prev ? p.h_prev[hi] : 0.f;
+    const int hm = p.hmask ? (int)p.hmask[hi] : 1, cm = p.cmask ? (int)p.cmask[hi] : 1;
+    const float* ps = p.part + (long)rowc * N + 4 * u;
+    const long slab = (long)p.B * N;
+    float4 pv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pv[k] = *reinterpret_cast<const float4*>(ps + (long)min(k, p.KS - 1) * slab);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (k < p.KS) { g4.x += pv[k].x; g4.y += pv[k].y; g4.z += pv[k].z; g4.w += pv[k].w; }
+    for (int k = 8; k < p.KS; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(ps + (long)k * slab);
+        g4.x += v.x; g4.y += v.y; g4.z += v.z; g4.w += v.w;
+    }
+    g4.x += pre4.x; g4.y += pre4.y; g4.z += pre4.z; g4.w += pre4.w;
+
+    const float ig = sigmoidf_(g4.x), fg = sigmoidf_(g4.y), gg = tanhf_(g4.z), og = sigmoidf_(g4.w);
+    const float cn = fg * cp + ig * gg;
+    const float hn = og * tanhf_(cn);
+    float ho, co = cn;
+    if (p.zone == 1) { ho = hm ? hn : hp; co = cm ? cn : cp; }
+    else if (p.zone == 2) { ho = p.zh * hp + (1.f - p.zh) * hn; co = p.zc * cp + (1.f - p.zc) * cn; }
+    else ho = p.hmask ? (hm ? hn * p.hscale : 0.f) : hn;
+    if (valid) {
+        p.h_out[hi] = ho;
+        p.c_out[hi] = co;
+        if (p.gates_out) {
+            float* go = p.gates_out + (long)row * N + u;
+            go[0] = ig; go[p.H] = fg; go[2 * p.H] = gg; go[3 * p.H] = og;
+        }
+    }
+    if (!p.qpart) return;
+    hs[r][uu] = valid ? ho : 0.f;
+    __syncthreads();
+    // q_part[ut][rows of this workgroup][A] = h_tile [16 x 16] W_q[:, 16 ut .. +16]^T on v_mfma_f32_16x16x4_f32 (exact fp32)
+    const float av[4] = {hs[i16][4 * q4 + 0], hs[i16][4 * q4 + 1], hs[i16][4 * q4 + 2], hs[i16][4 * q4 + 3]};
+#pragma unroll
+    for (int c = 0; c < LC_MAXCT; ++c) {
+        const int ct = wave + 4 * c;
+        if (ct >= nct) break;
+        const float bv[4] = {wq4[c].x, wq4[c].y, wq4[c].z, wq4[c].w};
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bv[s2], acc, 0, 0, 0);
+        float* out = p.qpart + ((long)ut * p.B) * p.A + 16 * ct + i16;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int orow = 16 * rt + 4 * q4 + rr;
+            if (orow < p.B) out[(long)orow * p.A] = acc[rr];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------------
+static int ls_check_segs(int nseg, const int* K, const int* ld, const char* what) {
+    MTTS_REQUIRE(nseg >= 1 && nseg <= 3, "%s: 1..3 K segments", what);
+    for (int i = 0; i < nseg; ++i)
+        MTTS_REQUIRE(K[i] > 0 && (K[i] & 31) == 0 && (ld[i] & 3) == 0, "%s: segment %d needs K %% 32 == 0 and ld %% 4 == 0 (K=%d ld=%d)", what, i,
+                     K[i], ld[i]);
+    return 0;
+}
+
+MTTS_API int mtts_lstm_step_ksplit(int k_total) { return ls_ksplit((k_total + 31) / 32); }
+
+MTTS_API long mtts_lstm_step_partial_floats(int B, int H, int k_total) { return (long)mtts_lstm_step_ksplit(k_total) * B * 4 * H; }
+
+MTTS_API long mtts_lstm_packed_weight_bytes(int H, int k_total, int precision) {
+    return (long)4 * H * k_total * (precision ? 2 : 4);
+}
+
+MTTS_API int mtts_lstm_pack_weights(const LstmPackArgs* args, void* stream) {
+    const LstmPackArgs& a = *args;
+    MTTS_TRY(ls_check_segs(a.nseg, a.K, a.ldw, "mtts_lstm_pack_weights"));
+    MTTS_REQUIRE(a.H > 0 && (a.H & 31) == 0, "mtts_lstm_pack_weights: H must be a multiple of 32 (H=%d)", a.H);
+    LsPack p; memset(&p, 0, sizeof(p));
+    p.w0 = a.w[0]; p.K0 = a.K[0]; p.ld0 = a.ldw[0];
+    p.w1 = a.nseg > 1 ? a.w[1] : a.w[0]; p.K1 = a.nseg > 1 ? a.K[1] : 0; p.ld1 = a.nseg > 1 ? a.ldw[1] : 0;
+    p.w2 = a.nseg > 2 ? a.w[2] : a.w[0]; p.K2 = a.nseg > 2 ? a.K[2] : 0; p.ld2 = a.nseg > 2 ? a.ldw[2] : 0;
+    p.H = a.H; p.nkb = (p.K0 + p.K1 + p.K2) / 32; p.precision = a.precision; p.dst = a.dst;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(lstm_pack_kernel, dim3(2048), dim3(256), 0, s, p);
+    MTTS_CHECK_LAUNCH("lstm_pack_kernel");
+    if (a.bias_u) {
+        MTTS_REQUIRE(a.b_ih, "mtts_lstm_pack_weights: bias_u needs b_ih");
+        hipLaunchKernelGGL(lstm_rows_unit_major_kernel, dim3(16), dim3(256), 0, s, a.b_ih, a.b_hh, 1, a.H, 1, a.bias_u);
+        MTTS_CHECK_LAUNCH("lstm_rows_unit_major_kernel");
+    }
+    return 0;
+}
+
+MTTS_API int mtts_lstm_rows_unit_major(const float* src, int ld, int H, int K, float* dst, void* stream) {
+    hipLaunchKernelGGL(lstm_rows_unit_major_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, src, (const float*)nullptr, ld, H, K, dst);
+    MTTS_CHECK_LAUNCH("lstm_rows_unit_major_kernel");
+    return 0;
+}
+
+int lstm_step_launch(const LstmStepArgs& a, hipStream_t s) {
+    MTTS_TRY(ls_check_segs(a.nseg, a.K, a.ldx, "mtts_lstm_step_fwd"));
+    MTTS_REQUIRE(a.B > 0 && a.H > 0 && (a.H & 31) == 0, "mtts_lstm_step_fwd: H must be a multiple of 32 (H=%d)", a.H);
+    MTTS_REQUIRE(a.w_packed && a.partials && a.c_prev && a.h_out && a.c_out, "mtts_lstm_step_fwd: missing buffers");
+    MTTS_REQUIRE(!a.qpart || (a.w_query && (a.A & 15) == 0 && a.A <= 16 * 4 * LC_MAXCT), "mtts_lstm_step_fwd: query partials need A %% 16 == 0, A <= %d",
+                 16 * 4 * LC_MAXCT);
+    for (int i = 0; i < a.nseg; ++i) MTTS_REQUIRE(((uintptr_t)a.x[i] & 15) == 0, "mtts_lstm_step_fwd: x[%d] must be 16-byte aligned", i);
+    LsGates g; memset(&g, 0, sizeof(g));
+    g.x0 = a.x[0]; g.K0 = a.K[0]; g.ld0 = a.ldx[0];
+    g.x1 = a.nseg > 1 ? a.x[1] : a.x[0]; g.K1 = a.nseg > 1 ? a.K[1] : 0; g.ld1 = a.nseg > 1 ? a.ldx[1] : a.ldx[0];
+    g.x2 = a.nseg > 2 ? a.x[2] : a.x[0]; g.K2 = a.nseg > 2 ? a.K[2] : 0; g.ld2 = a.nseg > 2 ? a.ldx[2] : a.ldx[0];
+    g.wp = a.w_packed; g.nkb = (g.K0 + g.K1 + g.K2) / 32; g.KS = ls_ksplit(g.nkb); g.B = a.B; g.N = 4 * a.H; g.part = a.partials;
+    const int ntile = (4 * a.H) / LS_COLS;
+    static bool attr_done = false;
+    if (!attr_done) {
+        MTTS_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_gates_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * LS_MAXKB * LS_PLANE_B));
+        attr_done = true;
+    }
+    if (a.precision) hipLaunchKernelGGL(lstm_gates_kernel<1>, dim3(ntile * g.KS), dim3(LS_THREADS), LS_MAXKB * LS_PLANE_B, s, g);
+    else hipLaunchKernelGGL(lstm_gates_kernel<0>, dim3(ntile * g.KS), dim3(LS_THREADS), 3 * LS_MAXKB * LS_PLANE_B, s, g);
+    MTTS_CHECK_LAUNCH("lstm_gates_kernel");
+    LsCell c; memset(&c, 0, sizeof(c));
+    c.part = a.partials; c.KS = g.KS; c.B = a.B; c.H = a.H; c.pre = a.pre; c.ldpre = a.ldpre; c.bias_u = a.bias_u;
+    c.h_prev = a.h_prev; c.c_prev = a.c_prev; c.h_out = a.h_out; c.c_out = a.c_out; c.gates_out = a.gates_out;
+    c.hmask = a.hmask; c.cmask = a.cmask; c.hscale = a.hscale; c.zone = a.zone; c.zh = a.zh; c.zc = a.zc;
+    c.wq = a.qpart ? a.w_query : nullptr; c.A = a.A; c.qpart = a.qpart;
+    MTTS_REQUIRE(!(c.zone && !c.h_prev), "mtts_lstm_step_fwd: zoneout needs h_prev");
+    hipLaunchKernelGGL(lstm_cell_q_kernel, dim3(a.H / 16, (a.B + 15) / 16), dim3(256), 0, s, c);
+    MTTS_CHECK_LAUNCH("lstm_cell_q_kernel");
+    return 0;
+}
+
+MTTS_API int mtts_lstm_step_fwd(const LstmStepArgs* args, void* stream) { return lstm_step_launch(*args, (hipStream_t)stream); }

@@ -18,7 +18,7 @@ def _round4(x):
 class DecoderState:
     """Device buffers of one decode (time-major, see DecoderArgs in include/mtts.h)."""
 
-    def __init__(self, B, L, T, dims, device, n_prenet, save_gates=True, fast=False, kq=8):
+    def __init__(self, B, L, T, dims, device, n_prenet, save_gates=True, fast=False, kq=8, precision=0):
         M, P, H, A, Dm, ksz, C = dims
         self.B, self.L, self.T, self.dims, self.n_prenet, self.kq, self.fast = B, L, T, dims, n_prenet, kq, fast
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
@@ -26,7 +26,20 @@ class DecoderState:
         self.Mo = _round4(M + 1)
         self.prenet_act = [e(T, B, P) for _ in range(n_prenet)]
         self.U, self.Mt, self.PL = e(A, ksz), e(B, L, A), e(2, B, L, A)
-        self.qpart = e(kq, B, A)
+        # K-split step path of the attention LSTM (csrc/lstm_step.hip): query partials come in H/16 slabs
+        self.precision = int(precision)
+        self.use_lstep = bool(fast and os.environ.get('MTTS_NO_LSTEP', '0') != '1' and Dm % 32 == 0 and H % 32 == 0 and A % 16 == 0 and A <= 256)
+        self.qpart = e(max(kq, H // 16) if self.use_lstep else kq, B, A)
+        self.att_w2p = self.att_bias_u = self.att_w_pre_u = self.gate_part = None
+        self.gen_w2p = self.gen_bias_u = self.gen_w_ih_u = self.gate_part_gen = None
+        if fast and os.environ.get('MTTS_NO_LSTEP', '0') not in ('1', 'gen') and H % 32 == 0:
+            self.gen_w2p = torch.empty(int(lib().mtts_lstm_packed_weight_bytes(H, H, self.precision)), dtype=torch.uint8, device=device)
+            self.gen_bias_u, self.gen_w_ih_u = e(4 * H), e(4 * H, H + Dm)
+            self.gate_part_gen = e(int(lib().mtts_lstm_step_partial_floats(B, H, H)))
+        if self.use_lstep:
+            self.att_w2p = torch.empty(int(lib().mtts_lstm_packed_weight_bytes(H, Dm + H, self.precision)), dtype=torch.uint8, device=device)
+            self.att_bias_u, self.att_w_pre_u = e(4 * H), e(4 * H, P)
+            self.gate_part = e(int(lib().mtts_lstm_step_partial_floats(B, H, Dm + H)))
         # only slot 0 (the initial state) is read before it is written: no need to clear ~1 GB per decode
         def z0(*s):
             t = e(*s)
@@ -54,7 +67,7 @@ class DecoderState:
         self.att_w_hh_p = e(4 * H * H) if hp_ok else None
         self.gen_w_hh_p = e(4 * H * H) if hp_ok else None
         self.w_query_p = e(((A + 15) & ~15) * H) if hp_ok else None
-        self._args = (B, L, dims, device, n_prenet, save_gates, fast, kq)
+        self._args = (B, L, dims, device, n_prenet, save_gates, fast, kq, precision)
 
     _PER_STEP = ('prenet_act', 'h_att', 'c_att', 'h_gen', 'c_gen', 'ctx', 'cum', 'align', 'gates_att', 'gates_gen', 'out', 'pre_att',
                  'pre_gen', 'q_all', 'h_att_p', 'h_gen_p', 'ctx_p')
@@ -62,8 +75,8 @@ class DecoderState:
     def grown(self, T):
         """A state with room for T steps that continues this one: every per-step array keeps its first slots (free-running
         synthesis allocates geometrically instead of hp.max_output_length = 5000 frames up front)."""
-        B, L, dims, device, n_prenet, save_gates, fast, kq = self._args
-        new = DecoderState(B, L, T, dims, device, n_prenet, save_gates, fast, kq)
+        B, L, dims, device, n_prenet, save_gates, fast, kq, precision = self._args
+        new = DecoderState(B, L, T, dims, device, n_prenet, save_gates, fast, kq, precision)
         for name in self._PER_STEP:
             old, cur = getattr(self, name), getattr(new, name)
             if old is None:
@@ -73,7 +86,8 @@ class DecoderState:
                     c[:o.shape[0]].copy_(o)
             else:
                 cur[:old.shape[0]].copy_(old)
-        for name in ('U', 'Mt', 'PL', 'qpart', 'att_w_ctx_p', 'att_w_hh_p', 'gen_w_hh_p', 'w_query_p'):      # per-call constants
+        for name in ('U', 'Mt', 'PL', 'qpart', 'att_w_ctx_p', 'att_w_hh_p', 'gen_w_hh_p', 'w_query_p', 'att_w2p', 'att_bias_u', 'att_w_pre_u',
+                     'gate_part', 'gen_w2p', 'gen_bias_u', 'gen_w_ih_u', 'gate_part_gen'):      # per-call constants
             setattr(new, name, getattr(self, name))
         return new
 
@@ -99,9 +113,9 @@ def fill_decoder_args(a, st, w, memory, lengths32, frames_in, teacher_host, mask
     a.gen_hmask, a.gen_cmask = ptr(masks.get('gen_h')), ptr(masks.get('gen_c'))
     for name in ('U', 'Mt', 'PL', 'qpart', 'h_att', 'c_att', 'h_gen', 'c_gen', 'ctx', 'cum', 'align', 'gates_att', 'gates_gen',
                  'out', 'pre_att', 'pre_gen', 'q_all', 'h_att_p', 'h_gen_p', 'ctx_p', 'att_w_ctx_p', 'att_w_hh_p', 'gen_w_hh_p',
-                 'w_query_p'):
+                 'w_query_p', 'att_w2p', 'att_bias_u', 'att_w_pre_u', 'gate_part', 'gen_w2p', 'gen_bias_u', 'gen_w_ih_u', 'gate_part_gen'):
         setattr(a, name, ptr(getattr(st, name)))
-    a.kq, a.fast = st.kq, int(st.fast)
+    a.kq, a.fast, a.precision = st.kq, int(st.fast), st.precision
     return a
 
 
@@ -158,7 +172,8 @@ class DecoderFn(torch.autograd.Function):
         dev = memory.device
         teacher = [bool(x) for x in teacher]
         fast = all(teacher) and cfg.get('allow_fast', True)
-        st = DecoderState(B, L, T, (M, P, H, A, Dm, ksz, C), dev, n_prenet, save_gates=True, fast=fast, kq=cfg.get('kq', 8))
+        st = DecoderState(B, L, T, (M, P, H, A, Dm, ksz, C), dev, n_prenet, save_gates=True, fast=fast, kq=cfg.get('kq', 8),
+                          precision=cfg.get('precision', 0))
         # frame fed at step t: zero frame at t=0, target[t-1] afterwards (tacotron2.py:129-131), time-major
         frames_in = torch.zeros(T, B, M, dtype=torch.float32, device=dev)
         frames_in[1:] = target[:, :T - 1].transpose(0, 1)

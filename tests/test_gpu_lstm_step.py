@@ -1,0 +1,147 @@
+"""mtts_lstm_step_fwd (csrc/lstm_step.hip): K-split gate GEMM + (partial sum, LSTM cell, query partials) against a plain
+torch fp64 / fp32 restatement of torch.nn.LSTMCell + dropout / zoneout (reference modules/layers.py:18-47) and of the
+attention query projection (modules/attention.py:68)."""
+import ctypes
+
+import pytest
+import torch
+
+from multilingual_text_to_speech_amd import _C
+from multilingual_text_to_speech_amd._C import check, lib, ptr, stream_ptr
+
+pytestmark = pytest.mark.gpu
+
+
+def run_step(B, H, Ks, A, precision, zone=0, seed=0, with_pre=True, with_q=True):
+    g = torch.Generator().manual_seed(seed)
+    dev = 'cuda'
+    xs = [torch.randn(B, K, generator=g).to(dev) for K in Ks]
+    ws = [(torch.randn(4 * H, K, generator=g) / sum(Ks) ** 0.5).to(dev) for K in Ks]
+    b_ih, b_hh = torch.randn(4 * H, generator=g).to(dev), torch.randn(4 * H, generator=g).to(dev)
+    pre = torch.randn(B, 4 * H, generator=g).to(dev) if with_pre else None       # gate-major, like the reference's gates
+    h_prev, c_prev = torch.randn(B, H, generator=g).to(dev), torch.randn(B, H, generator=g).to(dev)
+    wq = (torch.randn(A, H, generator=g) / H ** 0.5).to(dev)
+    hmask = (torch.rand(B, H, generator=g) >= 0.1).to(torch.uint8).to(dev)
+    cmask = (torch.rand(B, H, generator=g) >= 0.1).to(torch.uint8).to(dev)
+    Kt = sum(Ks)
+    L = lib()
+    packed = torch.empty(int(L.mtts_lstm_packed_weight_bytes(H, Kt, precision)), dtype=torch.uint8, device=dev)
+    bias_u = torch.empty(4 * H, device=dev)
+    pk = _C.LstmPackArgs()
+    for i, w in enumerate(ws):
+        pk.w[i], pk.K[i], pk.ldw[i] = w.data_ptr(), Ks[i], Ks[i]
+    pk.nseg, pk.H, pk.precision, pk.dst = len(Ks), H, precision, ptr(packed)
+    pk.b_ih, pk.b_hh, pk.bias_u = ptr(b_ih), ptr(b_hh), ptr(bias_u)
+    check(L.mtts_lstm_pack_weights(ctypes.byref(pk), stream_ptr()), 'pack')
+    pre_u = None
+    if pre is not None:      # unit-major columns 4u + g
+        pre_u = pre.view(B, 4, H).permute(0, 2, 1).reshape(B, 4 * H).contiguous()
+    a = _C.LstmStepArgs()
+    for i, x in enumerate(xs):
+        a.x[i], a.K[i], a.ldx[i] = x.data_ptr(), Ks[i], Ks[i]
+    a.nseg, a.w_packed, a.precision, a.B, a.H = len(Ks), ptr(packed), precision, B, H
+    part = torch.full((int(L.mtts_lstm_step_partial_floats(B, H, Kt)),), float('nan'), device=dev)
+    h_out, c_out = torch.full((B, H), float('nan'), device=dev), torch.full((B, H), float('nan'), device=dev)
+    gates = torch.full((B, 4 * H), float('nan'), device=dev)
+    qpart = torch.full((H // 16, B, A), float('nan'), device=dev)
+    a.partials, a.pre, a.ldpre, a.bias_u = ptr(part), ptr(pre_u), 4 * H, ptr(bias_u)
+    a.h_prev, a.c_prev, a.h_out, a.c_out, a.gates_out = ptr(h_prev), ptr(c_prev), ptr(h_out), ptr(c_out), ptr(gates)
+    a.zone = zone
+    if zone == 0:
+        a.hmask, a.hscale = ptr(hmask), 1.0 / 0.9
+    elif zone == 1:
+        a.hmask, a.cmask = ptr(hmask), ptr(cmask)
+    else:
+        a.zh, a.zc = 0.1, 0.15
+    if with_q:
+        a.w_query, a.A, a.qpart = ptr(wq), A, ptr(qpart)
+    check(L.mtts_lstm_step_fwd(ctypes.byref(a), stream_ptr()), 'lstm_step')
+    torch.cuda.synchronize()
+
+    # ---- reference (fp64)
+    d = lambda t: t.double()
+    if precision:
+        rb = lambda t: t.to(torch.bfloat16).double()
+        z = sum(rb(x) @ rb(w).t() for x, w in zip(xs, ws))
+    else:
+        z = sum(d(x) @ d(w).t() for x, w in zip(xs, ws))
+    z = z + d(b_ih) + d(b_hh) + (d(pre) if pre is not None else 0)
+    i_, f_, g_, o_ = z.view(B, 4, H).unbind(1)
+    i_, f_, g_, o_ = torch.sigmoid(i_), torch.sigmoid(f_), torch.tanh(g_), torch.sigmoid(o_)
+    cn = f_ * d(c_prev) + i_ * g_
+    hn = o_ * torch.tanh(cn)
+    if zone == 0:
+        ho, co = hn * d(hmask) / 0.9, cn
+    elif zone == 1:
+        ho = torch.where(hmask.bool(), hn, d(h_prev)); co = torch.where(cmask.bool(), cn, d(c_prev))
+    else:
+        ho, co = 0.1 * d(h_prev) + 0.9 * hn, 0.15 * d(c_prev) + 0.85 * cn
+    tol = 2e-5
+    assert (h_out.double() - ho).abs().max().item() <= tol, ('h', (h_out.double() - ho).abs().max().item())
+    assert (c_out.double() - co).abs().max().item() <= tol * max(1.0, co.abs().max().item())
+    ref_gates = torch.stack((i_, f_, g_, o_), 1).reshape(B, 4 * H)
+    assert (gates.double() - ref_gates).abs().max().item() <= tol
+    if with_q:
+        q = qpart.double().sum(0)
+        ref_q = h_out.double() @ d(wq).t()
+        assert (q - ref_q).abs().max().item() <= 2e-5 * max(1.0, ref_q.abs().max().item())
+    return h_out
+
+
+@pytest.mark.parametrize('B', [1, 7, 16, 40, 64, 65, 100, 240])
+def test_lstm_step_matches_lstm_cell(B):
+    """The decoder's shapes (H = 1024, [context | h] operand of both presets) over every row-tile regime: one ragged 16-row tile,
+    one 64-row tile, several row tiles with the weights held in registers."""
+    run_step(B, 1024, [544, 1024], 128, 0, seed=B)
+    run_step(B, 1024, [288, 1024], 128, 0, seed=B + 1)
+
+
+@pytest.mark.parametrize('Ks,H,A', [([32], 32, 16), ([256, 544, 1024], 1024, 128), ([1024, 288, 1024], 1024, 64), ([96, 64], 64, 48),
+                                    ([2592], 128, 128)])
+def test_lstm_step_shapes(Ks, H, A):
+    """1-3 K segments, k-slices that straddle segment boundaries, K larger than 8 x 7 k-blocks (KS > 8), small H / A."""
+    run_step(24, H, Ks, A, 0, seed=3)
+
+
+@pytest.mark.parametrize('zone', [1, 2])
+def test_lstm_step_zoneout(zone):
+    run_step(33, 256, [64, 256], 64, 0, zone=zone, seed=11)
+
+
+def test_lstm_step_without_addend_and_query():
+    run_step(20, 128, [128], 128, 0, with_pre=False, with_q=False, seed=5)
+
+
+@pytest.mark.parametrize('B', [16, 64, 240])
+def test_lstm_step_bf16_operands(B):
+    """precision 1: operands rounded to bf16 (RNE), exact products, fp32 accumulation -> equals the fp64 product of the rounded
+    operands to fp32 accumulation error."""
+    run_step(B, 1024, [288, 1024], 128, 1, seed=B)
+
+
+def test_fp32_split_products_are_fp32_accurate():
+    """Six-term bf16 split vs fp64 on wide-dynamic-range data: error at the level of an fp32 accumulation (cf. the GEMM core test)."""
+    g = torch.Generator().manual_seed(1)
+    B, H, K = 64, 256, 1024
+    dev = 'cuda'
+    x = (torch.randn(B, K, generator=g) * torch.exp2(torch.randint(-6, 6, (B, K), generator=g).float())).to(dev)
+    w = (torch.randn(4 * H, K, generator=g) * torch.exp2(torch.randint(-6, 6, (4 * H, K), generator=g).float())).to(dev)
+    L = lib()
+    packed = torch.empty(int(L.mtts_lstm_packed_weight_bytes(H, K, 0)), dtype=torch.uint8, device=dev)
+    pk = _C.LstmPackArgs()
+    pk.w[0], pk.K[0], pk.ldw[0], pk.nseg, pk.H, pk.precision, pk.dst = w.data_ptr(), K, K, 1, H, 0, ptr(packed)
+    check(L.mtts_lstm_pack_weights(ctypes.byref(pk), stream_ptr()), 'pack')
+    a = _C.LstmStepArgs()
+    a.x[0], a.K[0], a.ldx[0], a.nseg, a.w_packed, a.B, a.H = x.data_ptr(), K, K, 1, ptr(packed), B, H
+    KS = int(L.mtts_lstm_step_ksplit(K))
+    part = torch.empty(KS, B, 4 * H, device=dev)
+    c_prev, h_out, c_out = torch.zeros(B, H, device=dev), torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)
+    a.partials, a.c_prev, a.h_out, a.c_out = ptr(part), ptr(c_prev), ptr(h_out), ptr(c_out)
+    check(L.mtts_lstm_step_fwd(ctypes.byref(a), stream_ptr()), 'lstm_step')
+    torch.cuda.synchronize()
+    z = part.double().sum(0).view(B, H, 4).permute(0, 2, 1).reshape(B, 4 * H)        # unit-major -> gate-major
+    ref = x.double() @ w.double().t()
+    scale = x.double().abs() @ w.double().abs().t()
+    err = ((z - ref).abs() / scale).max().item()
+    err_torch = (((x @ w.t()).double() - ref).abs() / scale).max().item()
+    assert err <= 1.25 * err_torch + 2.0 ** -24, (err, err_torch)
