@@ -35,6 +35,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 L_CHARS, T_FRAMES, PER_GPU_BATCH = 120, 600, 64
+GEMM_CORE = {'f32': 'fp32 in/out; products as 6 bf16x bf16 MFMA terms of exact 3-way operand splits, fp32 accumulate (error <= fp32 chain)',
+             'bf16': 'operands rounded to bf16 (RNE) at tile staging, recurrent weights stored bf16; one MFMA term, fp32 accumulate, fp32 state/outputs'}
 PRESET = 'shared_training'
 
 
@@ -113,11 +115,14 @@ def decoder_forward_us(model, hp, batch, L, repeats=3):
     return steady[len(steady) // 2], enc, spk, lang
 
 
-def step_roofline(model, hp, batch, B, L, T, preset):
-    """The north star's quantity: attention+decoder forward step against the HBM roofline."""
+def step_roofline(model, hp, batch, B, L, T, preset, dtype='f32'):
+    """The north star's quantity: attention+decoder forward step against the HBM roofline.  In bf16 mode the weights are
+    counted at 2 bytes (the step kernels stream bf16-packed copies), activations at 4 (they stay fp32 in HBM)."""
     us, _, _, _ = decoder_forward_us(model, hp, batch, L)
     us_step = us / T
     alg = step_algorithmic(hp, B, L)
+    if dtype == 'bf16':
+        alg['bytes'] = 2.0 * alg['weights'] + 4.0 * B * alg['act_per_sample']
     gbps = alg['bytes'] / (us_step * 1e-6) / 1e9
     return {'bound': 'hbm', 'what': f'attention+decoder forward step (teacher forced), params/{preset}, batch {B}, L={L}, Dm={alg["Dm"]}: '
                                     'prenet + attention LSTM + query + location-sensitive attention + generator LSTM + frame/stop projection',
@@ -125,10 +130,10 @@ def step_roofline(model, hp, batch, B, L, T, preset):
             'us_per_step': round(us_step, 2), 'bytes_per_step': alg['bytes'], 'flop_per_step': alg['flop'],
             'frac_of_measured_copy_6290GBps': round(gbps / 6290.0, 4),
             'fp32_mfma_frac_of_157TF': round(alg['flop'] / (us_step * 1e-6) / 157.3e12, 4),
-            'frames_timed': T, 'traffic': None}
+            'frames_timed': T, 'dtype': dtype, 'traffic': None}
 
 
-def secondary_step_roofline(preset, B, L, T, device):
+def secondary_step_roofline(preset, B, L, T, device, dtype='f32'):
     """Same quantity for another preset / batch (fresh random-init model; BASELINE north star: batch 256 -> nearest valid 240)."""
     from multilingual_text_to_speech_amd.params import presets, Params as hp
     from multilingual_text_to_speech_amd.modules.tacotron2 import Tacotron
@@ -136,7 +141,13 @@ def secondary_step_roofline(preset, B, L, T, device):
     torch.manual_seed(0)
     model = Tacotron().to(device).train()
     batch = synthetic_batch(hp, B, L, T, device)
-    out = step_roofline(model, hp, batch, B, L, T, preset)
+    from multilingual_text_to_speech_amd import _C
+    before = _C.get_precision()
+    _C.set_precision(dtype)
+    try:
+        out = step_roofline(model, hp, batch, B, L, T, preset, dtype)
+    finally:
+        _C.set_precision('bf16' if before else 'fp32')
     del model
     return out
 
@@ -191,6 +202,8 @@ def traffic_probe(args):
     from multilingual_text_to_speech_amd.modules.tacotron2 import Tacotron
     import multilingual_text_to_speech_amd.kernels as K
     device = torch.device('cuda', 0)
+    if args.dtype == 'bf16':
+        _C.set_precision('bf16')
     presets.apply(args.preset, speaker_number=91)
     torch.manual_seed(0)
     model = Tacotron().to(device).train()
@@ -213,7 +226,7 @@ def traffic_probe(args):
         torch.cuda.synchronize()
 
 
-def measure_traffic(preset, B, timeout=240):
+def measure_traffic(preset, B, dtype='f32', timeout=240):
     """HBM bytes per forward decoder step from two rocprofv3 PMC passes over a child process (FETCH_SIZE, WRITE_SIZE; both
     in KB; gfx950: FETCH_SIZE counts 64 B per 128-B request of wide coalesced reads -> x2, MI355X_MICROARCH.md HBM section).
     Per step = (bytes of the long decode - bytes of the short one) / (difference of frame counts)."""
@@ -229,7 +242,7 @@ def measure_traffic(preset, B, timeout=240):
         d = tempfile.mkdtemp(prefix='mtts_pmc_', dir='/tmp')
         try:
             cmd = ['rocprofv3', '--kernel-trace', '--pmc', counter, '-d', d, '-o', 'p', '--output-format', 'csv', '--',
-                   sys.executable, os.path.abspath(__file__), '--traffic-probe', '--preset', preset, '--batch', str(B)]
+                   sys.executable, os.path.abspath(__file__), '--traffic-probe', '--preset', preset, '--batch', str(B), '--dtype', dtype]
             r = subprocess.run(cmd, cwd='/tmp', env={**os.environ, 'TMPDIR': '/tmp'}, capture_output=True, text=True, timeout=timeout)
             files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
             if r.returncode != 0 or not files:
@@ -323,6 +336,7 @@ def main():
     ap.add_argument('--batch', type=int, default=PER_GPU_BATCH, help='per-GPU batch')
     ap.add_argument('--frames', type=int, default=T_FRAMES)
     ap.add_argument('--preset', default=PRESET)
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'], help='bf16: BASELINE configs[3] (contraction operands bf16, fp32 accumulate)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the batch-240 step roofline, the inference object and the PMC traffic passes')
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
@@ -338,6 +352,8 @@ def main():
     from multilingual_text_to_speech_amd.params import presets, Params as hp
     from multilingual_text_to_speech_amd.modules.tacotron2 import Tacotron, TacotronLoss
     rank, world, local = D.init()
+    if args.dtype == 'bf16':
+        _C.set_precision('bf16')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (the hot path has no CPU fallback)')
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
@@ -395,7 +411,7 @@ def main():
         empty_s = (float(lib.mtts_prof_empty_ms()) / max(cnt.value, 1)) * 1e-3
         avg_s = max(raw_s - empty_s, 1e-9)
         achieved = flop / avg_s / 1e12 if avg_s > 0 else 0.0
-        roof = step_roofline(model, hp, batch, B, L, T, args.preset)
+        roof = step_roofline(model, hp, batch, B, L, T, args.preset, args.dtype)
         roof['kernels'] = {'attention_lstm_step': {
             'kernel': 'attention-LSTM step: [B,Dm+H]x[4H,Dm+H]^T + LSTM cell (1 launch per frame, largest total time)', 'bound': 'mfma',
             'achieved_TFLOPs': round(achieved, 2), 'peak_TFLOPs': 157.3, 'frac': round(achieved / 157.3, 4), 'flop_per_launch': flop,
@@ -406,9 +422,9 @@ def main():
             'metric': 'mel-frames/sec (train, fwd+bwd+optimizer, batch 64/GPU, 120 chars -> 600 frames)',
             'value': round(frames / dt, 1), 'unit': 'mel-frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * dt / args.steps, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'params/{args.preset}' + (' (BASELINE configs[1])' if args.preset == PRESET else '') + f' train step, per-GPU batch {B}, L={L} -> T={T}, '
-                                   f'fp32, random-init weights', 'gemm_core': 'fp32 in/out; products as 6 bf16x bf16 MFMA terms of exact 3-way operand splits, fp32 accumulate (error <= fp32 chain)',
+                                   f'{args.dtype}, random-init weights', 'gemm_core': GEMM_CORE[args.dtype],
                        'global_batch': B * world, 'parallelism': f'dp{world}',
                        'loss': float(loss.item())},
             'roofline': roof,
@@ -418,15 +434,17 @@ def main():
             del model, opt, crit, batch
             torch.cuda.empty_cache()
             try:
-                traffic, why = measure_traffic(args.preset, B)
+                traffic, why = measure_traffic(args.preset, B, args.dtype)
                 roof['traffic'] = traffic['bytes_per_step'] if traffic else None
                 roof['traffic_detail'] = traffic if traffic else {'error': why}
             except Exception as exc:
                 roof['traffic_detail'] = {'error': repr(exc)[:200]}
-            try:
-                line['roofline_b240'] = secondary_step_roofline('generated_switching', 240, L_CHARS, 300, device)
-            except Exception as exc:
-                line['roofline_b240'] = {'error': repr(exc)[:200]}
+            for key, dt_ in (('roofline_b240', 'f32'), ('roofline_b240_bf16', 'bf16')):
+                try:
+                    line[key] = secondary_step_roofline('generated_switching', 240, L_CHARS, 300, device, dt_)
+                except Exception as exc:
+                    line[key] = {'error': repr(exc)[:200]}
+            _C.set_precision('bf16' if args.dtype == 'bf16' else 'fp32')
             try:
                 line['inference'] = inference_bench(device)
             except Exception as exc:

@@ -63,11 +63,18 @@ typedef struct GemmArgs {
     float beta;
     int act;
     float mask_scale;
-    int nosplit;      /* helper-stream launches: 1 = never split K; 2 = may split K into the UPPER half of the workspace (at most one
-                         stream may use mode 2 at a time); both ask for one workgroup per CU.  0 = caller's stream, lower half. */
+    int nosplit;      /* scratch region for split-K partial tiles: 0 = caller's stream, 1 = the library's side stream, 2 = its
+                         weight-gradient stream (each third of the arena belongs to one of them; the name is historical) */
+    int precision;    /* 0: the process-wide default set by mtts_set_precision (fp32 unless changed; what library-internal GEMMs
+                         use); 1: bf16 path - operands rounded to bf16 (RNE) when their tile is staged, ONE MFMA term, fp32
+                         accumulation and output; 2: fp32-accurate (six bf16 MFMA terms of exact 3-way operand splits) */
 } GemmArgs;
 
 int mtts_gemm_ex(const GemmArgs* args, void* stream);
+/* Process-wide default precision (0 = fp32-accurate, 1 = bf16 operands) of the library-internal contractions: the batched GEMMs inside
+ * mtts_decoder_fwd/bwd and mtts_bilstm_fwd/bwd.  The per-step kernels take theirs from DecoderArgs.precision. */
+int mtts_set_precision(int precision);
+int mtts_get_precision(void);
 /* Scratch arena for split-K partial tiles, provided by the caller (the library never allocates); NULL disables split-K.
  * mtts_set_workspace binds the arena to the CURRENT device (default for all of its streams); mtts_set_stream_workspace
  * gives one caller stream its own arena, which is what makes concurrent callers on different streams of one device

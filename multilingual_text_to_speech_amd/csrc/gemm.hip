@@ -173,35 +173,47 @@ __device__ __forceinline__ void split_pair(float x, float y, unsigned& p1, unsig
     p3 = __builtin_amdgcn_perm(__float_as_uint(sy), __float_as_uint(sx), 0x07060302u);
 }
 
+__device__ __forceinline__ unsigned rne_pair(float x, float y) {      // two floats -> packed bf16, round to nearest even
+    const unsigned ux = __float_as_uint(x), uy = __float_as_uint(y);
+    const unsigned rx = ux + 0x7fffu + ((ux >> 16) & 1u), ry = uy + 0x7fffu + ((uy >> 16) & 1u);
+    return __builtin_amdgcn_perm(ry, rx, 0x07060302u);
+}
+
+// NPL = 3: exact three-way split (fp32 path); NPL = 1: one bf16 plane, round to nearest even (bf16 path)
+template <int NPL>
 __device__ __forceinline__ void store_split4(char* lds, int row, int k4, float4 v) {
+    char* p = lds + row * SP_ROW_B + (((k4 >> 1) ^ ((row >> 2) & 3)) * 16) + (k4 & 1) * 8;
+    if (NPL == 1) {
+        *reinterpret_cast<uint2*>(p) = make_uint2(rne_pair(v.x, v.y), rne_pair(v.z, v.w));
+        return;
+    }
     unsigned a1, a2, a3, b1, b2, b3;
     split_pair(v.x, v.y, a1, a2, a3);
     split_pair(v.z, v.w, b1, b2, b3);
-    char* p = lds + row * SP_ROW_B + (((k4 >> 1) ^ ((row >> 2) & 3)) * 16) + (k4 & 1) * 8;
     *reinterpret_cast<uint2*>(p) = make_uint2(a1, b1);
     *reinterpret_cast<uint2*>(p + SP_PLANE_B) = make_uint2(a2, b2);
     *reinterpret_cast<uint2*>(p + 2 * SP_PLANE_B) = make_uint2(a3, b3);
 }
 
-template <bool TRANS>
+template <bool TRANS, int NPL>
 __device__ __forceinline__ void store_tile_split(char* lds, const Tile<TRANS>& t) {
     const int tid = threadIdx.x;
     if (!TRANS) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) store_split4(lds, it * 32 + (tid >> 3), tid & 7, t.v[it]);
+        for (int it = 0; it < 4; ++it) store_split4<NPL>(lds, it * 32 + (tid >> 3), tid & 7, t.v[it]);
     } else {      // thread holds k = 4*(tid%8) + it (it = 0..3) of rows 4*(tid/8) + {x,y,z,w}
-        store_split4(lds, (tid >> 3) * 4 + 0, tid & 7, make_float4(t.v[0].x, t.v[1].x, t.v[2].x, t.v[3].x));
-        store_split4(lds, (tid >> 3) * 4 + 1, tid & 7, make_float4(t.v[0].y, t.v[1].y, t.v[2].y, t.v[3].y));
-        store_split4(lds, (tid >> 3) * 4 + 2, tid & 7, make_float4(t.v[0].z, t.v[1].z, t.v[2].z, t.v[3].z));
-        store_split4(lds, (tid >> 3) * 4 + 3, tid & 7, make_float4(t.v[0].w, t.v[1].w, t.v[2].w, t.v[3].w));
+        store_split4<NPL>(lds, (tid >> 3) * 4 + 0, tid & 7, make_float4(t.v[0].x, t.v[1].x, t.v[2].x, t.v[3].x));
+        store_split4<NPL>(lds, (tid >> 3) * 4 + 1, tid & 7, make_float4(t.v[0].y, t.v[1].y, t.v[2].y, t.v[3].y));
+        store_split4<NPL>(lds, (tid >> 3) * 4 + 2, tid & 7, make_float4(t.v[0].z, t.v[1].z, t.v[2].z, t.v[3].z));
+        store_split4<NPL>(lds, (tid >> 3) * 4 + 3, tid & 7, make_float4(t.v[0].w, t.v[1].w, t.v[2].w, t.v[3].w));
     }
 }
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, int NPL = 3>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p, float* g_ws) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* sa = reinterpret_cast<char*>(smem);
-    char* sb = sa + 3 * SP_PLANE_B;
+    char* sb = sa + NPL * SP_PLANE_B;
 
     const int ntx = (p.N + BN - 1) / BN, nty = (p.M + BM - 1) / BM;
     const int nt = ntx * nty;
@@ -245,8 +257,8 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p, float* g
     const int nk = min(nk_all, kb0 + per_split);
     load_tile<TA, true, true>(p, A, m0, kb0 * BK, p.M, p.lda, vecA, shift_z, ta);
     load_tile<TB, false, true>(p, B, n0, kb0 * BK, p.N, p.ldb, vecB, shift_z, tb);
-    store_tile_split<TA>(sa, ta);
-    store_tile_split<TB>(sb, tb);
+    store_tile_split<TA, NPL>(sa, ta);
+    store_tile_split<TB, NPL>(sb, tb);
     __syncthreads();
 
     // fragment addresses: lane reads row (l & 31), k-chunk 2*ks + (l >> 5) of each plane
@@ -265,24 +277,25 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p, float* g
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 a[2][3], b[2][3];
+            bf16x8 a[2][NPL], b[2][NPL];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {      // chunk (2*ks + lq) ^ s == (lq ^ s) ^ 2*ks
+                for (int pl = 0; pl < NPL; ++pl) {      // chunk (2*ks + lq) ^ s == (lq ^ s) ^ 2*ks
                     a[i][pl] = *reinterpret_cast<const bf16x8*>(sa + pl * SP_PLANE_B + (offa[i] ^ (ks * 32)));
                     b[i][pl] = *reinterpret_cast<const bf16x8*>(sb + pl * SP_PLANE_B + (offb[i] ^ (ks * 32)));
                 }
 #define MTTS_MM(PA, PB)                                                                                          \
     _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] =      \
         __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA], b[j][PB], acc[i][j], 0, 0, 0);
-            MTTS_MM(2, 0) MTTS_MM(0, 2) MTTS_MM(1, 1) MTTS_MM(1, 0) MTTS_MM(0, 1) MTTS_MM(0, 0)
+            if (NPL == 1) { MTTS_MM(0, 0) }
+            else { MTTS_MM(NPL - 1, 0) MTTS_MM(0, NPL - 1) MTTS_MM(NPL / 2, NPL / 2) MTTS_MM(NPL / 2, 0) MTTS_MM(0, NPL / 2) MTTS_MM(0, 0) }
 #undef MTTS_MM
         }
         __syncthreads();
         if (kb + 1 < nk) {
-            store_tile_split<TA>(sa, ta);
-            store_tile_split<TB>(sb, tb);
+            store_tile_split<TA, NPL>(sa, ta);
+            store_tile_split<TB, NPL>(sb, tb);
         }
         __syncthreads();
     }
@@ -461,8 +474,17 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs p, float* g_ws)
         }
 }
 
+static int g_default_precision = 0;
+MTTS_API int mtts_set_precision(int precision) {
+    MTTS_REQUIRE(precision == 0 || precision == 1, "mtts_set_precision: 0 (fp32) or 1 (bf16)");
+    g_default_precision = precision;
+    return 0;
+}
+MTTS_API int mtts_get_precision(void) { return g_default_precision; }
+
 MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
     GemmArgs p = *args;
+    p.precision = p.precision == 0 ? g_default_precision : (p.precision == 1 ? 1 : 0);
     if (p.M <= 0 || p.N <= 0) return 0;
     MTTS_REQUIRE(p.K >= 0 && p.taps >= 1 && p.taps * p.Kc == p.K, "mtts_gemm_ex: K=%d must equal taps*Kc=%d*%d", p.K,
                  p.taps, p.Kc);
@@ -470,25 +492,24 @@ MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
     if (p.zt < 1) p.zt = 1;
     MTTS_REQUIRE(p.shift_mode == 0 || p.seq_len > 0, "mtts_gemm_ex: shift_mode needs seq_len");
     const int ntx = cdiv(p.N, BN), nty = cdiv(p.M, BM);
-    // split-K when few output tiles face a long reduction (weight gradients): fill ~4 workgroups per CU
+    // split-K when few output tiles face a long reduction: the kernel needs >= 2 workgroups per CU to keep the matrix pipe
+    // busy (one workgroup alone spends 2/3 of a k-step outside its MFMA phase), i.e. >= 512 workgroups.
+    // The scratch arena is cut into three regions so that launches of the caller's stream (nosplit 0), of the side stream
+    // (nosplit 1) and of the weight-gradient stream (nosplit 2) never share partial tiles.
     int S = 1;
     size_t g_ws_bytes = 0;
     float* g_ws_host = workspace_for((hipStream_t)stream, &g_ws_bytes);
+    const int region = p.nosplit < 0 || p.nosplit > 2 ? 0 : p.nosplit;
+    const size_t region_bytes = (g_ws_bytes / 3) & ~(size_t)255;
     {
         const long tiles = (long)ntx * nty * p.batch * p.zt;
         const int nkb = cdiv(p.K, BK);
-        const size_t half = g_ws_bytes / 2;
-        if (g_ws_host && p.nosplit == 0 && tiles < 512 && nkb >= 64) {
-            S = (int)((1024 + tiles - 1) / tiles);
+        if (g_ws_host && tiles < 512 && nkb >= 32) {
+            const long target = region == 0 ? 1024 : 512;        // helper streams: just fill the chip twice over
+            S = (int)((target + tiles - 1) / tiles);
             if (S > nkb / 16) S = nkb / 16;
             if (S > 32) S = 32;
-            while (S > 1 && (size_t)S * p.batch * p.zt * p.M * p.N * sizeof(float) > half) --S;
-            if (S < 1) S = 1;
-        } else if (g_ws_host && p.nosplit == 2 && tiles < 128 && nkb >= 32) {   // helper stream: aim at one workgroup per CU
-            S = (int)(256 / tiles);
-            if (S > nkb / 16) S = nkb / 16;
-            if (S > 32) S = 32;
-            while (S > 1 && (size_t)S * p.batch * p.zt * p.M * p.N * sizeof(float) > half) --S;
+            while (S > 1 && (size_t)S * p.batch * p.zt * p.M * p.N * sizeof(float) > region_bytes) --S;
             if (S < 1) S = 1;
         }
     }
@@ -513,12 +534,18 @@ MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
         for (const void* k : kernels) MTTS_CHECK_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_done = true;
     }
-    float* ws = p.nosplit == 2 ? g_ws_host + g_ws_bytes / 2 / sizeof(float) : g_ws_host;
+    float* ws = g_ws_host ? g_ws_host + (size_t)region * (region_bytes / sizeof(float)) : nullptr;
     if (exact_f32) {
         if (!p.transA && !p.transB) hipLaunchKernelGGL((gemm_mfma_kernel<false, false>), grid, dim3(256), lds, s, p, ws);
         else if (!p.transA && p.transB) hipLaunchKernelGGL((gemm_mfma_kernel<false, true>), grid, dim3(256), lds, s, p, ws);
         else if (p.transA && !p.transB) hipLaunchKernelGGL((gemm_mfma_kernel<true, false>), grid, dim3(256), lds, s, p, ws);
         else hipLaunchKernelGGL((gemm_mfma_kernel<true, true>), grid, dim3(256), lds, s, p, ws);
+    } else if (p.precision == 1) {     // bf16 path: operands rounded to one bf16 plane, one MFMA product, fp32 accumulation
+        const size_t lds1 = SP_LDS_B / 3;
+        if (!p.transA && !p.transB) hipLaunchKernelGGL((gemm_split_kernel<false, false, 1>), grid, dim3(256), lds1, s, p, ws);
+        else if (!p.transA && p.transB) hipLaunchKernelGGL((gemm_split_kernel<false, true, 1>), grid, dim3(256), lds1, s, p, ws);
+        else if (p.transA && !p.transB) hipLaunchKernelGGL((gemm_split_kernel<true, false, 1>), grid, dim3(256), lds1, s, p, ws);
+        else hipLaunchKernelGGL((gemm_split_kernel<true, true, 1>), grid, dim3(256), lds1, s, p, ws);
     } else {
         if (!p.transA && !p.transB) hipLaunchKernelGGL((gemm_split_kernel<false, false>), grid, dim3(256), lds, s, p, ws);
         else if (!p.transA && p.transB) hipLaunchKernelGGL((gemm_split_kernel<false, true>), grid, dim3(256), lds, s, p, ws);

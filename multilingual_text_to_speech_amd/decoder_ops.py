@@ -173,7 +173,7 @@ class DecoderFn(torch.autograd.Function):
         teacher = [bool(x) for x in teacher]
         fast = all(teacher) and cfg.get('allow_fast', True)
         st = DecoderState(B, L, T, (M, P, H, A, Dm, ksz, C), dev, n_prenet, save_gates=True, fast=fast, kq=cfg.get('kq', 8),
-                          precision=cfg.get('precision', 0))
+                          precision=cfg.get('precision', _C.get_precision()))
         # frame fed at step t: zero frame at t=0, target[t-1] afterwards (tacotron2.py:129-131), time-major
         frames_in = torch.zeros(T, B, M, dtype=torch.float32, device=dev)
         frames_in[1:] = target[:, :T - 1].transpose(0, 1)

@@ -1,0 +1,96 @@
+"""bf16 path (BASELINE configs[3]; the reference itself is fp32 only): contraction operands rounded to bf16 (RNE), recurrent
+weights stored as bf16 for the step kernels, fp32 accumulation, cell state and outputs.  Tolerances here are the stated bf16
+tolerances - the fp32 gate (|delta| <= 1e-3) does not apply: a bf16 operand carries 8 significand bits (relative rounding 2^-9),
+a K-term dot product of such operands errs by about sqrt(K) * 2^-9 of its typical term."""
+import pytest
+import torch
+
+from multilingual_text_to_speech_amd import _C
+from tests.helpers import build_hip_model, hip_forward, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def bf16_mode():
+    _C.set_precision('bf16')
+    yield
+    _C.set_precision('fp32')
+
+
+@pytest.mark.parametrize('variant', ['nt', 'nn', 'tt', 'tn'])
+def test_bf16_gemm_equals_product_of_rounded_operands(variant, bf16_mode):
+    """One MFMA term per product: the result must equal the fp64 product of the RNE-rounded operands up to fp32 accumulation."""
+    from multilingual_text_to_speech_amd import kernels as K
+    torch.manual_seed(3)
+    M, N, Kd = 333, 517, 1234
+    dev = torch.device('cuda')
+    A, Bm = torch.randn(M, Kd, device=dev), torch.randn(N, Kd, device=dev)
+    C = torch.empty(M, N, device=dev)
+    tA, tB = variant[0] == 't', variant[1] == 'n'
+    a_st = A.t().contiguous() if tA else A
+    b_st = Bm.t().contiguous() if tB else Bm
+    K.gemm(a_st, b_st, C, M, N, Kd, M if tA else Kd, N if tB else Kd, N, transA=tA, transB=tB)
+    ref = A.to(torch.bfloat16).double() @ Bm.to(torch.bfloat16).double().t()
+    scale = A.double().abs() @ Bm.double().abs().t()
+    assert ((C.double() - ref).abs() / scale).max().item() <= 3e-7
+    exact = A.double() @ Bm.double().t()
+    rel = ((C.double() - exact).abs() / scale).max().item()
+    assert 1e-5 < rel < 2.0 ** -7, rel            # really on the bf16 path (fp32 would sit near 1e-7), and within bf16 rounding
+
+
+@pytest.mark.parametrize('name', ['simple_train', 'generated_train', 'simple_long_train'])
+def test_bf16_train_step_within_bf16_tolerance_of_the_reference(name, bf16_mode):
+    """Forward outputs, loss and gradients of the bf16 path against the fixture recorded from the fp32 reference.
+    Stated tolerance: relative L2 error of every output <= 5e-2 (bf16 operands round at 2^-9 relative; batch norm over a
+    handful of rows amplifies single elements, hence a norm-wise bound), loss 3 %, gradient direction cosine >= 0.98 per large
+    tensor."""
+    from multilingual_text_to_speech_amd.modules.tacotron2 import TacotronLoss
+    from multilingual_text_to_speech_amd.params import Params as hp
+    fx = load_golden(name)
+    model = build_hip_model(fx)
+    post, pre, stop, align, spk, enc = hip_forward(fx, model)
+    dev = 'cuda'
+    crit = TacotronLoss(hp.guided_attention_steps, fx['guided_g'], hp.guided_attention_gain)
+    loss, _ = crit(fx['text_length'].to(dev), fx['target_length'].to(dev), pre, fx['target'].to(dev), post, fx['target'].to(dev),
+                   stop, fx['stop_target'].to(dev), align, None if fx['speakers'] is None else fx['speakers'].to(dev), spk, enc, None)
+    loss.backward()
+    torch.cuda.synchronize()
+    for k, got in (('post', post), ('pre', pre), ('alignment', align), ('encoder_output', enc)):
+        d = (got.detach().cpu() - fx[k]).double()
+        rel = (d.norm() / fx[k].double().norm()).item()
+        assert rel <= 5e-2, f'{name}/{k}: relative L2 error {rel:.3e}, max |delta| {d.abs().max().item():.3e}'
+    assert (post.detach().cpu() - fx['post']).abs().max().item() > 1e-6          # not silently the fp32 path
+    assert abs(loss.item() - fx['loss'].item()) <= 3e-2 * abs(fx['loss'].item())
+    for k, p in model.named_parameters():
+        ref = fx['grads'].get(k)
+        if ref is None or ref.numel() < 256:
+            continue
+        g = p.grad.detach().cpu().flatten().double()
+        r = ref.flatten().double()
+        cos = torch.dot(g, r) / (g.norm() * r.norm() + 1e-30)
+        assert cos.item() >= 0.98, f'{name}/{k}: cosine {cos.item():.4f}'
+
+
+def test_bf16_decoder_at_real_widths_tracks_the_fp32_path(bf16_mode):
+    """shared_training widths, batch 16, 60 frames (two chunks): bf16 alignments / mels stay within the stated tolerance of the
+    fp32 path of the same model and dropout draws; the K-split step kernels run with bf16-packed weights."""
+    from multilingual_text_to_speech_amd.params import presets, Params as hp
+    from multilingual_text_to_speech_amd.modules.tacotron2 import Tacotron
+    from tests.test_gpu_more import _random_batch
+    presets.apply('shared_training')
+    torch.manual_seed(0)
+    model = Tacotron().cuda().train()
+    text, tl, target, tgl, spk, lang = _random_batch(hp, 16, 40, 60)
+    args = (text.cuda(), tl, target.cuda(), tgl, None, lang.cuda(), 1.0)
+    outs = {}
+    for mode in ('bf16', 'fp32'):
+        _C.set_precision(mode)
+        torch.manual_seed(7)
+        with torch.no_grad():
+            outs[mode] = model(*args)
+    _C.set_precision('bf16')
+    for i, name in ((0, 'post'), (1, 'pre'), (3, 'alignment')):
+        a, b = outs['bf16'][i], outs['fp32'][i]
+        err = ((a - b).double().norm() / b.double().norm()).item()
+        assert 0 < err <= 5e-2, f'{name}: relative L2 error {err:.3e}'
