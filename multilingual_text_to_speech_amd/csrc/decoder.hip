@@ -107,6 +107,10 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
     // attention LSTM as K-split gate GEMM + (cell, query partials): see lstm_step.hip
     const bool use_ls = a.fast && a.att_w2p && a.att_bias_u && a.att_w_pre_u && a.gate_part && (Dm & 31) == 0 && (H & 31) == 0 &&
                         (A & 15) == 0 && A <= 256;
+    // general schedule (free running / mixed teacher forcing): the same kernels over the un-hoisted operands
+    //   attention LSTM  [prenet(t) | ctx | h_att]  x  [W_ih | W_hh],   generator LSTM  [h_att | ctx | h_gen]  x  [W_ih | W_hh]
+    const bool use_lg = !a.fast && a.att_w2p && a.att_bias_u && a.gate_part && a.gen_w2p && a.gen_bias_u && a.gate_part_gen &&
+                        (P & 31) == 0 && (Dm & 31) == 0 && (H & 31) == 0 && (A & 15) == 0 && A <= 256;
 
     if (a.t0 == 0) {
         // U = W_loc [A,C] * W_conv [C,ksz];  Mt = memory W_memory^T;  PL[0] = Mt + bias   (attention.py:23-28)
@@ -125,6 +129,20 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
             k.b_ih = a.att_b_ih; k.b_hh = a.att_b_hh; k.bias_u = a.att_bias_u;
             MTTS_TRY(mtts_lstm_pack_weights(&k, s));
             MTTS_TRY(mtts_lstm_rows_unit_major(a.att_w_ih, P + Dm, H, P, a.att_w_pre_u, s));
+        }
+        if (use_lg) {
+            LstmPackArgs k; memset(&k, 0, sizeof(k));
+            k.w[0] = a.att_w_ih; k.K[0] = P; k.ldw[0] = P + Dm;
+            k.w[1] = a.att_w_ih + P; k.K[1] = Dm; k.ldw[1] = P + Dm;
+            k.w[2] = a.att_w_hh; k.K[2] = H; k.ldw[2] = H;
+            k.nseg = 3; k.H = H; k.precision = a.precision; k.dst = a.att_w2p;
+            k.b_ih = a.att_b_ih; k.b_hh = a.att_b_hh; k.bias_u = a.att_bias_u;
+            MTTS_TRY(mtts_lstm_pack_weights(&k, s));
+            k.w[0] = a.gen_w_ih; k.K[0] = H; k.ldw[0] = H + Dm;
+            k.w[1] = a.gen_w_ih + H; k.K[1] = Dm; k.ldw[1] = H + Dm;
+            k.w[2] = a.gen_w_hh; k.K[2] = H; k.ldw[2] = H;
+            k.dst = a.gen_w2p; k.b_ih = a.gen_b_ih; k.b_hh = a.gen_b_hh; k.bias_u = a.gen_bias_u;
+            MTTS_TRY(mtts_lstm_pack_weights(&k, s));
         }
         if (gen_uses_lstep(a)) {
             LstmPackArgs k; memset(&k, 0, sizeof(k));
@@ -164,7 +182,16 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
         const bool teach = a.frames_in && a.teacher && a.teacher[t];
         if (!teach) {
             // prenet on the model's own previous frame (tacotron2.py:181), out slot t holds frame t-1 (slot 0 = zeros)
-            for (int i = 0; i < a.n_prenet; ++i) {
+            int fused = -1;
+            if (a.n_prenet == 2) {      // both layers in one launch
+                const bool masked = a.p_prenet > 0.f;
+                fused = prenet2_launch(a.out + (long)t * B * Mo, Mo, M, a.prenet_w[0], a.prenet_b[0], a.prenet_w[1], a.prenet_b[1],
+                                       masked && a.prenet_mask[0] ? a.prenet_mask[0] + t * BP : nullptr,
+                                       masked && a.prenet_mask[1] ? a.prenet_mask[1] + t * BP : nullptr, pscale,
+                                       a.prenet_act[0] + t * BP, a.prenet_act[1] + t * BP, B, P, s);
+                if (fused > 0) return fused;
+            }
+            for (int i = 0; fused < 0 && i < a.n_prenet; ++i) {
                 SkinnyArgs k; memset(&k, 0, sizeof(k));
                 k.nseg = 1; k.B = B; k.N = P; k.ksplit = 1;
                 if (i == 0) k.seg[0] = SkSeg{a.out + (long)t * B * Mo, a.prenet_w[0], M, Mo, M, 0, 0};
@@ -174,12 +201,15 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
                 MTTS_TRY(skinny_launch(k, s));
             }
         }
-        if (use_ls) {   // attention LSTM + query partials (tacotron2.py:184-185, attention.py:68) in two launches
+        if (use_ls || use_lg) {   // attention LSTM + query partials (tacotron2.py:184-185, attention.py:68) in two launches
             LstmStepArgs k; memset(&k, 0, sizeof(k));
-            k.x[0] = a.ctx + t * BD; k.K[0] = Dm; k.ldx[0] = Dm;
-            k.x[1] = a.h_att + t * BH; k.K[1] = H; k.ldx[1] = H;
-            k.nseg = 2; k.w_packed = a.att_w2p; k.precision = a.precision; k.B = B; k.H = H; k.partials = a.gate_part;
-            k.pre = a.pre_att + t * B4H; k.ldpre = 4 * H; k.bias_u = a.att_bias_u;
+            int n = 0;
+            if (use_lg) { k.x[n] = pren + t * BP; k.K[n] = P; k.ldx[n] = P; ++n; }
+            k.x[n] = a.ctx + t * BD; k.K[n] = Dm; k.ldx[n] = Dm; ++n;
+            k.x[n] = a.h_att + t * BH; k.K[n] = H; k.ldx[n] = H; ++n;
+            k.nseg = n; k.w_packed = a.att_w2p; k.precision = a.precision; k.B = B; k.H = H; k.partials = a.gate_part;
+            if (use_ls) { k.pre = a.pre_att + t * B4H; k.ldpre = 4 * H; }
+            k.bias_u = a.att_bias_u;
             k.h_prev = a.h_att + t * BH; k.c_prev = a.c_att + t * BH;
             k.h_out = a.h_att + (t + 1) * BH; k.c_out = a.c_att + (t + 1) * BH;
             k.gates_out = a.gates_att ? a.gates_att + t * B4H : nullptr;
@@ -216,7 +246,7 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
             MTTS_TRY(skinny_launch(k, s));
             if (sampled) prof_sample(t, s, 1);
         }
-        if (!use_ls) {   // query projection partials (attention.py:68)
+        if (!use_ls && !use_lg) {   // query projection partials (attention.py:68)
             SkinnyArgs k; memset(&k, 0, sizeof(k));
             k.nseg = 1; k.B = B; k.N = A; k.ksplit = a.kq;
             k.seg[0] = seg_h(a.h_att, a.h_att_p, t + 1, B, H, a.w_query, a.w_query_p, H);
@@ -225,7 +255,7 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
         }
         {   // energies -> softmax -> context, PL for the next step (attention.py:39-45,67-86)
             AttnStepArgs q; memset(&q, 0, sizeof(q));
-            q.qpart = a.qpart; q.kq = use_ls ? H / 16 : a.kq; q.q_ks = (long)B * A;
+            q.qpart = a.qpart; q.kq = (use_ls || use_lg) ? H / 16 : a.kq; q.q_ks = (long)B * A;
             q.PL = a.PL + (long)(t & 1) * BL * A; q.PL_next = a.PL + (long)((t + 1) & 1) * BL * A;
             q.Mt = a.Mt; q.U = a.U; q.bias = a.att_bias; q.v = a.w_energy; q.memory = a.memory; q.lengths = a.lengths;
             q.cum_in = a.cum + t * BL; q.cum_out = a.cum + (t + 1) * BL; q.w_out = a.align + t * BL;
@@ -238,7 +268,21 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
             MTTS_TRY(attn_step_launch(q, s));
         }
         if (!a.fast) {
-            {   // generator LSTM (tacotron2.py:187-188)
+            if (use_lg) {   // generator LSTM (tacotron2.py:187-188)
+                LstmStepArgs k; memset(&k, 0, sizeof(k));
+                k.x[0] = a.h_att + (t + 1) * BH; k.K[0] = H; k.ldx[0] = H;
+                k.x[1] = a.ctx + (t + 1) * BD; k.K[1] = Dm; k.ldx[1] = Dm;
+                k.x[2] = a.h_gen + t * BH; k.K[2] = H; k.ldx[2] = H;
+                k.nseg = 3; k.w_packed = a.gen_w2p; k.precision = a.precision; k.B = B; k.H = H; k.partials = a.gate_part_gen;
+                k.bias_u = a.gen_bias_u;
+                k.h_prev = a.h_gen + t * BH; k.c_prev = a.c_gen + t * BH;
+                k.h_out = a.h_gen + (t + 1) * BH; k.c_out = a.c_gen + (t + 1) * BH;
+                k.gates_out = a.gates_gen ? a.gates_gen + t * B4H : nullptr;
+                SkinnyArgs r; memset(&r, 0, sizeof(r));
+                lstm_reg(a, r, a.gen_hmask, a.gen_cmask, t);
+                k.hmask = r.hmask; k.cmask = r.cmask; k.hscale = r.hscale; k.zone = r.zone; k.zh = r.zh; k.zc = r.zc;
+                MTTS_TRY(lstm_step_launch(k, s));
+            } else {   // generator LSTM (tacotron2.py:187-188)
                 SkinnyArgs k; memset(&k, 0, sizeof(k));
                 k.B = B; k.N = 4 * H; k.ksplit = 1; k.lstm = 1; k.H = H; k.nseg = 3;
                 k.seg[0] = seg_h(a.h_att, a.h_att_p, t + 1, B, H, a.gen_w_ih, nullptr, H + Dm);
@@ -255,10 +299,18 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
             {   // frame + stop projection (tacotron2.py:191-193)
                 SkinnyArgs k; memset(&k, 0, sizeof(k));
                 k.nseg = 2; k.B = B; k.N = M + 1; k.ksplit = 1;
-                k.seg[0] = seg_h(a.h_gen, a.h_gen_p, t + 1, B, H, a.w_out, nullptr, H + Dm);
-                k.seg[1] = seg_h(a.ctx, a.ctx_p, t + 1, B, Dm, a.w_out + H, nullptr, H + Dm);
-                k.out = a.out + (long)(t + 1) * B * Mo; k.ldo = Mo; k.bias = a.b_out;
-                MTTS_TRY(skinny_launch(k, s));
+                k.seg[0] = seg_h(a.h_gen, use_lg ? nullptr : a.h_gen_p, t + 1, B, H, a.w_out, nullptr, H + Dm);      // (the K-split cell kernel
+                k.seg[1] = seg_h(a.ctx, use_lg ? nullptr : a.ctx_p, t + 1, B, Dm, a.w_out + H, nullptr, H + Dm);      //  writes no packed copies)
+                if (use_lg && (long)8 * B * Mo <= (long)B * 4 * H) {
+                    // few output columns, long K: split K eight ways for parallelism (partials in the idle generator scratch) and
+                    // finish with a small reduction instead of streaming [B, H + Dm] through 6 workgroups
+                    k.ksplit = 8; k.out = a.gate_part_gen; k.ldo = Mo; k.out_ks = (long)B * Mo;
+                    MTTS_TRY(skinny_launch(k, s));
+                    MTTS_TRY(sum_slabs(a.gate_part_gen, 8, (long)B * Mo, Mo, a.b_out, a.out + (long)(t + 1) * B * Mo, B, M + 1, Mo, 0, s));
+                } else {
+                    k.out = a.out + (long)(t + 1) * B * Mo; k.ldo = Mo; k.bias = a.b_out;
+                    MTTS_TRY(skinny_launch(k, s));
+                }
             }
         }
         if (a.fast && (((t + 1 - a.t0) % CH) == 0 || t + 1 == a.t1)) {

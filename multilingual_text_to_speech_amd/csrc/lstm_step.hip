@@ -24,7 +24,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
 constexpr int LS_THREADS = 512;
 constexpr int LS_COLS = 128;         // gate columns per workgroup = 8 waves x 16
-constexpr int LS_MAXKB = 7;          // 32-wide k-blocks per K-slice (weights of a slice stay in registers)
+constexpr int LS_MAXKB = 10;         // 32-wide k-blocks per K-slice (weights of a slice stay in registers): K <= 8 x 320 with 8 slices
 constexpr int LS_PLANE_B = 64 * 64;  // one k-block of one plane in LDS: 64 rows x 32 bf16
 constexpr int LS_MIN_KS = 8;
 
@@ -114,10 +114,11 @@ struct LsGates {
     int K0, K1, K2, ld0, ld1, ld2;
     const void* wp;
     int nkb, KS, B, N;
+    int nbmax;            // k-blocks of the longest slice: LDS holds NPL x nbmax blocks
     float* part;          // [KS][B][N]
 };
 
-template <int PREC>
+template <int PREC, int NB>      // NB: k-blocks per K-slice held in registers (the smallest instantiation that fits is launched)
 __global__ __launch_bounds__(LS_THREADS) void lstm_gates_kernel(LsGates p) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
     constexpr int NPL = PREC ? 1 : 3;
@@ -125,37 +126,37 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_gates_kernel(LsGates p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int s = blockIdx.x % p.KS, j = blockIdx.x / p.KS;
     const int kb0 = (int)((long)s * p.nkb / p.KS), kb1 = (int)((long)(s + 1) * p.nkb / p.KS);
-    const int nb = kb1 - kb0;
+    const int nb = kb1 - kb0;                           // <= NB (host guarantees); blocks kb >= nb are skipped by wave-uniform guards
     const int i16 = lane & 15, q4 = lane >> 4;
 
     const int srow = tid >> 3, sk4 = tid & 7;           // staging: 8 threads cover the 32 k of one row
     const int n_row_tiles = (p.B + 63) >> 6;
-    // X slice of a row tile: one float4 per thread and k-block (row-major fp32 in global memory; mostly L2 hits)
-    auto load_x = [&](int row0, float4 (&xv)[LS_MAXKB]) {
-        const int rowc = min(row0 + srow, p.B - 1);
-#pragma unroll
-        for (int kb = 0; kb < LS_MAXKB; ++kb) {
-            int kg = 32 * (kb0 + (kb < nb ? kb : 0));
-            const float* xs; int ld;
-            if (kg < p.K0) { xs = p.x0; ld = p.ld0; }
-            else if (kg < p.K0 + p.K1) { xs = p.x1; ld = p.ld1; kg -= p.K0; }
-            else { xs = p.x2; ld = p.ld2; kg -= p.K0 + p.K1; }
-            xv[kb] = *reinterpret_cast<const float4*>(xs + (long)rowc * ld + kg + 4 * sk4);
-        }
-    };
-    float4 xv[LS_MAXKB];
-    load_x(0, xv);                                      // requested BEFORE the weights: it gates the first MFMA
+    // X slice of a row tile: one float4 per thread and k-block (row-major fp32 in global memory; mostly L2 hits).
+    // NOTE: every loop over k-blocks is fully unrolled with `if (kb < nb)` guards (no break): register arrays stay registers.
+    float4 xv[NB];
+#define LS_LOAD_X(ROW0)                                                                                           \
+    {                                                                                                             \
+        const int rowc = min((ROW0) + srow, p.B - 1);                                                             \
+        _Pragma("unroll") for (int kb = 0; kb < NB; ++kb) if (kb < nb) {                                          \
+            int kg = 32 * (kb0 + kb);                                                                             \
+            const float* xs; int ld;                                                                              \
+            if (kg < p.K0) { xs = p.x0; ld = p.ld0; }                                                             \
+            else if (kg < p.K0 + p.K1) { xs = p.x1; ld = p.ld1; kg -= p.K0; }                                     \
+            else { xs = p.x2; ld = p.ld2; kg -= p.K0 + p.K1; }                                                    \
+            xv[kb] = *reinterpret_cast<const float4*>(xs + (long)rowc * ld + kg + 4 * sk4);                       \
+        }                                                                                                         \
+    }
+    LS_LOAD_X(0)                                         // requested BEFORE the weights: it gates the first MFMA
 
     // ---- this wave's weight slice -> registers (one or two 16-byte loads per lane and k-block, 1 KiB contiguous per
     //      instruction); requested in k order and consumed in k order, so block kb's MFMAs start while later blocks still stream
-    float4 wr[LS_MAXKB][PREC ? 1 : 2];
+    float4 wr[NB][PREC ? 1 : 2];
     {
         const float4* src = reinterpret_cast<const float4*>(p.wp) + ((long)(j * 8 + wave) * p.nkb + kb0) * (PREC ? 64 : 128) + lane;
 #pragma unroll
-        for (int kb = 0; kb < LS_MAXKB; ++kb) {
-            const int kc = kb < nb ? kb : 0;        // clamped: unused blocks re-read block 0 (never consumed)
-            wr[kb][0] = src[(long)kc * (PREC ? 64 : 128)];
-            if (!PREC) wr[kb][1] = src[(long)kc * 128 + 64];
+        for (int kb = 0; kb < NB; ++kb) if (kb < nb) {
+            wr[kb][0] = src[(long)kb * (PREC ? 64 : 128)];
+            if (!PREC) wr[kb][1] = src[(long)kb * 128 + 64];
         }
     }
 
@@ -163,11 +164,10 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_gates_kernel(LsGates p) {
         const int row0 = rt * 64;
         // ---- X slice of this row tile -> bf16 plane(s) in LDS
         {
-            if (rt > 0) { load_x(row0, xv); __syncthreads(); }     // the previous row tile's fragments have been consumed
+            if (rt > 0) { LS_LOAD_X(row0) __syncthreads(); }     // the previous row tile's fragments have been consumed
             char* dst = sm + srow * 64 + (((sk4 >> 1) ^ ((srow >> 2) & 3)) * 16) + (sk4 & 1) * 8;
 #pragma unroll
-            for (int kb = 0; kb < LS_MAXKB; ++kb) {
-                if (kb >= nb) break;
+            for (int kb = 0; kb < NB; ++kb) if (kb < nb) {
                 if (PREC) {
                     const unsigned a = bf16_rne(xv[kb].x) | (bf16_rne(xv[kb].y) << 16), b = bf16_rne(xv[kb].z) | (bf16_rne(xv[kb].w) << 16);
                     *reinterpret_cast<uint2*>(dst + kb * LS_PLANE_B) = make_uint2(a, b);
@@ -175,9 +175,9 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_gates_kernel(LsGates p) {
                     unsigned a1, a2, a3, b1, b2, b3;
                     ls_split_pair(xv[kb].x, xv[kb].y, a1, a2, a3);
                     ls_split_pair(xv[kb].z, xv[kb].w, b1, b2, b3);
-                    *reinterpret_cast<uint2*>(dst + (0 * LS_MAXKB + kb) * LS_PLANE_B) = make_uint2(a1, b1);
-                    *reinterpret_cast<uint2*>(dst + (1 * LS_MAXKB + kb) * LS_PLANE_B) = make_uint2(a2, b2);
-                    *reinterpret_cast<uint2*>(dst + (2 * LS_MAXKB + kb) * LS_PLANE_B) = make_uint2(a3, b3);
+                    *reinterpret_cast<uint2*>(dst + (0 * NB + kb) * LS_PLANE_B) = make_uint2(a1, b1);
+                    *reinterpret_cast<uint2*>(dst + (1 * NB + kb) * LS_PLANE_B) = make_uint2(a2, b2);
+                    *reinterpret_cast<uint2*>(dst + (2 * NB + kb) * LS_PLANE_B) = make_uint2(a3, b3);
                 }
             }
         }
@@ -190,8 +190,7 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_gates_kernel(LsGates p) {
         for (int m = 0; m < 4; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int a_off = i16 * 64 + ((q4 ^ ((i16 >> 2) & 3)) * 16);
 #pragma unroll
-        for (int kb = 0; kb < LS_MAXKB; ++kb) {
-            if (kb >= nb) break;
+        for (int kb = 0; kb < NB; ++kb) if (kb < nb) {
             Frag8 wb[NPL];
             if (PREC) {
                 wb[0].u[0] = __float_as_uint(wr[kb][0].x); wb[0].u[1] = __float_as_uint(wr[kb][0].y);
@@ -204,21 +203,20 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_gates_kernel(LsGates p) {
             }
             // two row tiles at a time: their accumulators alternate, so no MFMA waits for the one issued just before it
 #pragma unroll
-            for (int mp = 0; mp < 4; mp += 2) {
-                if (mp >= mt_n) break;
+            for (int mp = 0; mp < 4; mp += 2) if (mp < mt_n) {
                 bf16x8 a[2][NPL];
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int pl = 0; pl < NPL; ++pl)
-                        a[m][pl] = *reinterpret_cast<const bf16x8*>(sm + (pl * LS_MAXKB + kb) * LS_PLANE_B + min(mp + m, mt_n - 1) * 1024 + a_off);
+                        a[m][pl] = *reinterpret_cast<const bf16x8*>(sm + (pl * NB + kb) * LS_PLANE_B + min(mp + m, mt_n - 1) * 1024 + a_off);
 #define LS_MM(PA, PB)                                                                                            \
     _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                               \
         acc[mp + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][PA], wb[PB].v, acc[mp + m], 0, 0, 0);
                 if (PREC) { LS_MM(0, 0) }
                 else { LS_MM(2, 0) LS_MM(0, 2) LS_MM(1, 1) LS_MM(1, 0) LS_MM(0, 1) LS_MM(0, 0) }      // small terms first
-            }
 #undef LS_MM
+            }
         }
         // ---- partial slab: D layout col = lane & 15, row = 4 (lane >> 4) + r
         const int col = j * LS_COLS + wave * 16 + i16;
@@ -233,6 +231,7 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_gates_kernel(LsGates p) {
                 }
         }
     }
+#undef LS_LOAD_X
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -330,6 +329,138 @@ __global__ __launch_bounds__(256) void lstm_cell_q_kernel(LsCell p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// Two-layer prenet of ONE free-running step in one launch (reference Prenet.forward modules/tacotron2.py:37-46 called at :181):
+//   y1 = dropout(relu(x W1^T + b1)),  y2 = dropout(relu(y1 W2^T + b2));  dropout always on (keep flags are inputs).
+// Workgroup = 16 batch rows; wave w owns output columns {16 w .. } of both layers; y1 stays in LDS.  Exact fp32 MFMA.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct Prenet2 {
+    const float* x; int ldx; int Kin;           // [B, Kin] (Kin % 4 == 0)
+    const float* w1; const float* b1; const float* w2; const float* b2;
+    const uint8_t* m1; const uint8_t* m2; float scale;
+    float* y1; float* y2;                        // [B, P] each
+    int B, P;
+};
+constexpr int PN_MAXCT = 2;      // column tiles per wave: P <= 8 waves x 2 x 16 = 256
+constexpr int PN_MAXK1 = 6;      // 16-wide k-chunks of layer 1: Kin <= 96
+constexpr int PN_MAXK2 = 16;      // 16-wide k-chunks of layer 2: P <= 256
+
+__global__ __launch_bounds__(512) void prenet2_kernel(Prenet2 p) {
+    extern __shared__ __attribute__((aligned(16))) float psm[];      // y1 tile [16][P + 4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, q4 = lane >> 4;
+    const int row0 = blockIdx.x * 16;
+    const int P = p.P, ldh = P + 4, nct = P >> 4;
+    const int arow = min(row0 + i16, p.B - 1);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // ---- EVERY global operand of both layers is requested here, before any arithmetic: the kernel is one memory round trip
+    //      (weights come from the Infinity Cache at best: eight other kernels ran since the previous step) plus ~3 us of MFMA
+    float4 a4[PN_MAXK1], b1f[PN_MAXCT][PN_MAXK1], b2f[PN_MAXCT][PN_MAXK2];
+    float bias1[PN_MAXCT], bias2[PN_MAXCT];
+    int keep1[PN_MAXCT][4], keep2[PN_MAXCT][4];
+#pragma unroll
+    for (int kc = 0; kc < PN_MAXK1; ++kc) {
+        const int k = 16 * kc + 4 * q4;
+        const bool ok = k < p.Kin;
+        a4[kc] = ok ? *reinterpret_cast<const float4*>(p.x + (long)arow * p.ldx + k) : z4;
+#pragma unroll
+        for (int c = 0; c < PN_MAXCT; ++c) {
+            const int ct = wave + 8 * c;
+            b1f[c][kc] = (ok && ct < nct) ? *reinterpret_cast<const float4*>(p.w1 + (long)(16 * ct + i16) * p.Kin + k) : z4;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < PN_MAXCT; ++c) {
+        const int ct = min(wave + 8 * c, nct - 1), col = 16 * ct + i16;
+#pragma unroll
+        for (int kc = 0; kc < PN_MAXK2; ++kc) {
+            const int k = min(16 * kc, P - 16) + 4 * q4;
+            b2f[c][kc] = *reinterpret_cast<const float4*>(p.w2 + (long)col * P + k);
+        }
+        bias1[c] = p.b1[col]; bias2[c] = p.b2[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long mi = (long)min(row0 + 4 * q4 + r, p.B - 1) * P + col;
+            keep1[c][r] = p.m1 ? (int)p.m1[mi] : 1;
+            keep2[c][r] = p.m2 ? (int)p.m2[mi] : 1;
+        }
+    }
+    // ---- layer 1
+    f32x4 acc[PN_MAXCT];
+#pragma unroll
+    for (int c = 0; c < PN_MAXCT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < PN_MAXK1; ++kc) {
+        const float av[4] = {a4[kc].x, a4[kc].y, a4[kc].z, a4[kc].w};
+#pragma unroll
+        for (int c = 0; c < PN_MAXCT; ++c) {
+            const float bv[4] = {b1f[c][kc].x, b1f[c][kc].y, b1f[c][kc].z, b1f[c][kc].w};
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bv[s2], acc[c], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < PN_MAXCT; ++c) {
+        const int ct = wave + 8 * c;
+        if (ct < nct) {
+            const int col = 16 * ct + i16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = 4 * q4 + r, row = row0 + rr;
+                float v = fmaxf(acc[c][r] + bias1[c], 0.f);
+                if (row < p.B) {
+                    if (p.m1) v = keep1[c][r] ? v * p.scale : 0.f;
+                    p.y1[(long)row * P + col] = v;
+                } else v = 0.f;
+                psm[rr * ldh + col] = v;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- layer 2
+#pragma unroll
+    for (int c = 0; c < PN_MAXCT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < PN_MAXK2; ++kc) {
+        if (16 * kc < P) {
+            const float4 h4 = *reinterpret_cast<const float4*>(psm + i16 * ldh + 16 * kc + 4 * q4);
+            const float av[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+            for (int c = 0; c < PN_MAXCT; ++c) {
+                const float bv[4] = {b2f[c][kc].x, b2f[c][kc].y, b2f[c][kc].z, b2f[c][kc].w};
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bv[s2], acc[c], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < PN_MAXCT; ++c) {
+        const int ct = wave + 8 * c;
+        if (ct < nct) {
+            const int col = 16 * ct + i16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + 4 * q4 + r;
+                float v = fmaxf(acc[c][r] + bias2[c], 0.f);
+                if (p.m2) v = keep2[c][r] ? v * p.scale : 0.f;
+                if (row < p.B) p.y2[(long)row * P + col] = v;
+            }
+        }
+    }
+}
+
+// Returns -1 when the shape is outside the kernel's bounds (the caller then runs the layers one by one), 0 on success.
+int prenet2_launch(const float* x, int ldx, int Kin, const float* w1, const float* b1, const float* w2, const float* b2, const uint8_t* m1,
+                   const uint8_t* m2, float scale, float* y1, float* y2, int B, int P, hipStream_t s) {
+    if ((P & 15) != 0 || P > 16 * 8 * PN_MAXCT || Kin > 16 * PN_MAXK1 || (Kin & 3) != 0 || (ldx & 3) != 0 || (((uintptr_t)x | (uintptr_t)w1 | (uintptr_t)w2) & 15) != 0) return -1;
+    Prenet2 p;
+    p.x = x; p.ldx = ldx; p.Kin = Kin; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.m1 = m1; p.m2 = m2; p.scale = scale;
+    p.y1 = y1; p.y2 = y2; p.B = B; p.P = P;
+    hipLaunchKernelGGL(prenet2_kernel, dim3((B + 15) / 16), dim3(512), sizeof(float) * 16 * (P + 4), s, p);
+    if (hipGetLastError() != hipSuccess) return mtts_fail("launch prenet2_kernel failed");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------------
 static int ls_check_segs(int nseg, const int* K, const int* ld, const char* what) {
@@ -386,14 +517,22 @@ int lstm_step_launch(const LstmStepArgs& a, hipStream_t s) {
     g.x1 = a.nseg > 1 ? a.x[1] : a.x[0]; g.K1 = a.nseg > 1 ? a.K[1] : 0; g.ld1 = a.nseg > 1 ? a.ldx[1] : a.ldx[0];
     g.x2 = a.nseg > 2 ? a.x[2] : a.x[0]; g.K2 = a.nseg > 2 ? a.K[2] : 0; g.ld2 = a.nseg > 2 ? a.ldx[2] : a.ldx[0];
     g.wp = a.w_packed; g.nkb = (g.K0 + g.K1 + g.K2) / 32; g.KS = ls_ksplit(g.nkb); g.B = a.B; g.N = 4 * a.H; g.part = a.partials;
+    g.nbmax = (g.nkb + g.KS - 1) / g.KS;
     const int ntile = (4 * a.H) / LS_COLS;
     static bool attr_done = false;
     if (!attr_done) {
-        MTTS_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_gates_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * LS_MAXKB * LS_PLANE_B));
+        MTTS_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_gates_kernel<0, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 7 * LS_PLANE_B));
+        MTTS_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_gates_kernel<0, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 10 * LS_PLANE_B));
         attr_done = true;
     }
-    if (a.precision) hipLaunchKernelGGL(lstm_gates_kernel<1>, dim3(ntile * g.KS), dim3(LS_THREADS), LS_MAXKB * LS_PLANE_B, s, g);
-    else hipLaunchKernelGGL(lstm_gates_kernel<0>, dim3(ntile * g.KS), dim3(LS_THREADS), 3 * LS_MAXKB * LS_PLANE_B, s, g);
+    const dim3 grid(ntile * g.KS), blk(LS_THREADS);
+#define LS_LAUNCH(PREC, NB) hipLaunchKernelGGL((lstm_gates_kernel<PREC, NB>), grid, blk, (size_t)(PREC ? 1 : 3) * NB * LS_PLANE_B, s, g)
+    if (a.precision) {
+        if (g.nbmax <= 4) LS_LAUNCH(1, 4); else if (g.nbmax <= 7) LS_LAUNCH(1, 7); else LS_LAUNCH(1, 10);
+    } else {
+        if (g.nbmax <= 4) LS_LAUNCH(0, 4); else if (g.nbmax <= 7) LS_LAUNCH(0, 7); else LS_LAUNCH(0, 10);
+    }
+#undef LS_LAUNCH
     MTTS_CHECK_LAUNCH("lstm_gates_kernel");
     LsCell c; memset(&c, 0, sizeof(c));
     c.part = a.partials; c.KS = g.KS; c.B = a.B; c.H = a.H; c.pre = a.pre; c.ldpre = a.ldpre; c.bias_u = a.bias_u;

@@ -26,25 +26,29 @@ class DecoderState:
         self.Mo = _round4(M + 1)
         self.prenet_act = [e(T, B, P) for _ in range(n_prenet)]
         self.U, self.Mt, self.PL = e(A, ksz), e(B, L, A), e(2, B, L, A)
-        # K-split step path of the attention LSTM (csrc/lstm_step.hip): query partials come in H/16 slabs
+        # K-split step kernels (csrc/lstm_step.hip): query partials come in H/16 slabs
         self.precision = int(precision)
-        self.use_lstep = bool(fast and os.environ.get('MTTS_NO_LSTEP', '0') != '1' and Dm % 32 == 0 and H % 32 == 0 and A % 16 == 0 and A <= 256)
-        self.qpart = e(max(kq, H // 16) if self.use_lstep else kq, B, A)
+        off = os.environ.get('MTTS_NO_LSTEP', '0')
+        ok = H % 32 == 0 and Dm % 32 == 0 and A % 16 == 0 and A <= 256
+        self.use_lstep = bool(fast and off != '1' and ok)                       # teacher-forced schedule: hoisted projections
+        use_lgen = bool(not fast and off != '1' and ok and P % 32 == 0)          # general schedule: un-hoisted 3-segment operands
+        self.qpart = e(max(kq, H // 16) if (self.use_lstep or use_lgen) else kq, B, A)
         self.att_w2p = self.att_bias_u = self.att_w_pre_u = self.gate_part = None
         self.gen_w2p = self.gen_bias_u = self.gen_w_ih_u = self.gate_part_gen = None
-        if fast and os.environ.get('MTTS_NO_LSTEP', '0') not in ('1', 'gen') and H % 32 == 0:
-            self.gen_w2p = torch.empty(int(lib().mtts_lstm_packed_weight_bytes(H, H, self.precision)), dtype=torch.uint8, device=device)
-            self.gen_bias_u, self.gen_w_ih_u = e(4 * H), e(4 * H, H + Dm)
-            self.gate_part_gen = e(int(lib().mtts_lstm_step_partial_floats(B, H, H)))
+        packed = lambda K: torch.empty(int(lib().mtts_lstm_packed_weight_bytes(H, K, self.precision)), dtype=torch.uint8, device=device)
+        part = lambda K: e(int(lib().mtts_lstm_step_partial_floats(B, H, K)))
+        if fast and off not in ('1', 'gen') and H % 32 == 0:
+            self.gen_w2p, self.gen_bias_u, self.gen_w_ih_u, self.gate_part_gen = packed(H), e(4 * H), e(4 * H, H + Dm), part(H)
         if self.use_lstep:
-            self.att_w2p = torch.empty(int(lib().mtts_lstm_packed_weight_bytes(H, Dm + H, self.precision)), dtype=torch.uint8, device=device)
-            self.att_bias_u, self.att_w_pre_u = e(4 * H), e(4 * H, P)
-            self.gate_part = e(int(lib().mtts_lstm_step_partial_floats(B, H, Dm + H)))
-        # only slot 0 (the initial state) is read before it is written: no need to clear ~1 GB per decode
+            self.att_w2p, self.att_bias_u, self.att_w_pre_u, self.gate_part = packed(Dm + H), e(4 * H), e(4 * H, P), part(Dm + H)
+        if use_lgen:
+            self.att_w2p, self.att_bias_u, self.gate_part = packed(P + Dm + H), e(4 * H), part(P + Dm + H)
+            self.gen_w2p, self.gen_bias_u, self.gate_part_gen = packed(2 * H + Dm), e(4 * H), part(2 * H + Dm)
         def z0(*s):
             t = e(*s)
             t[0].zero_()
             return t
+        # only slot 0 (the initial state) is read before it is written: no need to clear ~1 GB per decode
         self.h_att, self.c_att = z0(T + 1, B, H), z0(T + 1, B, H)
         self.h_gen, self.c_gen = z0(T + 1, B, H), z0(T + 1, B, H)
         self.ctx, self.cum = z0(T + 1, B, Dm), z0(T + 1, B, L)

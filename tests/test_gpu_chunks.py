@@ -26,6 +26,16 @@ def test_multi_chunk_train_step_matches_oracle(preset, B, T):
     run_train_step_case(preset, B, 30, T, {})
 
 
+@pytest.mark.parametrize('preset,B', [('shared_training', 6), ('generated_switching', 10)])
+def test_mixed_teacher_forcing_train_step_at_real_widths(preset, B):
+    """Teacher forcing < 1 (reference evaluate(): train.py:125, Decoder._decode :171,181): the GENERAL schedule - un-hoisted
+    3-segment K-split LSTM steps, fused two-layer prenet step on the model's own frames - and its per-step backward chain,
+    outputs and every gradient against the oracle."""
+    T = 14
+    teacher = [True, False, True, True, False, False, True, False, True, True, False, True, False, False]
+    run_train_step_case(preset, B, 20, T, {}, teacher=teacher)
+
+
 def test_benchmark_shape_forward_matches_oracle():
     """The benchmark's own shape - shared_training, batch 64, 120 characters -> 600 frames (13 chunks), train mode with all
     dropout draws injected - forward only: mel outputs and alignments against the CPU oracle."""

@@ -146,7 +146,7 @@ def test_train_step_gradients_match_oracle_at_real_widths(preset, B, L, T, over)
     run_train_step_case(preset, B, L, T, over)
 
 
-def run_train_step_case(preset, B, L, T, over, check_grads=True, ragged=None):
+def run_train_step_case(preset, B, L, T, over, check_grads=True, ragged=None, teacher=None):
     """One train-mode step of the product on the GPU against the CPU oracle with identical dropout draws: outputs, loss and
     (check_grads) the gradient of every parameter.  Shared by the chunk-boundary tests in test_gpu_chunks.py."""
     from multilingual_text_to_speech_amd.params import presets, Params as hp
@@ -162,7 +162,8 @@ def run_train_step_case(preset, B, L, T, over, check_grads=True, ragged=None):
     g = torch.Generator().manual_seed(21)
     keep = lambda *shape, p: (torch.rand(*shape, generator=g) >= p).to(torch.uint8)
     H, P = hp.decoder_dimension, hp.prenet_dimension
-    inj = {'teacher': [True] * T, 'dec.att_lstm': keep(T, B, H, p=hp.dropout_hidden), 'dec.gen_lstm': keep(T, B, H, p=hp.dropout_hidden)}
+    teacher = [True] * T if teacher is None else [bool(x) for x in teacher]
+    inj = {'teacher': teacher, 'dec.att_lstm': keep(T, B, H, p=hp.dropout_hidden), 'dec.gen_lstm': keep(T, B, H, p=hp.dropout_hidden)}
     inj.update({f'dec.prenet.{i}': keep(T, B, P, p=hp.dropout) for i in range(2)})
     G = hp.language_number if hp.encoder_type == 'generated' else 1
     if hp.encoder_type == 'generated':
@@ -184,6 +185,7 @@ def run_train_step_case(preset, B, L, T, over, check_grads=True, ragged=None):
     om = {'att_lstm': mult(inj['dec.att_lstm'], hp.dropout_hidden), 'gen_lstm': mult(inj['dec.gen_lstm'], hp.dropout_hidden)}
     for i in range(2):
         om[f'prenet.{i}'] = torch.cat((mult(inj[f'dec.prenet.{i}'], hp.dropout).transpose(0, 1), torch.ones(B, 1, P)), 1)
+        om[f'prenet_step.{i}'] = mult(inj[f'dec.prenet.{i}'], hp.dropout)          # free-running steps draw per step ([T,B,P])
     for k, v in inj.items():
         if k.startswith('enc.'):
             om[k] = mult(v, 0.05 if hp.encoder_type == 'generated' else hp.dropout).permute(0, 2, 1)
@@ -191,7 +193,7 @@ def run_train_step_case(preset, B, L, T, over, check_grads=True, ragged=None):
             om[k] = mult(v, hp.dropout).permute(0, 2, 1)
     torch.set_flush_denormal(True)               # CPU speed only: identical output (SURVEY 8c recipe 5)
     with torch.set_grad_enabled(check_grads):
-        ref = O.tacotron_forward(sd, cfg, text, tl, target, tgl, spk, lang, torch.ones(T, dtype=torch.bool), om, True)
+        ref = O.tacotron_forward(sd, cfg, text, tl, target, tgl, spk, lang, torch.tensor(teacher), om, True)
         rloss, _ = O.tacotron_loss(cfg, ref, tl, tgl, target, stop_t, spk, hp.guided_attention_toleration)
     if check_grads:
         rloss.backward()
@@ -201,7 +203,7 @@ def run_train_step_case(preset, B, L, T, over, check_grads=True, ragged=None):
     provider.injected = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in inj.items()}
     try:
         to = lambda t: None if t is None else t.cuda()
-        post, pre, stop, align, spk_pred, enc = model(to(text), tl, to(target), tgl, to(spk), to(lang), 1.0)
+        post, pre, stop, align, spk_pred, enc = model(to(text), tl, to(target), tgl, to(spk), to(lang), 1.0 if all(teacher) else 0.5)
     finally:
         provider.injected = None
     crit = TacotronLoss(hp.guided_attention_steps, hp.guided_attention_toleration, hp.guided_attention_gain)
