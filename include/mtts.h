@@ -382,6 +382,7 @@ typedef struct DecoderArgs {
     float* gen_bias_u;     /* [4H] */
     float* gen_w_ih_u;     /* [4H, H + Dm] rows of W_ih in unit-major order (pre_gen is then unit-major) */
     float* gate_part_gen;  /* mtts_lstm_step_partial_floats(B, H, H) floats */
+    float* prenet_wp[2];   /* free-running steps: MFMA-tile-order copies of the two prenet weights ([P, M] and [P, P]; M, P % 16 == 0) */
     int precision;         /* 0: fp32 (3-way bf16 split products); 1: bf16 operands in the step GEMMs */
 } DecoderArgs;
 

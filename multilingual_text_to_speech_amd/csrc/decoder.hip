@@ -130,6 +130,10 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
             MTTS_TRY(mtts_lstm_pack_weights(&k, s));
             MTTS_TRY(mtts_lstm_rows_unit_major(a.att_w_ih, P + Dm, H, P, a.att_w_pre_u, s));
         }
+        if (a.n_prenet == 2 && a.prenet_wp[0] && a.prenet_wp[1] && (M & 15) == 0 && (P & 15) == 0) {
+            MTTS_TRY(mtts_pack_weight(a.prenet_w[0], M, P, M, 0, a.prenet_wp[0], s));
+            MTTS_TRY(mtts_pack_weight(a.prenet_w[1], P, P, P, 0, a.prenet_wp[1], s));
+        }
         if (use_lg) {
             LstmPackArgs k; memset(&k, 0, sizeof(k));
             k.w[0] = a.att_w_ih; k.K[0] = P; k.ldw[0] = P + Dm;
@@ -183,9 +187,9 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
         if (!teach) {
             // prenet on the model's own previous frame (tacotron2.py:181), out slot t holds frame t-1 (slot 0 = zeros)
             int fused = -1;
-            if (a.n_prenet == 2) {      // both layers in one launch
+            if (a.n_prenet == 2 && a.prenet_wp[0] && a.prenet_wp[1] && (M & 15) == 0 && (P & 15) == 0) {      // both layers in one launch
                 const bool masked = a.p_prenet > 0.f;
-                fused = prenet2_launch(a.out + (long)t * B * Mo, Mo, M, a.prenet_w[0], a.prenet_b[0], a.prenet_w[1], a.prenet_b[1],
+                fused = prenet2_launch(a.out + (long)t * B * Mo, Mo, M, a.prenet_wp[0], a.prenet_b[0], a.prenet_wp[1], a.prenet_b[1],
                                        masked && a.prenet_mask[0] ? a.prenet_mask[0] + t * BP : nullptr,
                                        masked && a.prenet_mask[1] ? a.prenet_mask[1] + t * BP : nullptr, pscale,
                                        a.prenet_act[0] + t * BP, a.prenet_act[1] + t * BP, B, P, s);

@@ -335,28 +335,38 @@ __global__ __launch_bounds__(256) void lstm_cell_q_kernel(LsCell p) {
 // ---------------------------------------------------------------------------------------------------------------------------
 struct Prenet2 {
     const float* x; int ldx; int Kin;           // [B, Kin] (Kin % 4 == 0)
-    const float* w1; const float* b1; const float* w2; const float* b2;
+    const float* w1; const float* b1; const float* w2; const float* b2;      // w1 / w2 in MFMA tile order (mtts_pack_weight)
     const uint8_t* m1; const uint8_t* m2; float scale;
     float* y1; float* y2;                        // [B, P] each
     int B, P;
 };
-constexpr int PN_MAXCT = 2;      // column tiles per wave: P <= 8 waves x 2 x 16 = 256
+constexpr int PN_MAXCT = 2;      // layer-1 column tiles per wave: P <= 8 waves x 2 x 16 = 256
 constexpr int PN_MAXK1 = 6;      // 16-wide k-chunks of layer 1: Kin <= 96
-constexpr int PN_MAXK2 = 16;      // 16-wide k-chunks of layer 2: P <= 256
+constexpr int PN_NCG = 4;        // column groups of layer 2 (grid.y): more workgroups for a 22-MFLOP problem
+constexpr int PN_MAXK2 = 8;      // layer-2 k-chunks per wave: the 8 waves are 4 column tiles x 2 K-halves, P <= 256
 
 __global__ __launch_bounds__(512) void prenet2_kernel(Prenet2 p) {
-    extern __shared__ __attribute__((aligned(16))) float psm[];      // y1 tile [16][P + 4]
+    extern __shared__ __attribute__((aligned(16))) float psm[];      // y1 tile [16][P + 4], then the K-half partial sums [4][16][17]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, q4 = lane >> 4;
-    const int row0 = blockIdx.x * 16;
-    const int P = p.P, ldh = P + 4, nct = P >> 4;
+    const int row0 = blockIdx.x * 16, cg = blockIdx.y;
+    const int P = p.P, ldh = P + 4, nct = P >> 4, nk2 = P >> 4;
     const int arow = min(row0 + i16, p.B - 1);
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    // ---- EVERY global operand of both layers is requested here, before any arithmetic: the kernel is one memory round trip
-    //      (weights come from the Infinity Cache at best: eight other kernels ran since the previous step) plus ~3 us of MFMA
-    float4 a4[PN_MAXK1], b1f[PN_MAXCT][PN_MAXK1], b2f[PN_MAXCT][PN_MAXK2];
-    float bias1[PN_MAXCT], bias2[PN_MAXCT];
-    int keep1[PN_MAXCT][4], keep2[PN_MAXCT][4];
+    const int nk1 = (p.Kin + 15) >> 4;
+    // layer 2 geometry: this workgroup owns column tiles [cg * tpg, (cg + 1) * tpg), tpg <= 4; wave = (tile w & 3, K-half w >> 2)
+    const int tpg = (nct + PN_NCG - 1) / PN_NCG;
+    const int t2 = cg * tpg + (wave & 3), kh = wave >> 2;
+    const bool t2_ok = (wave & 3) < tpg && t2 < nct;
+    const int t2c = min(t2, nct - 1);
+    const int kc_lo = kh * ((nk2 + 1) >> 1), kc_hi = kh ? nk2 : ((nk2 + 1) >> 1);
+    // ---- EVERY global operand of both layers is requested here, before any arithmetic: one memory round trip (weights come
+    //      from the Infinity Cache at best: eight other kernels ran since the previous step), then ~2.5 us of MFMA.
+    //      Weights are in MFMA tile order ([column tile][k chunk][lane][4], mtts_pack_weight): one coalesced 1 KiB read per wave
+    //      instruction - row-major rows would be 64 separate 16-byte requests each and leave the kernel texture-address bound.
+    float4 a4[PN_MAXK1], b1f[PN_MAXCT][PN_MAXK1], b2f[PN_MAXK2];
+    float bias1[PN_MAXCT];
+    int keep1[PN_MAXCT][4];
 #pragma unroll
     for (int kc = 0; kc < PN_MAXK1; ++kc) {
         const int k = 16 * kc + 4 * q4;
@@ -365,26 +375,21 @@ __global__ __launch_bounds__(512) void prenet2_kernel(Prenet2 p) {
 #pragma unroll
         for (int c = 0; c < PN_MAXCT; ++c) {
             const int ct = wave + 8 * c;
-            b1f[c][kc] = (ok && ct < nct) ? *reinterpret_cast<const float4*>(p.w1 + (long)(16 * ct + i16) * p.Kin + k) : z4;
+            b1f[c][kc] = (ok && ct < nct) ? *reinterpret_cast<const float4*>(p.w1 + (((long)ct * nk1 + kc) * 64 + lane) * 4) : z4;
         }
     }
+#pragma unroll
+    for (int kc = 0; kc < PN_MAXK2; ++kc)
+        b2f[kc] = *reinterpret_cast<const float4*>(p.w2 + (((long)t2c * nk2 + min(kc_lo + kc, nk2 - 1)) * 64 + lane) * 4);
 #pragma unroll
     for (int c = 0; c < PN_MAXCT; ++c) {
-        const int ct = min(wave + 8 * c, nct - 1), col = 16 * ct + i16;
+        const int col = 16 * min(wave + 8 * c, nct - 1) + i16;
+        bias1[c] = p.b1[col];
 #pragma unroll
-        for (int kc = 0; kc < PN_MAXK2; ++kc) {
-            const int k = min(16 * kc, P - 16) + 4 * q4;
-            b2f[c][kc] = *reinterpret_cast<const float4*>(p.w2 + (long)col * P + k);
-        }
-        bias1[c] = p.b1[col]; bias2[c] = p.b2[col];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const long mi = (long)min(row0 + 4 * q4 + r, p.B - 1) * P + col;
-            keep1[c][r] = p.m1 ? (int)p.m1[mi] : 1;
-            keep2[c][r] = p.m2 ? (int)p.m2[mi] : 1;
-        }
+        for (int r = 0; r < 4; ++r) keep1[c][r] = p.m1 ? (int)p.m1[(long)min(row0 + 4 * q4 + r, p.B - 1) * P + col] : 1;
     }
-    // ---- layer 1
+    // epilogue operands of layer 2: thread -> (row tid >> 4, column within the tile tid & 15) for tile (tid >> 8) ... see below
+    // ---- layer 1 (every workgroup of a row tile computes all of it: 0.65 MFLOP)
     f32x4 acc[PN_MAXCT];
 #pragma unroll
     for (int c = 0; c < PN_MAXCT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -409,41 +414,42 @@ __global__ __launch_bounds__(512) void prenet2_kernel(Prenet2 p) {
                 float v = fmaxf(acc[c][r] + bias1[c], 0.f);
                 if (row < p.B) {
                     if (p.m1) v = keep1[c][r] ? v * p.scale : 0.f;
-                    p.y1[(long)row * P + col] = v;
+                    if (cg == 0) p.y1[(long)row * P + col] = v;
                 } else v = 0.f;
                 psm[rr * ldh + col] = v;
             }
         }
     }
     __syncthreads();
-    // ---- layer 2
-#pragma unroll
-    for (int c = 0; c < PN_MAXCT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // ---- layer 2: this wave's (column tile, K-half)
+    f32x4 acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kc = 0; kc < PN_MAXK2; ++kc) {
-        if (16 * kc < P) {
-            const float4 h4 = *reinterpret_cast<const float4*>(psm + i16 * ldh + 16 * kc + 4 * q4);
+        if (kc_lo + kc < kc_hi) {
+            const float4 h4 = *reinterpret_cast<const float4*>(psm + i16 * ldh + 16 * (kc_lo + kc) + 4 * q4);
             const float av[4] = {h4.x, h4.y, h4.z, h4.w};
+            const float bv[4] = {b2f[kc].x, b2f[kc].y, b2f[kc].z, b2f[kc].w};
 #pragma unroll
-            for (int c = 0; c < PN_MAXCT; ++c) {
-                const float bv[4] = {b2f[c][kc].x, b2f[c][kc].y, b2f[c][kc].z, b2f[c][kc].w};
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bv[s2], acc[c], 0, 0, 0);
-            }
+            for (int s2 = 0; s2 < 4; ++s2) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bv[s2], acc2, 0, 0, 0);
         }
     }
+    __syncthreads();                                    // all reads of the y1 tile are done: reuse the buffer for the K-half exchange
+    float* red = psm + (wave & 3) * (16 * 17);
+    if (kh == 1) {
 #pragma unroll
-    for (int c = 0; c < PN_MAXCT; ++c) {
-        const int ct = wave + 8 * c;
-        if (ct < nct) {
-            const int col = 16 * ct + i16;
+        for (int r = 0; r < 4; ++r) red[(4 * q4 + r) * 17 + i16] = acc2[r];
+    }
+    __syncthreads();
+    if (kh == 0 && t2_ok) {
+        const int col = 16 * t2 + i16;
+        const float bb = p.b2[col];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = row0 + 4 * q4 + r;
-                float v = fmaxf(acc[c][r] + bias2[c], 0.f);
-                if (p.m2) v = keep2[c][r] ? v * p.scale : 0.f;
-                if (row < p.B) p.y2[(long)row * P + col] = v;
-            }
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + 4 * q4 + r;
+            if (row >= p.B) continue;
+            float v = fmaxf(acc2[r] + red[(4 * q4 + r) * 17 + i16] + bb, 0.f);
+            if (p.m2) v = p.m2[(long)row * P + col] ? v * p.scale : 0.f;
+            p.y2[(long)row * P + col] = v;
         }
     }
 }
@@ -451,11 +457,11 @@ __global__ __launch_bounds__(512) void prenet2_kernel(Prenet2 p) {
 // Returns -1 when the shape is outside the kernel's bounds (the caller then runs the layers one by one), 0 on success.
 int prenet2_launch(const float* x, int ldx, int Kin, const float* w1, const float* b1, const float* w2, const float* b2, const uint8_t* m1,
                    const uint8_t* m2, float scale, float* y1, float* y2, int B, int P, hipStream_t s) {
-    if ((P & 15) != 0 || P > 16 * 8 * PN_MAXCT || Kin > 16 * PN_MAXK1 || (Kin & 3) != 0 || (ldx & 3) != 0 || (((uintptr_t)x | (uintptr_t)w1 | (uintptr_t)w2) & 15) != 0) return -1;
+    if (!w1 || !w2 || (P & 15) != 0 || P > 16 * 8 * PN_MAXCT || Kin > 16 * PN_MAXK1 || (Kin & 15) != 0 || (ldx & 3) != 0 || (((uintptr_t)x | (uintptr_t)w1 | (uintptr_t)w2) & 15) != 0) return -1;
     Prenet2 p;
     p.x = x; p.ldx = ldx; p.Kin = Kin; p.w1 = w1; p.b1 = b1; p.w2 = w2; p.b2 = b2; p.m1 = m1; p.m2 = m2; p.scale = scale;
     p.y1 = y1; p.y2 = y2; p.B = B; p.P = P;
-    hipLaunchKernelGGL(prenet2_kernel, dim3((B + 15) / 16), dim3(512), sizeof(float) * 16 * (P + 4), s, p);
+    hipLaunchKernelGGL(prenet2_kernel, dim3((B + 15) / 16, PN_NCG), dim3(512), sizeof(float) * 16 * (P + 4), s, p);
     if (hipGetLastError() != hipSuccess) return mtts_fail("launch prenet2_kernel failed");
     return 0;
 }

@@ -41,6 +41,9 @@ class DecoderState:
             self.gen_w2p, self.gen_bias_u, self.gen_w_ih_u, self.gate_part_gen = packed(H), e(4 * H), e(4 * H, H + Dm), part(H)
         if self.use_lstep:
             self.att_w2p, self.att_bias_u, self.att_w_pre_u, self.gate_part = packed(Dm + H), e(4 * H), e(4 * H, P), part(Dm + H)
+        self.prenet_wp = None
+        if not fast and n_prenet == 2 and M % 16 == 0 and P % 16 == 0:        # free-running steps: fused two-layer prenet kernel
+            self.prenet_wp = [e(P * M), e(P * P)]
         if use_lgen:
             self.att_w2p, self.att_bias_u, self.gate_part = packed(P + Dm + H), e(4 * H), part(P + Dm + H)
             self.gen_w2p, self.gen_bias_u, self.gate_part_gen = packed(2 * H + Dm), e(4 * H), part(2 * H + Dm)
@@ -91,7 +94,7 @@ class DecoderState:
             else:
                 cur[:old.shape[0]].copy_(old)
         for name in ('U', 'Mt', 'PL', 'qpart', 'att_w_ctx_p', 'att_w_hh_p', 'gen_w_hh_p', 'w_query_p', 'att_w2p', 'att_bias_u', 'att_w_pre_u',
-                     'gate_part', 'gen_w2p', 'gen_bias_u', 'gen_w_ih_u', 'gate_part_gen'):      # per-call constants
+                     'gate_part', 'gen_w2p', 'gen_bias_u', 'gen_w_ih_u', 'gate_part_gen', 'prenet_wp'):      # per-call constants
             setattr(new, name, getattr(self, name))
         return new
 
@@ -110,6 +113,8 @@ def fill_decoder_args(a, st, w, memory, lengths32, frames_in, teacher_host, mask
         pm = masks.get(f'prenet.{i}')
         a.prenet_mask[i] = pm.data_ptr() if pm is not None else None
         a.prenet_act[i] = st.prenet_act[i].data_ptr()
+    if getattr(st, 'prenet_wp', None) is not None:
+        a.prenet_wp[0], a.prenet_wp[1] = st.prenet_wp[0].data_ptr(), st.prenet_wp[1].data_ptr()
     for name in ('att_w_ih', 'att_w_hh', 'att_b_ih', 'att_b_hh', 'gen_w_ih', 'gen_w_hh', 'gen_b_ih', 'gen_b_hh', 'w_query',
                  'w_memory', 'w_loc', 'w_conv', 'att_bias', 'w_energy', 'w_out', 'b_out'):
         setattr(a, name, ptr(w[name]))
