@@ -592,6 +592,32 @@ typedef struct AdamArgs {
 
 int mtts_clip_adam_step(const AdamArgs* args, void* stream);
 
+/* ---- parameter generator of the 'generated' encoder (K2) ---------------------------------------------------------------------
+ * Replaces the second Linear of Conv1dGenerated + the .view + the layout change in front of F.conv1d (modules/generated.py:34-42):
+ * w_packed[(g Og + o), t, c] = b_kernel[j] + sum_b hidden[g, b] w_kernel[j, b],  j = (o Cg + c) k + t   (the implicit-GEMM layout
+ * [O, k, I/G] that mtts_gemm_ex consumes), and backwards from the conv's packed weight gradient:
+ * d_w_kernel[j, b] = sum_g d_w_packed[g, j] hidden[g, b];  d_b_kernel[j] = sum_g d_w_packed[g, j];
+ * d_hidden[g, b] = sum_j d_w_packed[g, j] w_kernel[j, b] as per-workgroup partial rows (sum them with mtts_colsum). */
+typedef struct GenParamsArgs {
+    const float* hidden;        /* [G, bott] output of the bottleneck Linear */
+    const float* w_kernel;      /* [Og*Cg*k, bott] */
+    const float* b_kernel;      /* [Og*Cg*k] or NULL */
+    float* w_packed;            /* fwd out: [G*Og, k, Cg] */
+    const float* d_w_packed;    /* bwd in */
+    float* d_w_kernel;          /* bwd out */
+    float* d_b_kernel;          /* bwd out or NULL */
+    float* d_hidden_slab;       /* bwd out: [mtts_gen_params_slabs(Og, Cg)][G*bott] */
+    int G;
+    int bott;
+    int Og;
+    int Cg;
+    int k;
+} GenParamsArgs;
+
+long mtts_gen_params_slabs(int Og, int Cg);
+int mtts_gen_params_fwd(const GenParamsArgs* args, void* stream);
+int mtts_gen_params_bwd(const GenParamsArgs* args, void* stream);
+
 /* ---- small data-movement kernels --------------------------------------------------------------------------- */
 /* Embedding lookup (modules/tacotron2.py:363, :122 speaker/language tables): out[r, col0:col0+D] = table[ids[r]].
  * `vocab` = rows of the table.  An id outside [0, vocab) reads as a zero row, never touches memory and sets *err (device int,
@@ -635,7 +661,7 @@ float mtts_prof_empty_ms(void);
 
 const char* mtts_last_error(void);
 int mtts_version(void);
-/* sizeof() of the structs above in declaration order (0 = GemmArgs ... 6 = BiLstmArgs, 7 = AttnBwdArgs, 8 = DecoderGradArgs, 9 = BiLstmGradArgs, 10 = TacoLossArgs, 11 = AdamArgs, 12 = LstmPackArgs, 13 = LstmStepArgs); -1 when out of range */
+/* sizeof() of the structs above in declaration order (0 = GemmArgs ... 6 = BiLstmArgs, 7 = AttnBwdArgs, 8 = DecoderGradArgs, 9 = BiLstmGradArgs, 10 = TacoLossArgs, 11 = AdamArgs, 12 = LstmPackArgs, 13 = LstmStepArgs, 14 = GenParamsArgs); -1 when out of range */
 int mtts_sizeof_struct(int which);
 
 #ifdef __cplusplus

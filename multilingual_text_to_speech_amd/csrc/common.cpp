@@ -33,6 +33,7 @@ MTTS_API int mtts_sizeof_struct(int which) {
         case 11: return (int)sizeof(AdamArgs);
         case 12: return (int)sizeof(LstmPackArgs);
         case 13: return (int)sizeof(LstmStepArgs);
+        case 14: return (int)sizeof(GenParamsArgs);
         default: return -1;
     }
 }

@@ -224,12 +224,13 @@ class ConvBnActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, rmean, rvar, mask, cfg):
-        k, dilation, groups, act, training, momentum, eps, mask_scale, highway = cfg
+        k, dilation, groups, act, training, momentum, eps, mask_scale, highway = cfg[:9]
+        packed = len(cfg) > 9 and cfg[9]          # weight already in the implicit-GEMM layout [O, k, I/G] (generated kernels)
         require_gpu(x, weight)
         x = x.contiguous()
         N_, L, Cin = x.shape
         O = weight.shape[0]
-        wp = pack_conv_weight(weight)
+        wp = weight.contiguous() if packed else pack_conv_weight(weight)
         conv = conv1d_fwd(x, wp, k, dilation, groups)
         conv2 = conv.view(N_ * L, O)
         dev = x.device
@@ -247,7 +248,8 @@ class ConvBnActFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, wp, conv, gamma, beta, smean, srstd, mask = ctx.saved_tensors
-        k, dilation, groups, act, training, momentum, eps, mask_scale, highway = ctx.cfg
+        k, dilation, groups, act, training, momentum, eps, mask_scale, highway = ctx.cfg[:9]
+        packed = len(ctx.cfg) > 9 and ctx.cfg[9]
         N_, L, Cin = x.shape
         O = conv.shape[2]
         dev = x.device
@@ -263,14 +265,59 @@ class ConvBnActFn(torch.autograd.Function):
         dx, dwp = conv1d_bwd(x, wp, dconv, k, dilation, groups, ctx.needs_input_grad[0] or highway)
         if highway:
             dx = dx + dresid
-        dw = unpack_conv_weight(dwp, *ctx.wshape)
+        dw = dwp if packed else unpack_conv_weight(dwp, *ctx.wshape)
         return dx, dw, dgamma, dbeta, None, None, None, None
 
 
 def conv_bn_act(x, weight, gamma, beta, rmean, rvar, mask, *, kernel, dilation=1, groups=1, act='identity', training=True,
-                momentum=0.1, eps=1e-5, mask_scale=1.0, highway=False):
-    cfg = (kernel, dilation, groups, ACT[act], training, momentum, eps, mask_scale, highway)
+                momentum=0.1, eps=1e-5, mask_scale=1.0, highway=False, packed=False):
+    cfg = (kernel, dilation, groups, ACT[act], training, momentum, eps, mask_scale, highway, packed)
     return ConvBnActFn.apply(x, weight, gamma, beta, rmean, rvar, mask, cfg)
+
+
+class GenKernelFn(torch.autograd.Function):
+    """Generated convolution kernel straight into the implicit-GEMM layout (reference Conv1dGenerated.forward,
+    modules/generated.py:34-42): hidden [G, bott] x w_kernel [(O/G)(I/G)k, bott]^T + b_kernel -> packed [O, k, I/G].
+    One bandwidth-bound kernel each way (mtts_gen_params_fwd / _bwd) instead of a padded MFMA GEMM + view + repack."""
+
+    @staticmethod
+    def forward(ctx, hidden, w_kernel, b_kernel, dims):
+        Og, Cg, k = dims
+        require_gpu(hidden, w_kernel)
+        hidden, w_kernel = hidden.contiguous(), w_kernel.contiguous()
+        G, bott = hidden.shape
+        wp = _f32(G * Og, k, Cg, device=hidden.device)
+        a = _C.GenParamsArgs()
+        a.hidden, a.w_kernel, a.b_kernel, a.w_packed = ptr(hidden), ptr(w_kernel), ptr(b_kernel), ptr(wp)
+        a.G, a.bott, a.Og, a.Cg, a.k = G, bott, Og, Cg, k
+        check(lib().mtts_gen_params_fwd(ctypes.byref(a), stream_ptr()), 'mtts_gen_params_fwd')
+        ctx.save_for_backward(hidden, w_kernel)
+        ctx.dims, ctx.has_bias = dims, b_kernel is not None
+        return wp
+
+    @staticmethod
+    def backward(ctx, dwp):
+        hidden, w_kernel = ctx.saved_tensors
+        Og, Cg, k = ctx.dims
+        G, bott = hidden.shape
+        dev = hidden.device
+        dwp = dwp.contiguous()
+        nslab = int(lib().mtts_gen_params_slabs(Og, Cg))
+        dwk = _f32(*w_kernel.shape, device=dev)
+        dbk = _f32(w_kernel.shape[0], device=dev) if ctx.has_bias else None
+        slab = _f32(nslab, G * bott, device=dev)
+        a = _C.GenParamsArgs()
+        a.hidden, a.w_kernel, a.d_w_packed, a.d_w_kernel, a.d_b_kernel, a.d_hidden_slab = ptr(hidden), ptr(w_kernel), ptr(dwp), ptr(dwk), ptr(dbk), ptr(slab)
+        a.G, a.bott, a.Og, a.Cg, a.k = G, bott, Og, Cg, k
+        check(lib().mtts_gen_params_bwd(ctypes.byref(a), stream_ptr()), 'mtts_gen_params_bwd')
+        dhid = _f32(G * bott, device=dev)
+        ws = _f32(int(lib().mtts_colsum_workspace_floats(G * bott)), device=dev)
+        check(lib().mtts_colsum(ptr(slab), ptr(dhid), nslab, G * bott, G * bott, ptr(ws), stream_ptr()), 'mtts_colsum')
+        return dhid.view(G, bott), dwk, dbk, None
+
+
+def generated_kernel(hidden, w_kernel, b_kernel, Og, Cg, k):
+    return GenKernelFn.apply(hidden, w_kernel, b_kernel, (Og, Cg, k))
 
 
 # ------------------------------------------------------------------------------------------------

@@ -38,6 +38,19 @@ class Conv1dGenerated(_TwoStageGenerator):
         flat = self._emit(generator_embedding, self._kernel, 'Conv1dGenerated')
         return flat.view(self._out_channels, self._in_channels // self._groups, self._kernel_size)
 
+    def generate_packed(self, generator_embedding):
+        """-> kernel in the implicit-GEMM layout [O, k, I / G], written directly by the generator kernel (mtts_gen_params_fwd);
+        None when the shape is outside that kernel's bounds (the caller then uses generate())."""
+        G, k = self._groups, self._kernel_size
+        Og, Cg = self._out_channels // G, self._in_channels // G
+        bott = self._bottleneck.weight.shape[0]
+        if generator_embedding.shape[0] != G:
+            raise AssertionError(f'Conv1dGenerated: {generator_embedding.shape[0]} generator embeddings for {G} groups')
+        if G > 16 or bott > 8 or k > 8 or Og * Cg * k != self._kernel.weight.shape[0]:
+            return None
+        hidden = K.linear(generator_embedding, self._bottleneck.weight, self._bottleneck.bias)
+        return K.generated_kernel(hidden, self._kernel.weight, self._kernel.bias, Og, Cg, k)
+
 
 class BatchNorm1dGenerated(_TwoStageGenerator):
     def __init__(self, embedding_dim, bottleneck_dim, num_features, groups=1, eps=1e-8, momentum=0.1):

@@ -103,7 +103,10 @@ class ConvBlockGenerated(Module):
 
     def _run(self, e, x, mask_name, highway):
         training = self.training
-        weight = self._convolution.generate(e)
+        weight = self._convolution.generate_packed(e)           # implicit-GEMM layout straight from the generator kernel
+        packed = weight is not None
+        if not packed:
+            weight = self._convolution.generate(e)
         gamma, beta = self._regularizer.generate(e)
         reg = self._regularizer
         mask = None
@@ -114,7 +117,8 @@ class ConvBlockGenerated(Module):
         return K.conv_bn_act(x, weight, gamma, beta, reg.running_mean, reg.running_var, mask, kernel=self._kernel,
                              dilation=self._dilation, groups=self._groups, act=self._activation_name, training=training,
                              momentum=reg._momentum, eps=reg._eps,
-                             mask_scale=1.0 / (1.0 - self._dropout_rate) if self._dropout_rate > 0 else 1.0, highway=highway)
+                             mask_scale=1.0 / (1.0 - self._dropout_rate) if self._dropout_rate > 0 else 1.0, highway=highway,
+                             packed=packed)
 
     def forward(self, e, x, mask_name=None):
         return self._run(e, x, mask_name, False)

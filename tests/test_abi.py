@@ -23,7 +23,7 @@ def test_every_declared_symbol_is_exported(library):
 
 
 def test_struct_mirrors_match_compiler_layout(library):
-    order = ['GemmArgs', 'BnArgs', 'SkSeg', 'SkinnyArgs', 'AttnStepArgs', 'DecoderArgs', 'BiLstmArgs', 'AttnBwdArgs', 'DecoderGradArgs', 'BiLstmGradArgs', 'TacoLossArgs', 'AdamArgs', 'LstmPackArgs', 'LstmStepArgs']
+    order = ['GemmArgs', 'BnArgs', 'SkSeg', 'SkinnyArgs', 'AttnStepArgs', 'DecoderArgs', 'BiLstmArgs', 'AttnBwdArgs', 'DecoderGradArgs', 'BiLstmGradArgs', 'TacoLossArgs', 'AdamArgs', 'LstmPackArgs', 'LstmStepArgs', 'GenParamsArgs']
     for i, name in enumerate(order):
         assert library.mtts_sizeof_struct(i) == ctypes.sizeof(_C.STRUCTS[name]), name
     assert library.mtts_sizeof_struct(len(order)) == -1
