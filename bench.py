@@ -419,7 +419,7 @@ def main():
             'empty_bracket_us': round(empty_s * 1e6, 2), 'hbm_frac_of_8TBps': round(bytes_alg / avg_s / 8e12, 4) if avg_s > 0 else 0.0,
             'samples': cnt.value, 'sampled_in': 'the timed train steps (side streams active)'}}
         line = {
-            'metric': 'mel-frames/sec (train, fwd+bwd+optimizer, batch 64/GPU, 120 chars -> 600 frames)',
+            'metric': f'mel-frames/sec (train, fwd+bwd+optimizer, batch {B}/GPU, {L} chars -> {T} frames)',
             'value': round(frames / dt, 1), 'unit': 'mel-frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * dt / args.steps, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic',
