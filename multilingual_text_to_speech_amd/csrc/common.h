@@ -114,6 +114,7 @@ int add3(float* out, int ldo, const float* a, int lda, const float* b, int ldb, 
          bool accumulate, hipStream_t s);
 int attn_bwd_plus_skinny(const AttnBwdArgs& a, const SkinnyArgs& k, hipStream_t s);
 int lstm_step_launch(const LstmStepArgs& a, hipStream_t s);
+int lstm_step2_launch(const LstmStepArgs& a, const LstmStepArgs& b, hipStream_t s);
 int sum_slabs(const float* part, int n, long stride, int ldp, const float* bias, float* out, int rows, int cols, int ldo, int act, hipStream_t s);
 int prenet2_launch(const float* x, int ldx, int Kin, const float* w1, const float* b1, const float* w2, const float* b2, const uint8_t* m1,
                    const uint8_t* m2, float scale, float* y1, float* y2, int B, int P, hipStream_t s);

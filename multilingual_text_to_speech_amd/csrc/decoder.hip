@@ -41,35 +41,57 @@ static bool gen_uses_lstep(const DecoderArgs& a) {
     return a.fast && a.gen_w2p && a.gen_bias_u && a.gen_w_ih_u && a.gate_part_gen && (a.H & 31) == 0;
 }
 
-static int gen_chunk(const DecoderArgs& a, int c0, int c1, hipStream_t s) {
-    const int B = a.B, M = a.M, H = a.H, Dm = a.Dm;
-    const bool use_ls = gen_uses_lstep(a);
-    const float* w_ih = use_ls ? a.gen_w_ih_u : a.gen_w_ih;      // unit-major rows -> unit-major pre_gen
-    const int Mo = round4(M + 1), n = c1 - c0;
+// pre_gen[c0, c1) = [h_att, ctx] W_ih^T (batched over the chunk's steps)
+static int gen_pre(const DecoderArgs& a, int c0, int c1, int region, hipStream_t s) {
+    const int B = a.B, H = a.H, Dm = a.Dm, n = c1 - c0;
+    const float* w_ih = gen_uses_lstep(a) ? a.gen_w_ih_u : a.gen_w_ih;      // unit-major rows -> unit-major pre_gen
     const long BH = (long)B * H, BD = (long)B * Dm, B4H = 4 * BH;
     GemmArgs g; memset(&g, 0, sizeof(g));
-    g.taps = 1; g.batch = 1; g.zt = 1; g.alpha = 1.f; g.mask_scale = 1.f; g.nosplit = 1;
-    // pre_gen = [h_att, ctx] W_ih^T
+    g.taps = 1; g.batch = 1; g.zt = 1; g.alpha = 1.f; g.mask_scale = 1.f; g.nosplit = region;
     g.A = a.h_att + (c0 + 1) * BH; g.B = w_ih; g.C = a.pre_gen + c0 * B4H;
     g.M = n * B; g.N = 4 * H; g.K = H; g.Kc = H; g.lda = H; g.ldb = H + Dm; g.ldc = 4 * H; g.beta = 0.f;
     MTTS_TRY(mtts_gemm_ex(&g, s));
     g.A = a.ctx + (c0 + 1) * BD; g.B = w_ih + H; g.K = Dm; g.Kc = Dm; g.lda = Dm; g.beta = 1.f;
+    return mtts_gemm_ex(&g, s);
+}
+
+// frame / stop projection of steps [c0, c1) (batched)
+static int gen_proj(const DecoderArgs& a, int c0, int c1, int region, hipStream_t s) {
+    const int B = a.B, M = a.M, H = a.H, Dm = a.Dm, Mo = round4(M + 1), n = c1 - c0;
+    const long BH = (long)B * H, BD = (long)B * Dm;
+    GemmArgs g; memset(&g, 0, sizeof(g));
+    g.taps = 1; g.batch = 1; g.zt = 1; g.alpha = 1.f; g.mask_scale = 1.f; g.nosplit = region;
+    g.A = a.h_gen + (c0 + 1) * BH; g.B = a.w_out; g.C = a.out + (long)(c0 + 1) * B * Mo; g.bias = a.b_out;
+    g.M = n * B; g.N = M + 1; g.K = H; g.Kc = H; g.lda = H; g.ldb = H + Dm; g.ldc = Mo; g.beta = 0.f;
     MTTS_TRY(mtts_gemm_ex(&g, s));
+    g.A = a.ctx + (c0 + 1) * BD; g.B = a.w_out + H; g.bias = nullptr; g.K = Dm; g.Kc = Dm; g.lda = Dm; g.beta = 1.f;
+    return mtts_gemm_ex(&g, s);
+}
+
+// K-split step arguments of the generator LSTM (recurrent part; the input projection sits in pre_gen)
+static LstmStepArgs gen_step_args(const DecoderArgs& a, int t) {
+    const int B = a.B, H = a.H;
+    const long BH = (long)B * H, B4H = 4 * BH;
+    LstmStepArgs k; memset(&k, 0, sizeof(k));
+    k.x[0] = a.h_gen + t * BH; k.K[0] = H; k.ldx[0] = H; k.nseg = 1;
+    k.w_packed = a.gen_w2p; k.precision = a.precision; k.B = B; k.H = H; k.partials = a.gate_part_gen;
+    k.pre = a.pre_gen + t * B4H; k.ldpre = 4 * H; k.bias_u = a.gen_bias_u;
+    k.h_prev = a.h_gen + t * BH; k.c_prev = a.c_gen + t * BH;
+    k.h_out = a.h_gen + (t + 1) * BH; k.c_out = a.c_gen + (t + 1) * BH;
+    k.gates_out = a.gates_gen ? a.gates_gen + t * B4H : nullptr;
+    SkinnyArgs r; memset(&r, 0, sizeof(r));
+    lstm_reg(a, r, a.gen_hmask, a.gen_cmask, t);
+    k.hmask = r.hmask; k.cmask = r.cmask; k.hscale = r.hscale; k.zone = r.zone; k.zh = r.zh; k.zc = r.zc;
+    return k;
+}
+
+// recurrent steps [c0, c1) of the generator LSTM on their own (side-stream chain / tail of the fused schedule)
+static int gen_steps(const DecoderArgs& a, int c0, int c1, hipStream_t s) {
+    const int B = a.B, H = a.H;
+    const long BH = (long)B * H, B4H = 4 * BH;
+    const bool use_ls = gen_uses_lstep(a);
     for (int t = c0; t < c1; ++t) {
-        if (use_ls) {
-            LstmStepArgs k; memset(&k, 0, sizeof(k));
-            k.x[0] = a.h_gen + t * BH; k.K[0] = H; k.ldx[0] = H; k.nseg = 1;
-            k.w_packed = a.gen_w2p; k.precision = a.precision; k.B = B; k.H = H; k.partials = a.gate_part_gen;
-            k.pre = a.pre_gen + t * B4H; k.ldpre = 4 * H; k.bias_u = a.gen_bias_u;
-            k.h_prev = a.h_gen + t * BH; k.c_prev = a.c_gen + t * BH;
-            k.h_out = a.h_gen + (t + 1) * BH; k.c_out = a.c_gen + (t + 1) * BH;
-            k.gates_out = a.gates_gen ? a.gates_gen + t * B4H : nullptr;
-            SkinnyArgs r; memset(&r, 0, sizeof(r));
-            lstm_reg(a, r, a.gen_hmask, a.gen_cmask, t);
-            k.hmask = r.hmask; k.cmask = r.cmask; k.hscale = r.hscale; k.zone = r.zone; k.zh = r.zh; k.zc = r.zc;
-            MTTS_TRY(lstm_step_launch(k, s));
-            continue;
-        }
+        if (use_ls) { MTTS_TRY(lstm_step_launch(gen_step_args(a, t), s)); continue; }
         SkinnyArgs k; memset(&k, 0, sizeof(k));
         k.B = B; k.N = 4 * H; k.ksplit = 1; k.lstm = 1; k.H = H; k.nseg = 1;
         k.seg[0] = seg_h(a.h_gen, a.h_gen_p, t, B, H, a.gen_w_hh, a.gen_w_hh_p, H);
@@ -82,13 +104,14 @@ static int gen_chunk(const DecoderArgs& a, int c0, int c1, hipStream_t s) {
         lstm_reg(a, k, a.gen_hmask, a.gen_cmask, t);
         MTTS_TRY(skinny_launch(k, s));
     }
-    float* o = a.out + (long)(c0 + 1) * B * Mo;
-    g.A = a.h_gen + (c0 + 1) * BH; g.B = a.w_out; g.C = o; g.bias = a.b_out;
-    g.M = n * B; g.N = M + 1; g.K = H; g.Kc = H; g.lda = H; g.ldb = H + Dm; g.ldc = Mo; g.beta = 0.f;
-    MTTS_TRY(mtts_gemm_ex(&g, s));
-    g.A = a.ctx + (c0 + 1) * BD; g.B = a.w_out + H; g.bias = nullptr; g.K = Dm; g.Kc = Dm; g.lda = Dm; g.beta = 1.f;
-    MTTS_TRY(mtts_gemm_ex(&g, s));
     return 0;
+}
+
+// Chain B of the two-stream fast schedule for steps [c0, c1): input gates (batched), recurrent steps, projection (batched)
+static int gen_chunk(const DecoderArgs& a, int c0, int c1, hipStream_t s) {
+    MTTS_TRY(gen_pre(a, c0, c1, 1, s));
+    MTTS_TRY(gen_steps(a, c0, c1, s));
+    return gen_proj(a, c0, c1, 1, s);
 }
 
 MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
@@ -178,11 +201,19 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
                             use_ls ? P : P + Dm, 4 * H, false, false, 1.f, 0.f, nullptr, 0, s));
     }
 
-    // fast schedule: chain B trails chain A chunk by chunk on the side stream
+    // fast schedule: chain B trails chain A by one chunk on the side stream.
+    // MTTS_FUSE2=1 (experiment, off): the generator LSTM's step t - CH rides in the SAME two launches as the attention LSTM's
+    // step t (lstm_step2_launch), everything on the caller's stream.  Measured 53.9 vs 50.5 us per decoder step and 94.7 vs
+    // 92.0 ms per train step: although the two chains' step kernels hardly overlap (4 % of the wall time), the side stream
+    // fills exactly the ramp / drain / boundary gaps of chain A, and a 512-workgroup fused launch has a longer tail than two
+    // 256-workgroup launches on two queues.
     const int CH = decoder_chunk();
-    hipStream_t sb = a.fast ? side_stream(s) : nullptr;
-    if (a.fast && !sb) return mtts_fail("decoder: cannot create the side stream");
+    static const bool want_fuse2 = [] { const char* e = getenv("MTTS_FUSE2"); return e && e[0] == '1'; }();
+    const bool fuse2 = use_ls && gen_uses_lstep(a) && want_fuse2;
+    hipStream_t sb = (a.fast && !fuse2) ? side_stream(s) : nullptr;
+    if (a.fast && !fuse2 && !sb) return mtts_fail("decoder: cannot create the side stream");
     for (int t = a.t0; t < a.t1; ++t) {
+        if (fuse2 && t > a.t0 && ((t - a.t0) % CH) == 0) MTTS_TRY(gen_pre(a, t - CH, t, 0, s));      // input gates of the chunk chain B enters now
         const bool teach = a.frames_in && a.teacher && a.teacher[t];
         if (!teach) {
             // prenet on the model's own previous frame (tacotron2.py:181), out slot t holds frame t-1 (slot 0 = zeros)
@@ -224,7 +255,8 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
             }
             k.w_query = a.w_query; k.A = A; k.qpart = a.qpart;
             const bool sampled = prof_sample(t, s, 0);
-            MTTS_TRY(lstm_step_launch(k, s));
+            if (fuse2 && t - CH >= a.t0) MTTS_TRY(lstm_step2_launch(k, gen_step_args(a, t - CH), s));
+            else MTTS_TRY(lstm_step_launch(k, s));
             if (sampled) prof_sample(t, s, 1);
         } else {   // attention LSTM (tacotron2.py:184-185)
             SkinnyArgs k; memset(&k, 0, sizeof(k));
@@ -268,6 +300,7 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
             q.ctx_pack_out = a.ctx_p ? a.ctx_p + (long)(t + 1) * bp16(B) * Dm : nullptr;
             q.B = B; q.L = L; q.A = A; q.Dm = Dm; q.ksz = a.ksz;
             q.nch = (Dm + 511) / 512; if (q.nch < 4 && B * 4 <= 1024) q.nch = 4;
+            { const char* e = getenv("MTTS_ATTN_NCH"); if (e && atoi(e) > 0) q.nch = atoi(e); }      // tuning knob (scripts/sweep_nch.sh)
             if ((L + q.nch - 1) / q.nch > 64 && L <= 256) q.nch = (L + 63) / 64;      // <= 64 rows of PL_next per workgroup (MFMA path)
             MTTS_TRY(attn_step_launch(q, s));
         }
@@ -317,13 +350,19 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
                 }
             }
         }
-        if (a.fast && (((t + 1 - a.t0) % CH) == 0 || t + 1 == a.t1)) {
+        if (a.fast && !fuse2 && (((t + 1 - a.t0) % CH) == 0 || t + 1 == a.t1)) {
             const int c1 = t + 1, c0 = a.t0 + ((c1 - a.t0 - 1) / CH) * CH;
             hipEvent_t ev = pool_event(s);
             MTTS_CHECK_HIP(hipEventRecord(ev, s));
             MTTS_CHECK_HIP(hipStreamWaitEvent(sb, ev, 0));
             MTTS_TRY(gen_chunk(a, c0, c1, sb));
         }
+    }
+    if (fuse2) {      // tail: chain B's last chunk on its own, then ONE projection GEMM pair over all steps
+        const int last0 = a.t0 + ((nsteps - 1) / CH) * CH;                 // first step of the last (possibly ragged) chunk
+        MTTS_TRY(gen_pre(a, last0, a.t1, 0, s));
+        MTTS_TRY(gen_steps(a, nsteps > CH ? a.t1 - CH : a.t0, a.t1, s));
+        return gen_proj(a, a.t0, a.t1, 0, s);
     }
     if (a.fast) {     // join: the caller's stream continues after chain B
         hipEvent_t ev = pool_event(s);

@@ -119,12 +119,11 @@ struct LsGates {
 };
 
 template <int PREC, int NB>      // NB: k-blocks per K-slice held in registers (the smallest instantiation that fits is launched)
-__global__ __launch_bounds__(LS_THREADS) void lstm_gates_kernel(LsGates p) {
-    extern __shared__ __attribute__((aligned(16))) char sm[];
+__device__ __forceinline__ void lstm_gates_body(const LsGates& p, const int bid, char* sm) {
     constexpr int NPL = PREC ? 1 : 3;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int s = blockIdx.x % p.KS, j = blockIdx.x / p.KS;
+    const int s = bid % p.KS, j = bid / p.KS;
     const int kb0 = (int)((long)s * p.nkb / p.KS), kb1 = (int)((long)(s + 1) * p.nkb / p.KS);
     const int nb = kb1 - kb0;                           // <= NB (host guarantees); blocks kb >= nb are skipped by wave-uniform guards
     const int i16 = lane & 15, q4 = lane >> 4;
@@ -234,6 +233,22 @@ __global__ __launch_bounds__(LS_THREADS) void lstm_gates_kernel(LsGates p) {
 #undef LS_LOAD_X
 }
 
+template <int PREC, int NB>
+__global__ __launch_bounds__(LS_THREADS) void lstm_gates_kernel(LsGates p) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    lstm_gates_body<PREC, NB>(p, blockIdx.x, sm);
+}
+
+// Two independent gate GEMMs in ONE launch (attention LSTM of step t and generator LSTM of step t - chunk): the decoder's step
+// kernels fill the chip and serialise anyway, so a second launch only adds its ramp and drain (~3-4 us).  Workgroups [0, na)
+// belong to problem a.  (Both argument blocks are read through direct scalar loads: no address select on the kernel argument.)
+template <int PREC, int NB>
+__global__ __launch_bounds__(LS_THREADS) void lstm_gates2_kernel(LsGates a, LsGates b, int na) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    if ((int)blockIdx.x < na) lstm_gates_body<PREC, NB>(a, blockIdx.x, sm);
+    else lstm_gates_body<PREC, NB>(b, blockIdx.x - na, sm);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // C: partial sum + LSTM cell + query partials.  Workgroup = 16 units x 16 rows, thread = one (row, unit).
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -250,8 +265,7 @@ struct LsCell {
 
 constexpr int LC_MAXCT = 4;      // query column tiles per wave: A <= 4 waves x 4 x 16 = 256
 
-__global__ __launch_bounds__(256) void lstm_cell_q_kernel(LsCell p) {
-    __shared__ float hs[16][17];
+__device__ __forceinline__ void lstm_cell_q_body(const LsCell& p, float (&hs)[16][17]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ut = blockIdx.x, rt = blockIdx.y;
     const int r = tid >> 4, uu = tid & 15;
@@ -326,6 +340,17 @@ __global__ __launch_bounds__(256) void lstm_cell_q_kernel(LsCell p) {
             if (orow < p.B) out[(long)orow * p.A] = acc[rr];
         }
     }
+}
+
+__global__ __launch_bounds__(256) void lstm_cell_q_kernel(LsCell p) {
+    __shared__ float hs[16][17];
+    lstm_cell_q_body(p, hs);
+}
+
+__global__ __launch_bounds__(256) void lstm_cell_q2_kernel(LsCell a, LsCell b) {      // blockIdx.z selects the problem
+    __shared__ float hs[16][17];
+    if (blockIdx.z == 0) lstm_cell_q_body(a, hs);
+    else lstm_cell_q_body(b, hs);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -511,26 +536,44 @@ MTTS_API int mtts_lstm_rows_unit_major(const float* src, int ld, int H, int K, f
     return 0;
 }
 
-int lstm_step_launch(const LstmStepArgs& a, hipStream_t s) {
+static int ls_marshal(const LstmStepArgs& a, LsGates& g, LsCell& c) {
     MTTS_TRY(ls_check_segs(a.nseg, a.K, a.ldx, "mtts_lstm_step_fwd"));
     MTTS_REQUIRE(a.B > 0 && a.H > 0 && (a.H & 31) == 0, "mtts_lstm_step_fwd: H must be a multiple of 32 (H=%d)", a.H);
     MTTS_REQUIRE(a.w_packed && a.partials && a.c_prev && a.h_out && a.c_out, "mtts_lstm_step_fwd: missing buffers");
     MTTS_REQUIRE(!a.qpart || (a.w_query && (a.A & 15) == 0 && a.A <= 16 * 4 * LC_MAXCT), "mtts_lstm_step_fwd: query partials need A %% 16 == 0, A <= %d",
                  16 * 4 * LC_MAXCT);
     for (int i = 0; i < a.nseg; ++i) MTTS_REQUIRE(((uintptr_t)a.x[i] & 15) == 0, "mtts_lstm_step_fwd: x[%d] must be 16-byte aligned", i);
-    LsGates g; memset(&g, 0, sizeof(g));
+    memset(&g, 0, sizeof(g));
     g.x0 = a.x[0]; g.K0 = a.K[0]; g.ld0 = a.ldx[0];
     g.x1 = a.nseg > 1 ? a.x[1] : a.x[0]; g.K1 = a.nseg > 1 ? a.K[1] : 0; g.ld1 = a.nseg > 1 ? a.ldx[1] : a.ldx[0];
     g.x2 = a.nseg > 2 ? a.x[2] : a.x[0]; g.K2 = a.nseg > 2 ? a.K[2] : 0; g.ld2 = a.nseg > 2 ? a.ldx[2] : a.ldx[0];
     g.wp = a.w_packed; g.nkb = (g.K0 + g.K1 + g.K2) / 32; g.KS = ls_ksplit(g.nkb); g.B = a.B; g.N = 4 * a.H; g.part = a.partials;
     g.nbmax = (g.nkb + g.KS - 1) / g.KS;
-    const int ntile = (4 * a.H) / LS_COLS;
+    memset(&c, 0, sizeof(c));
+    c.part = a.partials; c.KS = g.KS; c.B = a.B; c.H = a.H; c.pre = a.pre; c.ldpre = a.ldpre; c.bias_u = a.bias_u;
+    c.h_prev = a.h_prev; c.c_prev = a.c_prev; c.h_out = a.h_out; c.c_out = a.c_out; c.gates_out = a.gates_out;
+    c.hmask = a.hmask; c.cmask = a.cmask; c.hscale = a.hscale; c.zone = a.zone; c.zh = a.zh; c.zc = a.zc;
+    c.wq = a.qpart ? a.w_query : nullptr; c.A = a.A; c.qpart = a.qpart;
+    MTTS_REQUIRE(!(c.zone && !c.h_prev), "mtts_lstm_step_fwd: zoneout needs h_prev");
+    return 0;
+}
+
+static int ls_set_attrs() {
     static bool attr_done = false;
     if (!attr_done) {
         MTTS_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_gates_kernel<0, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 7 * LS_PLANE_B));
         MTTS_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_gates_kernel<0, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 10 * LS_PLANE_B));
+        MTTS_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_gates2_kernel<0, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 7 * LS_PLANE_B));
         attr_done = true;
     }
+    return 0;
+}
+
+int lstm_step_launch(const LstmStepArgs& a, hipStream_t s) {
+    LsGates g; LsCell c;
+    MTTS_TRY(ls_marshal(a, g, c));
+    MTTS_TRY(ls_set_attrs());
+    const int ntile = (4 * a.H) / LS_COLS;
     const dim3 grid(ntile * g.KS), blk(LS_THREADS);
 #define LS_LAUNCH(PREC, NB) hipLaunchKernelGGL((lstm_gates_kernel<PREC, NB>), grid, blk, (size_t)(PREC ? 1 : 3) * NB * LS_PLANE_B, s, g)
     if (a.precision) {
@@ -540,14 +583,28 @@ int lstm_step_launch(const LstmStepArgs& a, hipStream_t s) {
     }
 #undef LS_LAUNCH
     MTTS_CHECK_LAUNCH("lstm_gates_kernel");
-    LsCell c; memset(&c, 0, sizeof(c));
-    c.part = a.partials; c.KS = g.KS; c.B = a.B; c.H = a.H; c.pre = a.pre; c.ldpre = a.ldpre; c.bias_u = a.bias_u;
-    c.h_prev = a.h_prev; c.c_prev = a.c_prev; c.h_out = a.h_out; c.c_out = a.c_out; c.gates_out = a.gates_out;
-    c.hmask = a.hmask; c.cmask = a.cmask; c.hscale = a.hscale; c.zone = a.zone; c.zh = a.zh; c.zc = a.zc;
-    c.wq = a.qpart ? a.w_query : nullptr; c.A = a.A; c.qpart = a.qpart;
-    MTTS_REQUIRE(!(c.zone && !c.h_prev), "mtts_lstm_step_fwd: zoneout needs h_prev");
     hipLaunchKernelGGL(lstm_cell_q_kernel, dim3(a.H / 16, (a.B + 15) / 16), dim3(256), 0, s, c);
     MTTS_CHECK_LAUNCH("lstm_cell_q_kernel");
+    return 0;
+}
+
+// Two LSTM steps (same B, H, precision; both K-slices <= 7 blocks) as ONE gate launch + ONE cell launch.
+int lstm_step2_launch(const LstmStepArgs& a, const LstmStepArgs& b, hipStream_t s) {
+    LsGates ga, gb; LsCell ca, cb;
+    MTTS_TRY(ls_marshal(a, ga, ca));
+    MTTS_TRY(ls_marshal(b, gb, cb));
+    if (a.B != b.B || a.H != b.H || a.precision != b.precision || ga.nbmax > 7 || gb.nbmax > 7) {
+        MTTS_TRY(lstm_step_launch(a, s));
+        return lstm_step_launch(b, s);
+    }
+    MTTS_TRY(ls_set_attrs());
+    const int ntile = (4 * a.H) / LS_COLS;
+    const int na = ntile * ga.KS, nb = ntile * gb.KS;
+    if (a.precision) hipLaunchKernelGGL((lstm_gates2_kernel<1, 7>), dim3(na + nb), dim3(LS_THREADS), (size_t)7 * LS_PLANE_B, s, ga, gb, na);
+    else hipLaunchKernelGGL((lstm_gates2_kernel<0, 7>), dim3(na + nb), dim3(LS_THREADS), (size_t)3 * 7 * LS_PLANE_B, s, ga, gb, na);
+    MTTS_CHECK_LAUNCH("lstm_gates2_kernel");
+    hipLaunchKernelGGL(lstm_cell_q2_kernel, dim3(a.H / 16, (a.B + 15) / 16, 2), dim3(256), 0, s, ca, cb);
+    MTTS_CHECK_LAUNCH("lstm_cell_q2_kernel");
     return 0;
 }
 

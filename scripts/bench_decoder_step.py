@@ -1,54 +1,23 @@
-"""Secondary measurement (SURVEY 8d / BASELINE north_star): the attention+decoder STEP at a given batch against the HBM roofline.
-One "step" = everything one output frame costs in the teacher-forced forward decoder (prenet, attention LSTM, query, attention,
-generator LSTM, frame/stop projection; hoisted batched pieces included).  Algorithmic bytes per step = 4 * (W + B * act) with
-SURVEY 8(d)'s W (weights read once per step) and act (per-sample activation elements).
-    python scripts/bench_decoder_step.py [--batch 256] [--preset generated_switching] [--frames 200]"""
-import argparse, json, os, sys, time
+"""The attention+decoder forward step against the HBM roofline for any preset / batch / dtype - the function bench.py
+puts on its line as `roofline` / `roofline_b240`:   python scripts/bench_decoder_step.py [--batch 240] [--preset generated_switching]
+[--frames 300] [--dtype f32|bf16]"""
+import argparse, json, os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import bench
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--batch', type=int, default=256)
+    ap.add_argument('--batch', type=int, default=240)
     ap.add_argument('--preset', default='generated_switching')
-    ap.add_argument('--frames', type=int, default=200)
+    ap.add_argument('--frames', type=int, default=300)
     ap.add_argument('--chars', type=int, default=120)
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'])
     args = ap.parse_args()
-    import bench
-    from multilingual_text_to_speech_amd.params import presets, Params as hp
-    from multilingual_text_to_speech_amd.modules.tacotron2 import Tacotron
-    import multilingual_text_to_speech_amd.kernels as K
-    presets.apply(args.preset, speaker_number=91)
-    torch.manual_seed(0)
-    dev = torch.device('cuda')
-    model = Tacotron().to(dev).train()
-    B, L, T = args.batch, args.chars, args.frames
-    b = bench.synthetic_batch(hp, B, L, T, dev)
-    H, P, A, M = hp.decoder_dimension, hp.prenet_dimension, hp.attention_dimension, hp.num_mels
-    C, ks = hp.attention_location_dimension, hp.attention_kernel_size
-    Dm = hp.encoder_dimension + (hp.speaker_embedding_dimension if hp.multi_speaker else 0) + (hp.language_embedding_dimension if hp.multi_language else 0)
-    W = 4 * H * (P + Dm + H) + 4 * H * (H + Dm + H) + 16 * H + A * H + C * ks + A * C + 2 * A + (M + 1) * (H + Dm + 1)
-    act = L * A + L * Dm + 3 * L + 8 * H + P + 2 * Dm + M + 1
-    bytes_step = 4.0 * (W + B * act)
-    flop_step = 2.0 * B * (4 * H * (P + Dm + H) + 4 * H * (H + Dm + H) + A * H + L * (C * ks + A * C + A + Dm) + (M + 1) * (H + Dm))
-    with torch.no_grad():
-        langs = b['languages']
-        emb = K.embedding(model._embedding.weight, b['text'], 0)
-        enc = model._encoder(emb, b['text_length'], langs.unsqueeze(1).expand(-1, L) if langs is not None else None)
-        lang = langs.unsqueeze(1).expand(-1, L) if langs is not None else None
-        spk = b['speakers'].unsqueeze(1).expand(-1, L) if b['speakers'] is not None else None
-        times = []
-        for it in range(4):
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            model._decoder(enc, b['text_length'], b['target'], 1.0, spk, lang)
-            torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
-    dt = sorted(times[1:])[1]
-    us = dt / T * 1e6
-    print(json.dumps({'metric': 'attention+decoder step, forward, teacher forced', 'batch': B, 'preset': args.preset, 'Dm': Dm, 'frames': T,
-                      'us_per_step': round(us, 2), 'algorithmic_MB_per_step': round(bytes_step / 1e6, 1), 'GFLOP_per_step': round(flop_step / 1e9, 2),
-                      'hbm_roofline_frac_of_8TBps': round(bytes_step / (us * 1e-6) / 8e12, 4),
-                      'fp32_mfma_frac_of_157TF': round(flop_step / (us * 1e-6) / 157.3e12, 4), 'frames_per_s': round(B * T / dt, 1)}))
+    out = bench.secondary_step_roofline(args.preset, args.batch, args.chars, args.frames, torch.device('cuda', 0), args.dtype)
+    print(json.dumps({k: out[k] for k in ('us_per_step', 'frac', 'achieved', 'bytes_per_step', 'dtype')} | {'batch': args.batch, 'preset': args.preset,
+                      'nch': os.environ.get('MTTS_ATTN_NCH', 'auto')}))
 
 
 if __name__ == '__main__':
