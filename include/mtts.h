@@ -217,6 +217,8 @@ typedef struct LstmPackArgs {
     const float* b_ih;     /* optional: bias_u[4u + g] = b_ih[gH + u] + b_hh[gH + u] */
     const float* b_hh;
     float* bias_u;
+    int plain_rows;        /* > 0: a plain [plain_rows, K] weight in identity row order (zero rows up to the next multiple of 128;
+                              dst needs mtts_ksplit_packed_weight_bytes) instead of an LSTM matrix in unit-major order */
 } LstmPackArgs;
 
 typedef struct LstmStepArgs {
@@ -251,6 +253,8 @@ typedef struct LstmStepArgs {
 int mtts_lstm_step_ksplit(int k_total);
 long mtts_lstm_step_partial_floats(int B, int H, int k_total);
 long mtts_lstm_packed_weight_bytes(int H, int k_total, int precision);
+long mtts_ksplit_packed_weight_bytes(int N, int k_total, int precision);
+long mtts_ksplit_partial_floats(int B, int N, int k_total);
 int mtts_lstm_pack_weights(const LstmPackArgs* args, void* stream);
 /* dst[(4u + g) K + k] = src[(gH + u) ld + k]: rows of a [4H, K] LSTM matrix into unit-major order (for the hoisted projection) */
 int mtts_lstm_rows_unit_major(const float* src, int ld, int H, int K, float* dst, void* stream);
@@ -433,6 +437,9 @@ typedef struct AttnBwdArgs {
     int n_part;
     long part_ks;
     int part_ld;
+    float* hsum_out;       /* optional [B, hsum_cols]: sum over the n_part slabs of columns [Dm, Dm + hsum_cols) (the h-columns of a
+                              combined [ctx | h] input-gradient product), written for the cell backward that follows */
+    int hsum_cols;
     float* dq;             /* [B,A] zero-initialised, accumulated atomically */
     float* dMt;            /* [B,L,A] accumulated (+=) */
     float* dU_slab;        /* [B*nch][A*ksz] accumulated (+=) */
@@ -468,6 +475,9 @@ typedef struct DecoderGradArgs {
     float* dG_gen;         /* [T,B,4H] */
     float* dG_att_p;       /* [T][Bp*4H] MFMA tile order copies (optional) */
     float* dG_gen_p;
+    void* att_w_rec_T2p;   /* optional: [W_ih[:, P:] | W_hh]^T ([Dm+H, 4H]) packed for the K-split kernel (mtts_ksplit_packed_weight_bytes(Dm+H, 4H, 0)) */
+    float* part_rec;       /* optional: mtts_ksplit_partial_floats(B, Dm+H, 4H) floats: partial slabs of dG_att x [W_ih[:, P:] | W_hh] */
+    float* dh_rec_sum;     /* optional: [B,H] slab sum of the h-columns (written by the attention backward) */
     float* att_w_rec_Tp;   /* packed [Dm+H, 4H] */
     float* gen_w_hh_Tp;    /* packed [H, 4H] */
     float* dHG;            /* [T,B,H] */

@@ -43,8 +43,9 @@ def decoder_bwd(ctx, dspec, dstop, dalign):
         setattr(g, name, ptr(t))
         return t
 
-    ksb = cfg.get('ksb', 4)
-    nch = cfg.get('nch_bwd', 4)
+    import os
+    ksb = int(os.environ.get('MTTS_KSB', cfg.get('ksb', 4)))                 # tuning knobs (scripts/sweep_bwd.sh)
+    nch = int(os.environ.get('MTTS_NCH_BWD', cfg.get('nch_bwd', 4)))
     buf('dout', dout)
     if dal is not None:
         buf('dalign', dal)
@@ -60,6 +61,11 @@ def decoder_bwd(ctx, dspec, dstop, dalign):
         buf('dG_gen_p', zp(T, Bp * 4 * H, device=dev))
         buf('att_w_rec_Tp', _e(((Dm + H + 15) & ~15) * 4 * H, device=dev))
         buf('gen_w_hh_Tp', _e(H * 4 * H, device=dev))
+    if st.fast and H % 32 == 0 and Dm % 4 == 0 and B <= 64 and os.environ.get('MTTS_GBWD', '0') == '1':
+        # experiment (off by default, see csrc/decoder_bwd.hip): K-split input-gradient product of chain A
+        buf('att_w_rec_T2p', torch.empty(int(lib().mtts_ksplit_packed_weight_bytes(Dm + H, 4 * H, 0)), dtype=torch.uint8, device=dev))
+        buf('part_rec', _e(24 * B * (Dm + H), device=dev))
+        buf('dh_rec_sum', _e(B, H, device=dev))
     if not st.fast:      # general schedule (teacher forcing < 1): per-step chain with transposed full weights
         buf('att_w_ih_T', _e(P + Dm + H, 4 * H, device=dev))
         buf('gen_w_ih_T', _e(2 * H + Dm, 4 * H, device=dev))
@@ -79,7 +85,7 @@ def decoder_bwd(ctx, dspec, dstop, dalign):
     buf('dq_all', _z(T, B, A, device=dev))
     buf('part_gen', _z(ksb, B, H, device=dev))
     # K-split of the ctx-column input gradient: as many slabs as keep the launch within ONE wave of workgroups (256 CUs)
-    ksc = cfg.get('ksb_ctx', max(1, min(8, 256 // ((Dm + 15) // 16))))
+    ksc = int(os.environ.get('MTTS_KSC', cfg.get('ksb_ctx', max(1, min(8, 256 // ((Dm + 15) // 16))))))
     buf('part_att', _z(ksc * B * Dm + ksb * B * H, device=dev))
     g.ksb, g.nch, g.ksb_ctx = ksb, nch, ksc
     buf('dc_att', _z(2, B, H, device=dev))

@@ -25,11 +25,13 @@ __device__ __forceinline__ float block_sum(float v, float* red, int tid) {
 constexpr int BNU_MAX = 8;    // filter-bank elements per thread
 constexpr int BNR_MAX = 4;    // own rows per wave
 constexpr int BND_MAX = 9;    // memory floats per lane per row (Dm <= 576)
-constexpr int BNP_MAX = 8;    // partial slabs
+constexpr int BNP_MAX = 8;    // partial slabs (fused launch, 128-VGPR budget)
+constexpr int BNP_BIG = 24;   // partial slabs of the stand-alone kernel fed by the K-split [ctx | h] input-gradient product
 constexpr int BNX_MAX = 2;    // context floats per thread (Dm <= 1024)
 constexpr int BUP_LD = 36;    // U row (32 taps + pad)
 constexpr int BROWS = 32;     // padded row count of a chunk
 
+template <int NP = BNP_MAX>
 __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& p, float* sm, const int b, const int ch) {
     const int tid = threadIdx.x, lane = tid & 63, nwaves = ATB_THREADS / 64;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -67,13 +69,24 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& p, float* sm, c
     for (int j = 0; j < BNX_MAX; ++j) {
         const int d = min(tid + j * ATB_THREADS, Dm - 1);
         float g = p.dctx[(long)b * Dm + d];
-        float pp[BNP_MAX];
+        float pp[NP];
 #pragma unroll
-        for (int k = 0; k < BNP_MAX; ++k) pp[k] = (k < p.n_part) ? p.part[(long)k * p.part_ks + (long)b * p.part_ld + d] : 0.f;
+        for (int k = 0; k < NP; ++k) pp[k] = (k < p.n_part) ? p.part[(long)k * p.part_ks + (long)b * p.part_ld + d] : 0.f;
 #pragma unroll
-        for (int k = 0; k < BNP_MAX; ++k) g += pp[k];
+        for (int k = 0; k < NP; ++k) g += pp[k];
         dcx[j] = g;
         cx[j] = p.ctx[(long)b * Dm + d];
+    }
+    if (p.hsum_out) {      // h-columns [Dm, Dm + hsum_cols) of the same slabs, summed for the cell backward that follows this kernel
+        const int hc = (p.hsum_cols + p.nch - 1) / p.nch, h1 = min(p.hsum_cols, (ch + 1) * hc);
+        for (int i = ch * hc + tid; i < h1; i += ATB_THREADS) {
+            float pp[NP], g = 0.f;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) pp[k] = (k < p.n_part) ? p.part[(long)k * p.part_ks + (long)b * p.part_ld + Dm + i] : 0.f;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) g += pp[k];
+            p.hsum_out[(long)b * p.hsum_cols + i] = g;
+        }
     }
     float memr[BNR_MAX][BND_MAX];
 #pragma unroll
@@ -248,9 +261,9 @@ static inline size_t attn_bwd_fast_lds(const AttnBwdArgs& p) {
     return sizeof(float) * ((((size_t)5 * p.A + 3 * p.L + 64 + BROWS + 64 + 16 + p.Dm + 3) & ~(size_t)3) + (size_t)p.A * BUP_LD +
                             (size_t)(32 + BROWS) * (p.A + 4));
 }
-static inline bool attn_bwd_fast_ok(const AttnBwdArgs& p) {
+static inline bool attn_bwd_fast_ok(const AttnBwdArgs& p, int max_part = BNP_MAX) {
     const int lc = (p.L + p.nch - 1) / p.nch;
     return (p.A == 64 || p.A == 128) && p.L <= ATB_THREADS && lc <= BROWS && lc <= BNR_MAX * (ATB_THREADS / 64) && p.ksz <= 32 &&
            (long)p.A * p.ksz <= (long)BNU_MAX * ATB_THREADS && p.Dm <= 64 * BND_MAX && p.Dm <= BNX_MAX * ATB_THREADS &&
-           p.n_part <= BNP_MAX && attn_bwd_fast_lds(p) <= 64 * 1024;
+           p.n_part <= max_part && attn_bwd_fast_lds(p) <= 64 * 1024;
 }

@@ -4,6 +4,7 @@
 //   attn_bwd_plus_skinny:  attention backward of step t   ||   dG_att(t+1) x W_hh^T   (input gradient w.r.t. h_att_t, which is
 //                          only needed by the cell backward that follows the attention backward)
 // Workgroups [0, B*nch) run the attention body, the rest run the skinny-GEMM body; both use 512 threads.
+#include <stdlib.h>
 #include "attention_bwd_body.h"
 #include "skinny_body.h"
 
@@ -22,7 +23,8 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_plus_skinny_kernel(AttnBwdArgs
 
 // Falls back to two separate launches when the fused preconditions do not hold.
 int attn_bwd_plus_skinny(const AttnBwdArgs& a, const SkinnyArgs& k, hipStream_t s) {
-    const bool fusable = attn_bwd_fast_ok(a) && k.lstm == 0 && k.B > 32 && k.B <= 64 && k.nseg == 1 && k.ksplit >= 1;
+    static const bool no_fat = [] { const char* e = getenv("MTTS_NO_FAT"); return e && e[0] == '1'; }();      // A/B switch: two launches
+    const bool fusable = !no_fat && attn_bwd_fast_ok(a) && k.lstm == 0 && k.B > 32 && k.B <= 64 && k.nseg == 1 && k.ksplit >= 1;
     if (!fusable) {
         MTTS_TRY(mtts_attn_step_bwd(&a, s));
         return skinny_launch(k, s);
