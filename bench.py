@@ -383,8 +383,11 @@ def main():
     _C.check(lib.mtts_prof_begin(n_samples * args.steps, max(1, T // n_samples)), 'prof_begin')
     barrier()
     t0 = time.perf_counter()
+    sync_each = os.environ.get('MTTS_BENCH_SYNC', '0') == '1'
     for _ in range(args.steps):
         loss = train_step(model, crit, opt, buckets, batch, hp)
+        if sync_each:
+            torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
     tot_ms, cnt = ctypes.c_float(0), ctypes.c_int(0)
@@ -413,7 +416,7 @@ def main():
         achieved = flop / avg_s / 1e12 if avg_s > 0 else 0.0
         roof = step_roofline(model, hp, batch, B, L, T, args.preset, args.dtype)
         roof['kernels'] = {'attention_lstm_step': {
-            'kernel': 'attention-LSTM step: [B,Dm+H]x[4H,Dm+H]^T + LSTM cell (1 launch per frame, largest total time)', 'bound': 'mfma',
+            'kernel': 'attention-LSTM step: [B,Dm+H]x[4H,Dm+H]^T + LSTM cell + query partials (K-split gate GEMM + cell kernel: 2 launches per frame)', 'bound': 'mfma',
             'achieved_TFLOPs': round(achieved, 2), 'peak_TFLOPs': 157.3, 'frac': round(achieved / 157.3, 4), 'flop_per_launch': flop,
             'bytes_per_launch': bytes_alg, 'avg_launch_us': round(avg_s * 1e6, 2), 'event_bracket_us': round(raw_s * 1e6, 2),
             'empty_bracket_us': round(empty_s * 1e6, 2), 'hbm_frac_of_8TBps': round(bytes_alg / avg_s / 8e12, 4) if avg_s > 0 else 0.0,

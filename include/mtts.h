@@ -248,9 +248,11 @@ typedef struct LstmStepArgs {
     const float* w_query;  /* [A, H] row-major or NULL */
     int A;
     float* qpart;          /* [H/16][B][A] query-projection partials (summed by mtts_attn_step_fwd with kq = H/16) or NULL */
+    int nb_max;            /* 32-wide k-blocks per K-slice: 0 = up to 10 (fewest partial slabs); 4 = short slices, two workgroups per CU
+                              (training: shares CUs with concurrently running GEMM workgroups) */
 } LstmStepArgs;
 
-int mtts_lstm_step_ksplit(int k_total);
+int mtts_lstm_step_ksplit(int k_total);                    /* upper bound of the slab count over every nb_max >= 4 */
 long mtts_lstm_step_partial_floats(int B, int H, int k_total);
 long mtts_lstm_packed_weight_bytes(int H, int k_total, int precision);
 long mtts_ksplit_packed_weight_bytes(int N, int k_total, int precision);

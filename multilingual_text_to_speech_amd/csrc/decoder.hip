@@ -74,7 +74,7 @@ static LstmStepArgs gen_step_args(const DecoderArgs& a, int t) {
     const long BH = (long)B * H, B4H = 4 * BH;
     LstmStepArgs k; memset(&k, 0, sizeof(k));
     k.x[0] = a.h_gen + t * BH; k.K[0] = H; k.ldx[0] = H; k.nseg = 1;
-    k.w_packed = a.gen_w2p; k.precision = a.precision; k.B = B; k.H = H; k.partials = a.gate_part_gen;
+    k.w_packed = a.gen_w2p; k.precision = a.precision; k.B = B; k.H = H; k.partials = a.gate_part_gen; k.nb_max = 4;
     k.pre = a.pre_gen + t * B4H; k.ldpre = 4 * H; k.bias_u = a.gen_bias_u;
     k.h_prev = a.h_gen + t * BH; k.c_prev = a.c_gen + t * BH;
     k.h_out = a.h_gen + (t + 1) * BH; k.c_out = a.c_gen + (t + 1) * BH;
@@ -243,7 +243,7 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
             k.x[n] = a.ctx + t * BD; k.K[n] = Dm; k.ldx[n] = Dm; ++n;
             k.x[n] = a.h_att + t * BH; k.K[n] = H; k.ldx[n] = H; ++n;
             k.nseg = n; k.w_packed = a.att_w2p; k.precision = a.precision; k.B = B; k.H = H; k.partials = a.gate_part;
-            if (use_ls) { k.pre = a.pre_att + t * B4H; k.ldpre = 4 * H; }
+            if (use_ls) { k.pre = a.pre_att + t * B4H; k.ldpre = 4 * H; k.nb_max = 4; }      // training: short slices, 2 workgroups per CU
             k.bias_u = a.att_bias_u;
             k.h_prev = a.h_att + t * BH; k.c_prev = a.c_att + t * BH;
             k.h_out = a.h_att + (t + 1) * BH; k.c_out = a.c_att + (t + 1) * BH;

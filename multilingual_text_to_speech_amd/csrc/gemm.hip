@@ -505,7 +505,8 @@ MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
         const long tiles = (long)ntx * nty * p.batch * p.zt;
         const int nkb = cdiv(p.K, BK);
         if (g_ws_host && tiles < 512 && nkb >= 32) {
-            const long target = region == 0 ? 1024 : 512;        // helper streams: just fill the chip twice over
+            static const long helper_target = [] { const char* e = getenv("MTTS_HELPER_SPLIT_TARGET"); const long v = e ? atol(e) : 0; return v > 0 ? v : 512L; }();
+            const long target = region == 0 ? 1024 : helper_target;        // helper streams: fill the chip twice over
             S = (int)((target + tiles - 1) / tiles);
             if (S > nkb / 16) S = nkb / 16;
             if (S > 32) S = 32;
@@ -518,11 +519,12 @@ MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
     // latency-critical step kernels of the main stream always find room next to it
     static const bool exact_f32 = [] { const char* e = getenv("MTTS_GEMM_EXACT_F32"); return e && e[0] == '1'; }();
     const size_t lds_base = exact_f32 ? 4 * LDS_A * sizeof(float) : (size_t)SP_LDS_B;
-    // Round 1 reserved 96 KiB of LDS for helper-stream launches (one GEMM workgroup per CU, "room" for the step kernels).  Kernel
-    // traces show the step kernels and these GEMMs do not overlap anyway (every step kernel fills all 256 CUs; overlapped time is
-    // < 5 % of the decoder forward), so the reservation only halved the GEMMs' throughput: 92.1 -> 89.5 ms per train step without
-    // it.  MTTS_GEMM_RESERVE_CU=1 restores it for A/B runs.
-    static const bool reserve_cu = [] { const char* e = getenv("MTTS_GEMM_RESERVE_CU"); return e && e[0] == '1'; }();
+    // Helper-stream launches (side / weight-gradient stream) ask for 96 KiB of LDS: ONE GEMM workgroup per CU.  Every step
+    // kernel of the decoder chains is built to fit beside it (<= 128 VGPRs, <= 64 KiB LDS: lstm_gates_kernel<., 4>,
+    // skinny_kernel_lo, the attention kernels), so the latency-critical chain never waits for a 100-300 us GEMM workgroup to
+    // retire.  Same-box A/B, 20 steps: 89.2-89.6 ms per train step with the reservation, 91.4-91.9 without
+    // (MTTS_GEMM_RESERVE_CU=0), 95.5 with round 1's 150-VGPR step kernels.
+    static const bool reserve_cu = [] { const char* e = getenv("MTTS_GEMM_RESERVE_CU"); return !(e && e[0] == '0'); }();
     const size_t lds = (p.nosplit && reserve_cu) ? (size_t)96 * 1024 : lds_base;
     hipStream_t s = (hipStream_t)stream;
     static bool attr_done = false;

@@ -19,6 +19,7 @@
 // evaluated as six v_mfma_f32_16x16x32_bf16 terms with fp32 accumulation (precision 0), or operands are rounded to one
 // bf16 plane (precision 1: the bf16 path, weights stored as bf16).
 #include "common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
@@ -28,7 +29,15 @@ constexpr int LS_MAXKB = 10;         // 32-wide k-blocks per K-slice (weights of
 constexpr int LS_PLANE_B = 64 * 64;  // one k-block of one plane in LDS: 64 rows x 32 bf16
 constexpr int LS_MIN_KS = 8;
 
-static inline int ls_ksplit(int nkb) { const int need = (nkb + LS_MAXKB - 1) / LS_MAXKB; return need > LS_MIN_KS ? need : LS_MIN_KS; }
+// K-slices for nkb 32-wide blocks when a slice may hold at most nb_max blocks (0 = LS_MAXKB): at least 8 slices.
+// nb_max = 4 selects the two-workgroups-per-CU instantiation (training: the step kernels then share CUs with the helper streams'
+// GEMM workgroups instead of waiting for them; 95.7 vs 97.5 ms per train step) at the price of more partial slabs.
+static inline int ls_ksplit(int nkb, int nb_max = 0) {
+    static const int nb_env = [] { const char* e = getenv("MTTS_LS_NB"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= LS_MAXKB) ? v : 0; }();
+    int nb = nb_env ? nb_env : (nb_max >= 1 && nb_max <= LS_MAXKB ? nb_max : LS_MAXKB);
+    const int need = (nkb + nb - 1) / nb;
+    return need > LS_MIN_KS ? need : LS_MIN_KS;
+}
 
 __device__ __forceinline__ unsigned bf16_rne(float x) {      // upper 16 bits of the RNE-rounded value
     const unsigned u = __float_as_uint(x);
@@ -236,8 +245,10 @@ __device__ __forceinline__ void lstm_gates_body(const LsGates& p, const int bid,
 #undef LS_LOAD_X
 }
 
+// NB = 4 is compiled for two workgroups per CU (<= 128 VGPRs, 48 KiB LDS): with short K-slices (KS >= nkb / 4) two of these
+// kernels - or one of them and an attention / GEMM workgroup of another stream - share a CU and hide each other's latencies.
 template <int PREC, int NB>
-__global__ __launch_bounds__(LS_THREADS) void lstm_gates_kernel(LsGates p) {
+__global__ __launch_bounds__(LS_THREADS, (NB <= 4 ? 4 : 2)) void lstm_gates_kernel(LsGates p) {
     extern __shared__ __attribute__((aligned(16))) char sm[];
     lstm_gates_body<PREC, NB>(p, blockIdx.x, sm);
 }
@@ -296,13 +307,13 @@ __device__ __forceinline__ void lstm_cell_q_body(const LsCell& p, float (&hs)[16
     const int hm = p.hmask ? (int)p.hmask[hi] : 1, cm = p.cmask ? (int)p.cmask[hi] : 1;
     const float* ps = p.part + (long)rowc * N + 4 * u;
     const long slab = (long)p.B * N;
-    float4 pv[8];
+    float4 pv[16];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) pv[k] = *reinterpret_cast<const float4*>(ps + (long)min(k, p.KS - 1) * slab);
+    for (int k = 0; k < 16; ++k) pv[k] = *reinterpret_cast<const float4*>(ps + (long)min(k, p.KS - 1) * slab);
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
+    for (int k = 0; k < 16; ++k)
         if (k < p.KS) { g4.x += pv[k].x; g4.y += pv[k].y; g4.z += pv[k].z; g4.w += pv[k].w; }
-    for (int k = 8; k < p.KS; ++k) {
+    for (int k = 16; k < p.KS; ++k) {
         const float4 v = *reinterpret_cast<const float4*>(ps + (long)k * slab);
         g4.x += v.x; g4.y += v.y; g4.z += v.z; g4.w += v.w;
     }
@@ -505,7 +516,7 @@ static int ls_check_segs(int nseg, const int* K, const int* ld, const char* what
     return 0;
 }
 
-MTTS_API int mtts_lstm_step_ksplit(int k_total) { return ls_ksplit((k_total + 31) / 32); }
+MTTS_API int mtts_lstm_step_ksplit(int k_total) { return ls_ksplit((k_total + 31) / 32, 4); }      // upper bound over every nb_max >= 4
 
 MTTS_API long mtts_lstm_step_partial_floats(int B, int H, int k_total) { return (long)mtts_lstm_step_ksplit(k_total) * B * 4 * H; }
 
@@ -557,7 +568,7 @@ static int ls_marshal(const LstmStepArgs& a, LsGates& g, LsCell& c) {
     g.x0 = a.x[0]; g.K0 = a.K[0]; g.ld0 = a.ldx[0];
     g.x1 = a.nseg > 1 ? a.x[1] : a.x[0]; g.K1 = a.nseg > 1 ? a.K[1] : 0; g.ld1 = a.nseg > 1 ? a.ldx[1] : a.ldx[0];
     g.x2 = a.nseg > 2 ? a.x[2] : a.x[0]; g.K2 = a.nseg > 2 ? a.K[2] : 0; g.ld2 = a.nseg > 2 ? a.ldx[2] : a.ldx[0];
-    g.wp = a.w_packed; g.nkb = (g.K0 + g.K1 + g.K2) / 32; g.KS = ls_ksplit(g.nkb); g.B = a.B; g.N = 4 * a.H; g.part = a.partials;
+    g.wp = a.w_packed; g.nkb = (g.K0 + g.K1 + g.K2) / 32; g.KS = ls_ksplit(g.nkb, a.nb_max); g.B = a.B; g.N = 4 * a.H; g.part = a.partials;
     g.nbmax = (g.nkb + g.KS - 1) / g.KS;
     memset(&c, 0, sizeof(c));
     c.part = a.partials; c.KS = g.KS; c.B = a.B; c.H = a.H; c.pre = a.pre; c.ldpre = a.ldpre; c.bias_u = a.bias_u;

@@ -1,4 +1,5 @@
 // Skinny (small-M) fp32 MFMA GEMM launcher; the kernel body lives in skinny_body.h (shared with the fused step launches).
+#include <stdlib.h>
 #include "skinny_body.h"
 
 template <int MT>
@@ -32,9 +33,12 @@ int skinny_launch(const SkinnyArgs& p, hipStream_t s) {
     if (p.lstm == 2) q.N = p.H;
     if (p.lstm == 1 && !q.h_prev) q.h_prev = q.c_prev;
     const int cbs = p.lstm == 1 ? cdiv(p.H, 4) : cdiv(q.N, 16);
+    // Default for more than 32 rows: the <= 128-VGPR variant.  The 4-deep one (153 VGPRs) is ~10 % faster alone, but cannot share a CU
+    // with two GEMM workgroups of the helper streams and then WAITS for them: 92.0-92.3 vs 94.4-94.8 ms per train step.
+    static const bool force_lo = [] { const char* e = getenv("MTTS_SKINNY_DEEP"); return !(e && e[0] == '1'); }();
     if (p.B <= 16) hipLaunchKernelGGL(skinny_kernel<1>, dim3(cbs, cdiv(p.B, 16), ks), dim3(NT), 0, s, q);
     else if (p.B <= 32) hipLaunchKernelGGL(skinny_kernel<2>, dim3(cbs, cdiv(p.B, 32), ks), dim3(NT), 0, s, q);
-    else if ((long)cbs * cdiv(p.B, 64) * ks > 320) hipLaunchKernelGGL(skinny_kernel_lo<4>, dim3(cbs, cdiv(p.B, 64), ks), dim3(NT), 0, s, q);
+    else if (force_lo || (long)cbs * cdiv(p.B, 64) * ks > 320) hipLaunchKernelGGL(skinny_kernel_lo<4>, dim3(cbs, cdiv(p.B, 64), ks), dim3(NT), 0, s, q);
     else hipLaunchKernelGGL(skinny_kernel<4>, dim3(cbs, cdiv(p.B, 64), ks), dim3(NT), 0, s, q);
     MTTS_CHECK_LAUNCH("skinny_kernel");
     return 0;
