@@ -19,7 +19,7 @@ python $R/scripts/pmc_summary.py $O/pmc_fetch/fetch_counter_collection.csv $O/pm
 # 5. generated_training (K2) and inference
 timeout 300 rocprofv3 --kernel-trace -d $O/gen -o gen --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --preset generated_training --batch 60 > $O/gen.log 2>&1
 python $R/scripts/trace_summary.py $O/gen/gen_kernel_trace.csv --top 30 > $O/generated_training_kernels.txt 2>&1
-tail -1 $O/gen.log > $O/generated_training_line.json
+grep "^{" $O/gen.log | tail -1 > $O/generated_training_line.json
 timeout 300 rocprofv3 --kernel-trace -d $O/inf -o inf --output-format csv -- python $R/scripts/prof_inference.py --frames 240 > $O/inf.log 2>&1
 python $R/scripts/trace_summary.py $O/inf/inf_kernel_trace.csv --region 1 --top 16 > $O/inference_kernels.txt 2>&1
 # keep the merged-back payload small: summaries only
