@@ -24,7 +24,8 @@ def _hipcc():
 
 
 def _compile(src, obj):
-    cmd = [_hipcc(), *FLAGS, "-x", "hip", "-c", src, "-o", obj]
+    extra = os.environ.get("MTTS_EXTRA_FLAGS", "").split()          # e.g. -DMTTS_NO_STEP_PRIO for A/B builds
+    cmd = [_hipcc(), *FLAGS, *extra, "-x", "hip", "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

@@ -132,6 +132,7 @@ struct LsGates {
 
 template <int PREC, int NB>      // NB: k-blocks per K-slice held in registers (the smallest instantiation that fits is launched)
 __device__ __forceinline__ void lstm_gates_body(const LsGates& p, const int bid, char* sm) {
+    step_prio();
     constexpr int NPL = PREC ? 1 : 3;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -280,6 +281,7 @@ struct LsCell {
 constexpr int LC_MAXCT = 4;      // query column tiles per wave: A <= 4 waves x 4 x 16 = 256
 
 __device__ __forceinline__ void lstm_cell_q_body(const LsCell& p, float (&hs)[16][17]) {
+    step_prio();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ut = blockIdx.x, rt = blockIdx.y;
     const int r = tid >> 4, uu = tid & 15;
