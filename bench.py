@@ -16,7 +16,8 @@ Extra objects on the line (N = 1):
                  `traffic` = HBM bytes per step from live rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate passes,
                  difference of a long and a short decode so that everything not proportional to the frame count cancels).
                  `kernels` keeps the per-launch figures of the dominant kernel (attention-LSTM step) as a sub-field.
-  roofline_b240 - the same quantity for params/generated_switching at batch 240 (the valid batch next to the north star's 256).
+  roofline_b240 / roofline_b240_bf16 / roofline_b40_bf16 - the same quantity for params/generated_switching at batch 240 (the valid
+                 batch next to the north star's 256) in fp32 and bf16, and at batch 40 (one rank's shard of configs[3]) in bf16.
   inference    - BASELINE configs[4]: batched synthesis, 128 utterances x 201 tokens -> 600 frames, with its own step roofline.
   cpu_baseline - the CPU oracle (oracle/tacotron_oracle.py, a torch-CPU port of the reference's arithmetic, kind "port") timed
                  on this host's cores on a bounded sample of the same workload, plus `reference_recorded`: the reference
@@ -442,9 +443,11 @@ def main():
                 roof['traffic_detail'] = traffic if traffic else {'error': why}
             except Exception as exc:
                 roof['traffic_detail'] = {'error': repr(exc)[:200]}
-            for key, dt_ in (('roofline_b240', 'f32'), ('roofline_b240_bf16', 'bf16')):
+            # batch 240 = the valid batch next to the north star's 256 on ONE GPU; batch 40 = what one rank of BASELINE configs[3]
+            # (global batch 320 over 8 GPUs, bf16) actually sees
+            for key, nb, dt_ in (('roofline_b240', 240, 'f32'), ('roofline_b240_bf16', 240, 'bf16'), ('roofline_b40_bf16', 40, 'bf16')):
                 try:
-                    line[key] = secondary_step_roofline('generated_switching', 240, L_CHARS, 300, device, dt_)
+                    line[key] = secondary_step_roofline('generated_switching', nb, L_CHARS, 300, device, dt_)
                 except Exception as exc:
                     line[key] = {'error': repr(exc)[:200]}
             _C.set_precision('bf16' if args.dtype == 'bf16' else 'fp32')
