@@ -173,13 +173,28 @@ def inference_bench(device, preset='generated_switching', utterances=128, chars=
             w = torch.zeros(L, n_lang); w[:, i % n_lang] = 1.0
             langs.append(w)
     spks = [i % hp.speaker_number for i in range(utterances)] if hp.multi_speaker else None
-    times = []
-    for _ in range(repeats + 1):
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        out = model.inference_batch(texts, spks, langs, stop_threshold=2.0)
-        torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
-    assert all(o.shape == (hp.num_mels, frames) for o in out), out[0].shape
-    dt = sorted(times[1:])[len(times[1:]) // 2]
+    def timed(n):
+        times = []
+        for _ in range(n + 1):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            out = model.inference_batch(texts, spks, langs, stop_threshold=2.0)
+            torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
+        assert all(o.shape == (hp.num_mels, frames) for o in out), out[0].shape
+        return sorted(times[1:])[len(times[1:]) // 2]
+    dt = timed(repeats)
+    # the same with every 32-step chunk of the decode loop replayed as a hipGraph (mtts_decoder_fwd_graphed; first call eager,
+    # second captures, later ones replay)
+    graph = None
+    try:
+        from multilingual_text_to_speech_amd import decoder_ops as D
+        os.environ['MTTS_DECODE_GRAPH'] = '1'
+        dt_g = timed(repeats + 2)
+        sess = next(iter(D.GraphedDecode._cache.values()))
+        graph = {'value': round(utterances * frames / dt_g, 1), 'seconds_per_batch': round(dt_g, 4), 'chunks_replayed_per_call': sess.replayed}
+    except Exception as exc:
+        graph = {'error': repr(exc)[:200]}
+    finally:
+        os.environ.pop('MTTS_DECODE_GRAPH', None)
     alg = step_algorithmic(hp, utterances, L)
     us_step = dt / frames * 1e6
     gbps = alg['bytes'] / (us_step * 1e-6) / 1e9
@@ -187,6 +202,7 @@ def inference_bench(device, preset='generated_switching', utterances=128, chars=
             'value': round(utterances * frames / dt, 1), 'unit': 'mel-frames/s', 'seconds_per_batch': round(dt, 4),
             'workload': f'params/{preset} synthesis (BASELINE configs[4]), {utterances} utterances x {L} tokens -> {frames} frames, '
                         'stop rule disabled, random-init weights, fp32',
+            'hipgraph_replay': graph,
             'roofline': {'bound': 'hbm', 'what': 'free-running decoder step (whole-call time / frames: includes encoder and post-net)',
                          'achieved': round(gbps, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(gbps / 8000.0, 4),
                          'us_per_step': round(us_step, 2), 'bytes_per_step': alg['bytes']}}

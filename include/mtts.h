@@ -393,6 +393,12 @@ typedef struct DecoderArgs {
 } DecoderArgs;
 
 int mtts_decoder_fwd(const DecoderArgs* args, void* stream);
+/* hipGraph form of a FREE-RUNNING range [t0, t1) (general schedule, no teacher frames): the launches are captured once per distinct
+ * argument block - pointers, sizes and step range all take part - and replayed with one hipGraphLaunch afterwards (first call eager,
+ * second call captures).  The caller keeps every buffer alive at the same address between calls; `stream` must be a non-default
+ * stream.  *replayed (nullable) = 1 when a graph ran.  Replaces the per-step Python / kernel-launch loop of
+ * Decoder.inference (modules/tacotron2.py:216-219,178-207) for BASELINE configs[4]. */
+int mtts_decoder_fwd_graphed(const DecoderArgs* args, void* stream, int* replayed);
 
 /* ---- bidirectional LSTM over padded batch with packed-sequence semantics ----------------------------------
  * Replaces nn.LSTM(bidirectional) + pack/pad of modules/encoder.py:41-44. */

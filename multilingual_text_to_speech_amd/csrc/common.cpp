@@ -47,7 +47,14 @@ MTTS_API int mtts_sizeof_struct(int which) {
 #include <vector>
 
 namespace {
+struct GraphEntry {            // one captured decoder range: exact argument block + its executable graph
+    DecoderArgs args;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int seen = 0;              // capture on the second sighting (the first run executes eagerly: one-time setup stays out of graphs)
+};
 struct StreamCtx {
+    std::vector<GraphEntry*> graphs;
     int device = 0;
     hipStream_t owner = nullptr;
     hipStream_t side = nullptr, wgrad = nullptr;
@@ -148,5 +155,53 @@ MTTS_API int mtts_set_stream_workspace(void* stream, void* ptr, size_t bytes) {
     std::lock_guard<std::mutex> lk(g_mu);
     StreamCtx* c = ctx_locked((hipStream_t)stream);
     c->ws = (float*)ptr; c->ws_bytes = bytes;
+    return 0;
+}
+
+// ---- hipGraph replay of a free-running decoder range (BASELINE configs[4]: "hipGraph-captured decode steps") ----------------------
+// mtts_decoder_fwd_graphed(args, stream): the launches of mtts_decoder_fwd(args) for a range [t0, t1) of the GENERAL schedule
+// are captured once per distinct argument block (every pointer, size and the step range take part in the comparison) and replayed
+// with ONE hipGraphLaunch afterwards.  The caller keeps the buffers alive and at the same addresses between calls
+// (decoder_ops.GraphedDecode does); `stream` must not be the legacy default stream.  The first call with a new argument block
+// runs eagerly, the second one captures, later ones replay.  Returns 0 on success; *replayed (nullable) says which path ran.
+MTTS_API int mtts_decoder_fwd_graphed(const DecoderArgs* args, void* stream, int* replayed) {
+    hipStream_t s = (hipStream_t)stream;
+    if (replayed) *replayed = 0;
+    MTTS_REQUIRE(s != nullptr, "mtts_decoder_fwd_graphed: needs a non-default stream (stream capture)");
+    MTTS_REQUIRE(!args->fast && !args->teacher && !args->frames_in, "mtts_decoder_fwd_graphed: free-running (general schedule) ranges only");
+    GraphEntry* e = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        StreamCtx* c = ctx_locked(s);
+        for (GraphEntry* g : c->graphs)
+            if (memcmp(&g->args, args, sizeof(DecoderArgs)) == 0) { e = g; break; }
+        if (!e) {
+            if (c->graphs.size() >= 4096) {       // a long-lived process with ever-changing buffers: start over
+                for (GraphEntry* g : c->graphs) { if (g->exec) (void)hipGraphExecDestroy(g->exec); if (g->graph) (void)hipGraphDestroy(g->graph); delete g; }
+                c->graphs.clear();
+            }
+            e = new GraphEntry();
+            memcpy(&e->args, args, sizeof(DecoderArgs));
+            c->graphs.push_back(e);
+        }
+    }
+    if (e->exec) {
+        MTTS_CHECK_HIP(hipGraphLaunch(e->exec, s));
+        if (replayed) *replayed = 1;
+        return 0;
+    }
+    if (e->seen++ == 0) return mtts_decoder_fwd(args, stream);
+    MTTS_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int rc = mtts_decoder_fwd(args, stream);
+    hipGraph_t graph = nullptr;
+    const hipError_t end = hipStreamEndCapture(s, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (end != hipSuccess || !graph) return mtts_fail("hipStreamEndCapture: %s", hipGetErrorString(end));
+    hipGraphExec_t exec = nullptr;
+    const hipError_t inst = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (inst != hipSuccess) { (void)hipGraphDestroy(graph); return mtts_fail("hipGraphInstantiate: %s", hipGetErrorString(inst)); }
+    e->graph = graph; e->exec = exec;
+    MTTS_CHECK_HIP(hipGraphLaunch(exec, s));        // the captured launches have not executed yet
+    if (replayed) *replayed = 1;
     return 0;
 }

@@ -210,6 +210,60 @@ def decode_train(memory, target, lengths, teacher, masks, cfg, w):
     return DecoderFn.apply(memory, target, lengths, teacher, masks, cfg, n, *flat)
 
 
+class GraphedDecode:
+    """Persistent buffers + a private stream for hipGraph replay of free-running decode chunks (mtts_decoder_fwd_graphed).
+
+    A captured graph bakes in every pointer, so everything the decoder kernels touch must live at a fixed address between calls:
+    the DecoderState, the memory / lengths / keep-flag inputs (copied or regenerated IN PLACE per call) and the concatenated
+    frame+stop projection.  One session per (device, B, L, dims, frames, precision); the library keys its graphs by the exact
+    argument block, runs a new block eagerly once, captures it the second time and replays it afterwards."""
+    _cache = {}
+
+    @classmethod
+    def get(cls, B, L, frames, dims, dev, n_prenet, kq, precision):
+        key = (torch.device(dev).index or 0, B, L, frames, tuple(dims), n_prenet, kq, precision)
+        if key not in cls._cache:
+            cls._cache[key] = cls(B, L, frames, dims, dev, n_prenet, kq, precision)
+        return cls._cache[key]
+
+    def __init__(self, B, L, frames, dims, dev, n_prenet, kq, precision):
+        M, P, H, A, Dm, ksz, C = dims
+        self.st = DecoderState(B, L, frames, dims, dev, n_prenet, save_gates=False, fast=False, kq=kq, precision=precision)
+        self.memory = torch.empty(B, L, Dm, dtype=torch.float32, device=dev)
+        self.lengths32 = torch.empty(B, dtype=torch.int32, device=dev)
+        self.w_out = torch.empty(M + 1, H + Dm, dtype=torch.float32, device=dev)
+        self.b_out = torch.empty(M + 1, dtype=torch.float32, device=dev)
+        self.masks = {f'prenet.{i}': torch.empty(frames, B, P, dtype=torch.uint8, device=dev) for i in range(n_prenet)}
+        self.stream = torch.cuda.Stream(device=dev)
+        self.replayed = 0          # chunks of the last decode that ran as a graph
+
+    def load(self, memory, lengths, w, masks):
+        """Copy this call's inputs into the persistent buffers (on the session stream)."""
+        self.memory.copy_(memory)
+        self.lengths32.copy_(lengths.to(device=self.memory.device, dtype=torch.int32))
+        self.w_out.copy_(w['w_out']); self.b_out.copy_(w['b_out'])
+        for k, buf in self.masks.items():
+            m = masks.get(k)
+            if m is None:
+                buf.fill_(1)
+            else:
+                buf.copy_(m[:buf.shape[0]])
+        self.st.h_att[0].zero_(); self.st.c_att[0].zero_(); self.st.h_gen[0].zero_(); self.st.c_gen[0].zero_()
+        self.st.ctx[0].zero_(); self.st.cum[0].zero_(); self.st.out[0].zero_()
+        self.replayed = 0
+        return dict(w, w_out=self.w_out, b_out=self.b_out)
+
+    def run(self, w, cfg, t0, t1):
+        a = _C.DecoderArgs()
+        fill_decoder_args(a, self.st, w, self.memory, self.lengths32, None, None, self.masks, cfg)
+        a.t0, a.t1 = t0, t1
+        flag = ctypes.c_int(0)
+        check(lib().mtts_decoder_fwd_graphed(ctypes.byref(a), ctypes.c_void_p(self.stream.cuda_stream), ctypes.byref(flag)),
+              'mtts_decoder_fwd_graphed')
+        self.replayed += int(flag.value)
+        return a
+
+
 _COPY_STREAMS = {}
 
 
@@ -221,7 +275,7 @@ def _copy_stream(dev):
 
 
 def decode_free(memory, lengths, w, cfg, masks, max_frames, stop_frames, chunk=32, stop_threshold=0.5, dims=None,
-                initial_frames=None):
+                initial_frames=None, graph=False):
     """Free-running decode with the reference's stop rule (tacotron2.py:201-207), batch >= 1.
 
     Steps run in chunks of `chunk` on the device; after each chunk the stop logits come back to the host and
@@ -236,11 +290,37 @@ def decode_free(memory, lengths, w, cfg, masks, max_frames, stop_frames, chunk=3
     A, C, ksz = w['w_query'].shape[0], w['w_conv'].shape[0], w['w_conv'].shape[1]
     dev = memory.device
     mask_fn = masks if callable(masks) else None
-    cap = min(max_frames, max(chunk, initial_frames or 1024)) if mask_fn is not None else max_frames
-    if mask_fn is not None:
-        masks = mask_fn(cap)
-    st = DecoderState(B, L, cap, (M, P, H, A, Dm, ksz, C), dev, len(w['prenet_w']), save_gates=False, fast=False,
-                      kq=cfg.get('kq', 8))
+    session = None
+    if graph and max_frames <= 2048:          # hipGraph replay: fixed buffers for the whole range (mtts_decoder_fwd_graphed)
+        session = GraphedDecode.get(B, L, max_frames, (M, P, H, A, Dm, ksz, C), dev, len(w['prenet_w']), cfg.get('kq', 8),
+                                    cfg.get('precision', _C.get_precision()))
+        caller = torch.cuda.current_stream(dev)
+        session.stream.wait_stream(caller)
+        with torch.cuda.stream(session.stream):
+            out = _decode_free_loop(memory, lengths, w, cfg, mask_fn(max_frames) if mask_fn is not None else masks, max_frames, stop_frames,
+                                    chunk, stop_threshold, session, dev, M)
+        caller.wait_stream(session.stream)
+        for t in out[:3]:
+            t.record_stream(caller)
+        return out
+    return _decode_free_loop(memory, lengths, w, cfg, masks, max_frames, stop_frames, chunk, stop_threshold, None, dev, M,
+                             initial_frames=initial_frames)
+
+
+def _decode_free_loop(memory, lengths, w, cfg, masks, max_frames, stop_frames, chunk, stop_threshold, session, dev, M, initial_frames=None):
+    B, L, Dm = memory.shape
+    P, H = w['prenet_w'][0].shape[0], w['att_w_hh'].shape[1]
+    A, C, ksz = w['w_query'].shape[0], w['w_conv'].shape[0], w['w_conv'].shape[1]
+    mask_fn = masks if callable(masks) else None
+    if session is not None:
+        w = session.load(memory, lengths, w, masks)
+        st, cap = session.st, max_frames
+    else:
+        cap = min(max_frames, max(chunk, initial_frames or 1024)) if mask_fn is not None else max_frames
+        if mask_fn is not None:
+            masks = mask_fn(cap)
+        st = DecoderState(B, L, cap, (M, P, H, A, Dm, ksz, C), dev, len(w['prenet_w']), save_gates=False, fast=False,
+                          kq=cfg.get('kq', 8))
     lengths32 = lengths.to(device=dev, dtype=torch.int32).contiguous()
     # The stop rule is evaluated on the host per chunk while the device already runs the NEXT chunk (speculatively): the
     # stop logits of chunk k leave through a copy stream once an event after chunk k has fired.
@@ -256,7 +336,10 @@ def decode_free(memory, lengths, w, cfg, masks, max_frames, stop_frames, chunk=3
             cap = min(max_frames, max(2 * cap, t1))
             st = st.grown(cap)
             masks = mask_fn(cap)                     # fresh draws; only steps >= t read them
-        run_decoder(st, w, memory, lengths32, None, None, masks, cfg, t, t1)
+        if session is not None:
+            session.run(w, cfg, t, t1)
+        else:
+            run_decoder(st, w, memory, lengths32, None, None, masks, cfg, t, t1)
         flags = (torch.sigmoid(st.out[t + 1:t1 + 1, :, M]) >= stop_threshold)
         ev = torch.cuda.Event()
         ev.record()

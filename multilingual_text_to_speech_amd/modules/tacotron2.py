@@ -4,6 +4,8 @@
 aliased `_prenet` / `_attention` entries), the same `forward(...)` 6-tuple and `inference(...)`.  All
 arithmetic is dispatched to libmtts_hip; there is no CPU execution path.
 """
+import os
+
 import torch
 from torch.nn import functional as F
 from torch.nn import Sequential, ModuleList, Linear, Embedding, Module
@@ -128,8 +130,10 @@ class Decoder(Module):
             masks = lambda T: self._step_masks(T, B, memory.device)
         w = D.decoder_weights(self, self._attention, self._prenet)
         with torch.no_grad():
+            # MTTS_DECODE_GRAPH=1: chunks of the free-running loop replay as hipGraphs from the third call with the same shapes on
+            # (mtts_decoder_fwd_graphed; needs max_output_length <= 2048 so that the whole range has fixed buffers)
             frames, _, _, n = D.decode_free(memory, lengths, w, self._cfg(), masks, self._max_frames, hp.stop_frames,
-                                            stop_threshold=stop_threshold)
+                                            stop_threshold=stop_threshold, graph=os.environ.get('MTTS_DECODE_GRAPH', '0') == '1')
         return frames, n
 
 

@@ -81,3 +81,40 @@ def test_batched_inference_matches_oracle_batch1_loop(preset, lens):
         done = True
         break
     assert done, 'no seed produced a stop trajectory with safe margins'
+
+
+def test_graph_replayed_decode_equals_eager(monkeypatch):
+    """MTTS_DECODE_GRAPH=1 (BASELINE configs[4]: hipGraph-captured decode steps): the third call with the same shapes replays
+    captured graphs for every chunk and must reproduce the eager result bit for bit (same kernels, same arguments)."""
+    from multilingual_text_to_speech_amd.params import presets, Params as hp
+    from multilingual_text_to_speech_amd.modules.tacotron2 import Tacotron
+    from multilingual_text_to_speech_amd.masks import provider
+    from multilingual_text_to_speech_amd import decoder_ops as D
+    presets.apply('generated_switching', speaker_number=7, max_output_length=70)
+    torch.manual_seed(0)
+    model = Tacotron().cuda().eval()
+    g = torch.Generator().manual_seed(3)
+    lens = [21, 21, 13, 8]
+    texts = [torch.cat((torch.randint(3, hp.symbols_count() + 3, (n - 1,), generator=g), torch.tensor([1]))) for n in lens]
+    n_lang = len(hp.languages)
+    langs = []
+    for i, n in enumerate(lens):
+        w = torch.zeros(n, n_lang); w[:, i % n_lang] = 1.0
+        langs.append(w)
+    spks = [i % hp.speaker_number for i in range(len(lens))]
+    draws = {f'dec.prenet.{k}': (torch.rand(70, len(lens), hp.prenet_dimension, generator=g) >= hp.dropout).to(torch.uint8).cuda() for k in range(2)}
+
+    def run():
+        provider.injected = dict(draws)
+        try:
+            return model.inference_batch(texts, spks, langs, stop_threshold=2.0)       # stop rule off: all 70 frames, 3 chunks
+        finally:
+            provider.injected = None
+    eager = run()
+    monkeypatch.setenv('MTTS_DECODE_GRAPH', '1')
+    outs = [run() for _ in range(3)]
+    sess = next(iter(D.GraphedDecode._cache.values()))
+    assert sess.replayed == 3, sess.replayed                 # 70 frames = chunks of 32, 32, 6: all replayed on the third call
+    for o in outs:
+        for a, b in zip(o, eager):
+            assert torch.equal(a, b)
