@@ -584,6 +584,12 @@ typedef struct TacoLossArgs {
 
 int mtts_tacotron_loss(const TacoLossArgs* args, void* stream);
 
+/* mtts_masked_cross_entropy: ReversalClassifier.loss (modules/classifier.py:62-69) times `scale`: cross entropy of pred [B,L,S] against
+ * speakers[b] at every character l < lengths[b] (the rest is ignore_index), mean over the valid characters.  row_loss [B*L] holds the
+ * per-row contributions (sum them with mtts_colsum), dpred [B,L,S] the gradient of the scaled mean. */
+int mtts_masked_cross_entropy(const float* pred, const int64_t* speakers, const int* lengths, float* row_loss, float* dpred,
+                              int B, int L, int S, float scale, void* stream);
+
 /* mtts_clip_adam_step: torch.nn.utils.clip_grad_norm_(params, max_norm) followed by torch.optim.Adam.step() with L2-coupled
  * weight decay (train.py:84-85,260-270).  ptrs: device array of 4 pointers per tensor {param, grad, exp_avg, exp_avg_sq};
  * chunks partition every tensor into blocks of work. */

@@ -145,3 +145,55 @@ MTTS_API int mtts_clip_adam_step(const AdamArgs* args, void* stream) {
     MTTS_CHECK_LAUNCH("clip_adam_step");
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Adversarial speaker classifier loss (reference ReversalClassifier.loss, modules/classifier.py:62-69): cross entropy of
+// pred [B, L, S] against the utterance's speaker at every VALID character (padding = ignore_index), mean over the valid
+// characters, times `scale`.  One wave per (b, l) row: log-sum-exp over S, per-row loss (already divided by the count) and
+// the gradient (softmax - onehot) * scale / count in the same pass; the count is the sum of the lengths, recomputed per
+// workgroup (B values).
+// ---------------------------------------------------------------------------------------------------------------------
+struct CeArgs { const float* pred; const int64_t* speakers; const int* lengths; float* row_loss; float* dpred; int B, L, S; float scale; };
+
+__global__ __launch_bounds__(256) void masked_ce_kernel(CeArgs p) {
+    __shared__ float cnt_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (wave == 0) {
+        float c = 0.f;
+        for (int b = lane; b < p.B; b += 64) c += (float)min(p.lengths[b], p.L);
+        c = wave_sum(c);
+        if (lane == 0) cnt_s = c;
+    }
+    __syncthreads();
+    const float inv = cnt_s > 0.f ? p.scale / cnt_s : 0.f;
+    const long row = (long)blockIdx.x * 4 + wave;
+    if (row >= (long)p.B * p.L) return;
+    const int b = (int)(row / p.L), l = (int)(row - (long)b * p.L);
+    const bool valid = l < p.lengths[b];
+    const float* x = p.pred + row * p.S;
+    float* dx = p.dpred + row * p.S;
+    if (!valid) {
+        for (int s = lane; s < p.S; s += 64) dx[s] = 0.f;
+        if (lane == 0) p.row_loss[row] = 0.f;
+        return;
+    }
+    float mx = -INFINITY;
+    for (int s = lane; s < p.S; s += 64) mx = fmaxf(mx, x[s]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int s = lane; s < p.S; s += 64) sum += __expf(x[s] - mx);
+    sum = wave_sum(sum);
+    const float lse = mx + __logf(sum);
+    const int tgt = (int)p.speakers[b];
+    for (int s = lane; s < p.S; s += 64) dx[s] = (__expf(x[s] - lse) - (s == tgt ? 1.f : 0.f)) * inv;
+    if (lane == 0) p.row_loss[row] = (tgt >= 0 && tgt < p.S) ? (lse - x[tgt]) * inv : 0.f;
+}
+
+MTTS_API int mtts_masked_cross_entropy(const float* pred, const int64_t* speakers, const int* lengths, float* row_loss, float* dpred,
+                                       int B, int L, int S, float scale, void* stream) {
+    MTTS_REQUIRE(B > 0 && L > 0 && S > 0, "mtts_masked_cross_entropy: empty input");
+    CeArgs p{pred, speakers, lengths, row_loss, dpred, B, L, S, scale};
+    hipLaunchKernelGGL(masked_ce_kernel, dim3((unsigned)(((long)B * L + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+    MTTS_CHECK_LAUNCH("masked_ce_kernel");
+    return 0;
+}

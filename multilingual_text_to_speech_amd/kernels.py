@@ -43,6 +43,15 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, transA=False, transB=False, alpha=1.0,
     return C
 
 
+def colsum(x2):
+    """Column sums of a contiguous [R, C] matrix (deterministic two-stage reduction, mtts_colsum): bias gradients."""
+    R, C = x2.shape
+    out = _f32(C, device=x2.device)
+    ws = _f32(int(lib().mtts_colsum_workspace_floats(C)), device=x2.device)
+    check(lib().mtts_colsum(ptr(x2), ptr(out), R, C, C, ptr(ws), stream_ptr()), 'mtts_colsum')
+    return out
+
+
 def linear_fwd(x, weight, bias=None, act=0, mask=None, mask_scale=1.0):
     """y = act(x W^T + b) [* dropout]; x [..., K] contiguous, weight [N, K] (torch Linear layout)."""
     require_gpu(x, weight)
@@ -62,7 +71,7 @@ def linear_bwd(x, weight, dy, need_dx=True):
     R = x2.shape[0]
     dW = _f32(N, K, device=x.device)
     gemm(dy2, x2, dW, N, K, R, N, K, K, transA=True, transB=True)
-    db = dy2.sum(0)
+    db = colsum(dy2.contiguous())
     dx = None
     if need_dx:
         dx = _f32(R, K, device=x.device)

@@ -35,6 +35,9 @@ class ReversalClassifier(Module):
     @staticmethod
     def loss(input_lengths, speakers, prediction, embeddings=None):
         """Cross entropy over valid characters (padding -> ignore_index); reference modules/classifier.py:62-69."""
+        if prediction.is_cuda:       # value + gradient in one HIP kernel
+            from ..optim import MaskedCrossEntropyFn
+            return MaskedCrossEntropyFn.apply(prediction, speakers, input_lengths, 1.0)
         ignore_index = -100
         ml = torch.max(input_lengths)
         input_mask = torch.arange(ml, device=input_lengths.device)[None, :] < input_lengths[:, None]

@@ -45,6 +45,34 @@ class TacotronLossFn(torch.autograd.Function):
                 None if d_align is None else (dout[3] + s) * d_align, None, None, None, None, None, None, None)
 
 
+class MaskedCrossEntropyFn(torch.autograd.Function):
+    """scale * mean over valid characters of CE(pred[b, l, :], speakers[b])  (reference ReversalClassifier.loss,
+    modules/classifier.py:62-69) - value and gradient in one kernel (mtts_masked_cross_entropy)."""
+
+    @staticmethod
+    def forward(ctx, pred, speakers, lengths, scale):
+        require_gpu(pred)
+        pred = pred.contiguous()
+        B, L, S = pred.shape
+        dev = pred.device
+        spk = speakers.to(device=dev, dtype=torch.int64).contiguous()
+        lens = lengths.to(device=dev, dtype=torch.int32).contiguous()
+        row_loss = torch.empty(B * L, 1, dtype=torch.float32, device=dev)
+        dpred = torch.empty_like(pred)
+        check(lib().mtts_masked_cross_entropy(ptr(pred), ptr(spk), ptr(lens), ptr(row_loss), ptr(dpred), B, L, S, ctypes.c_float(scale),
+                                              stream_ptr()), 'mtts_masked_cross_entropy')
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+        ws = torch.empty(int(lib().mtts_colsum_workspace_floats(1)), dtype=torch.float32, device=dev)
+        check(lib().mtts_colsum(ptr(row_loss), ptr(out), B * L, 1, 1, ptr(ws), stream_ptr()), 'mtts_colsum')
+        ctx.save_for_backward(dpred)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpred,) = ctx.saved_tensors
+        return dpred * g, None, None, None
+
+
 class FusedAdam(torch.optim.Adam):
     """torch.optim.Adam (same hyper-parameters, same state_dict layout: step / exp_avg / exp_avg_sq) whose `step` runs
     clip_grad_norm_ + the Adam update in three kernel launches over device-side tensor tables

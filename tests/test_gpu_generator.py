@@ -28,3 +28,25 @@ def test_generated_kernel_matches_linear_view_and_its_autograd(G, bott, Og, Cg, 
     for a, t, name in zip(got, (hidden, wk, bk), ('hidden', 'w_kernel', 'b_kernel')):
         r = t.grad.double()
         assert (a.double() - r).abs().max().item() <= 2e-5 * max(1.0, r.abs().max().item()), name
+
+
+@pytest.mark.parametrize('B,L,S', [(4, 9, 5), (10, 120, 91), (3, 7, 130)])
+def test_masked_cross_entropy_matches_the_reference_loss(B, L, S):
+    """mtts_masked_cross_entropy vs the reference's ReversalClassifier.loss (modules/classifier.py:62-69: F.cross_entropy with
+    padding as ignore_index) - value and gradient."""
+    import torch.nn.functional as F
+    from multilingual_text_to_speech_amd.modules.classifier import ReversalClassifier
+    g = torch.Generator().manual_seed(B * 7 + S)
+    pred = (3 * torch.randn(B, L, S, generator=g)).cuda().requires_grad_(True)
+    lengths = torch.randint(1, L + 1, (B,), generator=g); lengths[0] = L
+    speakers = torch.randint(0, S, (B,), generator=g)
+    loss = ReversalClassifier.loss(lengths.cuda(), speakers.cuda(), pred)
+    (loss * 0.7).backward()
+    got = pred.grad.clone()
+    ref_in = pred.detach().double().cpu().requires_grad_(True)
+    target = speakers.repeat(L, 1).transpose(0, 1).clone()
+    target[~(torch.arange(L)[None, :] < lengths[:, None])] = -100
+    ref = F.cross_entropy(ref_in.transpose(1, 2), target, ignore_index=-100)
+    (ref * 0.7).backward()
+    assert abs(loss.item() - ref.item()) <= 1e-5 * max(1.0, abs(ref.item()))
+    assert (got.double().cpu() - ref_in.grad).abs().max().item() <= 1e-6
