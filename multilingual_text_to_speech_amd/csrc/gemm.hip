@@ -209,6 +209,47 @@ __device__ __forceinline__ void store_tile_split(char* lds, const Tile<TRANS>& t
     }
 }
 
+// Write one wave's 64x64 block of accumulators: raw partial tile into the split-K scratch, or the fused epilogue
+// (alpha, bias, beta * C, activation, keep-mask).  C/D layout of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+__device__ __forceinline__ void tile_epilogue(const GemmArgs& p, const f32x16 (&acc)[2][2], float* g_ws, float* C, const float* bias,
+                                              int z, int row0, int col0, int li, int lq) {
+    if (gridDim.y > 1) {
+        float* W = g_ws + ((long)z * gridDim.y + blockIdx.y) * (long)p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = col0 + j * 32 + li;
+                if (col >= p.N) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lq;
+                    if (row < p.M) W[(long)row * p.N + col] = acc[i][j][r];
+                }
+            }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = col0 + j * 32 + li;
+            if (col >= p.N) continue;
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lq;
+                if (row >= p.M) continue;
+                float v = p.alpha * acc[i][j][r] + bv;
+                float* cp = C + (long)row * p.ldc + col;
+                if (p.beta != 0.f) v += p.beta * (*cp);
+                v = apply_act(p.act, v);
+                if (p.mask) v = p.mask[(long)row * p.ldmask + col] ? v * p.mask_scale : 0.f;
+                *cp = v;
+            }
+        }
+}
+
 template <bool TA, bool TB, int NPL = 3>
 __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p, float* g_ws) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -300,42 +341,205 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p, float* g
         __syncthreads();
     }
 
-    // C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    if (gridDim.y > 1) {
-        float* W = g_ws + ((long)z * gridDim.y + blockIdx.y) * (long)p.M * p.N;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = n0 + wn + j * 32 + li;
-                if (col >= p.N) continue;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lq;
-                    if (row < p.M) W[(long)row * p.N + col] = acc[i][j][r];
-                }
-            }
-        return;
+    tile_epilogue(p, acc, g_ws, C, bias, z, m0 + wm, n0 + wn, li, lq);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// gemm_pipe_kernel: the split-bf16 core as a software pipeline inside ONE wave per SIMD.
+//
+// gemm_split_kernel above alternates phases (48 MFMAs | barrier | split + ds_write | barrier): with one workgroup per CU - the
+// only configuration the helper streams are allowed, DESIGN.md 3.1 - the matrix pipe idles during every split phase (MFMA
+// busy ~50 %).  Here the LDS image is double buffered (2 x 48 KiB) and the 3-way split of tile kb+1, its LDS stores, the
+// global loads of tile kb+2 and the fragment reads are issued IN THE SHADOW of tile kb's 48 MFMAs, about five instructions per
+// MFMA (the measured issue budget of a lone wave, MI355X_MICROARCH.md).  The placement is generated
+// (scripts/gen_gemm_pipe.py -> gemm_pipe_body.inc) and pinned with sched_barrier(0) after every MFMA group; MFMA order and
+// accumulation order equal gemm_split_kernel's, so both cores return bit-identical results.
+// Global loads are raw buffer loads (descriptor base per 32-row slab, one VGPR offset per operand, K position in an SGPR):
+// no per-load address arithmetic.  Plain GEMMs only (shift_mode 0, K % 32 == 0, 16-byte aligned operands); everything else
+// stays on gemm_split_kernel.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int PP_STAGE_B = 3 * SP_PLANE_B;            // one operand, one stage: 3 planes = 24 KiB
+constexpr int PP_OPERAND_B = 2 * PP_STAGE_B;          // A: [2 stages][3 planes], B behind it: 96 KiB in all
+constexpr unsigned PP_SEL = 0x07060302u, PP_MASK = 0xffff0000u;
+
+struct PipeTmp { unsigned hx[8], hy[8], p1[8], p2[8], p3[8]; float rx[8], ry[8]; };
+
+// pair j of a thread's 16 elements: K-contiguous operand: float4 `j >> 1`, halves (x,y) / (z,w); transposed operand: the thread
+// holds k = 4 * (tid % 8) + it of rows 4 * (tid / 8) + {x,y,z,w}, pair j = row j >> 1, k-halves (0,1) / (2,3)
+template <bool T> __device__ __forceinline__ unsigned pipe_x(const u32x4 (&R)[4], int j) { return T ? R[2 * (j & 1)][j >> 1] : R[j >> 1][2 * (j & 1)]; }
+template <bool T> __device__ __forceinline__ unsigned pipe_y(const u32x4 (&R)[4], int j) { return T ? R[2 * (j & 1) + 1][j >> 1] : R[j >> 1][2 * (j & 1) + 1]; }
+
+// LDS stores of a split tile, issued in six slots as soon as the planes they need exist (slot 0, 1: after the first split stage of
+// pairs 0-3 / 4-7; slots 2-5: after the second stage of pairs 2s-4, 2s-3).  K-contiguous operand: rows it and it + 1 of one plane
+// lie 2 KiB apart (one ds_write2st64_b64); transposed operand: row u = slot - 2 gets planes 0 + 1 and plane 2.
+template <bool T>
+__device__ __forceinline__ void pipe_store(char* base, const PipeTmp& t, int slot) {
+    if (!T) {
+        const int u = slot < 2 ? 2 * slot : (slot == 3 ? 0 : 2);
+        if (slot < 2) {
+            *reinterpret_cast<uint2*>(base + u * 2048) = make_uint2(t.p1[2 * u], t.p1[2 * u + 1]);
+            *reinterpret_cast<uint2*>(base + (u + 1) * 2048) = make_uint2(t.p1[2 * u + 2], t.p1[2 * u + 3]);
+        } else if (slot == 3 || slot == 5) {
+            *reinterpret_cast<uint2*>(base + SP_PLANE_B + u * 2048) = make_uint2(t.p2[2 * u], t.p2[2 * u + 1]);
+            *reinterpret_cast<uint2*>(base + SP_PLANE_B + (u + 1) * 2048) = make_uint2(t.p2[2 * u + 2], t.p2[2 * u + 3]);
+            *reinterpret_cast<uint2*>(base + 2 * SP_PLANE_B + u * 2048) = make_uint2(t.p3[2 * u], t.p3[2 * u + 1]);
+            *reinterpret_cast<uint2*>(base + 2 * SP_PLANE_B + (u + 1) * 2048) = make_uint2(t.p3[2 * u + 2], t.p3[2 * u + 3]);
+        }
+    } else if (slot >= 2) {
+        const int u = slot - 2;
+        *reinterpret_cast<uint2*>(base + u * SP_ROW_B) = make_uint2(t.p1[2 * u], t.p1[2 * u + 1]);
+        *reinterpret_cast<uint2*>(base + u * SP_ROW_B + SP_PLANE_B) = make_uint2(t.p2[2 * u], t.p2[2 * u + 1]);
+        *reinterpret_cast<uint2*>(base + u * SP_ROW_B + 2 * SP_PLANE_B) = make_uint2(t.p3[2 * u], t.p3[2 * u + 1]);
     }
+}
+
+#define PP_SB __builtin_amdgcn_sched_barrier(0);
+#define PP_MFMA(F, i, j, pa, pb) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F##a[i][pa], F##b[j][pb], acc[i][j], 0, 0, 0);
+#define PP_RDA(F, ks, i, pl, STG) F##a[i][pl] = *reinterpret_cast<const bf16x8*>(lds + ((STG) * PP_STAGE_B + (pl) * SP_PLANE_B) + ra[ks][i]);
+#define PP_RDB(F, ks, j, pl, STG) F##b[j][pl] = *reinterpret_cast<const bf16x8*>(lds + ((STG) * PP_STAGE_B + (pl) * SP_PLANE_B) + rb[ks][j]);
+#define PP_S1A(O, j) { tmp.hx[j] = pipe_x<T##O>(R##O, j) & PP_MASK; tmp.hy[j] = pipe_y<T##O>(R##O, j) & PP_MASK; }
+#define PP_S1B(O, j) { const unsigned ux = pipe_x<T##O>(R##O, j), uy = pipe_y<T##O>(R##O, j);                                  \
+        tmp.rx[j] = __uint_as_float(ux) - __uint_as_float(tmp.hx[j]); tmp.ry[j] = __uint_as_float(uy) - __uint_as_float(tmp.hy[j]); \
+        tmp.p1[j] = __builtin_amdgcn_perm(uy, ux, PP_SEL); }
+#define PP_S2A(O, j) { const unsigned vx = __float_as_uint(tmp.rx[j]), vy = __float_as_uint(tmp.ry[j]);                           \
+        tmp.hx[j] = vx & PP_MASK; tmp.hy[j] = vy & PP_MASK; tmp.p2[j] = __builtin_amdgcn_perm(vy, vx, PP_SEL); }
+#define PP_S2B(O, j) { const float sx = tmp.rx[j] - __uint_as_float(tmp.hx[j]), sy = tmp.ry[j] - __uint_as_float(tmp.hy[j]);      \
+        tmp.p3[j] = __builtin_amdgcn_perm(__float_as_uint(sy), __float_as_uint(sx), PP_SEL); }
+#define PP_LD(O, it) R##O[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc##O[it], voff##O, soff##O, 0);
+#define PP_NEXT(O) soff##O = min(soff##O + step##O, last##O);
+#define PP_OFF_A 0
+#define PP_OFF_B PP_OPERAND_B
+#define PP_ST(O, k) pipe_store<T##O>(lds + (PP_NXT * PP_STAGE_B + PP_OFF_##O) + wa##O, tmp, k);
+#define PP_BARRIER __syncthreads();
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(GemmArgs p, float* g_ws) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* lds = reinterpret_cast<char*>(smem);
+
+    const int ntx = (p.N + BN - 1) / BN, nty = (p.M + BM - 1) / BM;
+    const int nt = ntx * nty;
+    int id = blockIdx.x;
+    {   // XCD-aware tile order (see gemm_mfma_kernel)
+        const int q = nt / 8, r = nt % 8, xcd = id % 8, idx = id / 8;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = id / ntx, tile_n = id % ntx;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int z = blockIdx.z;
+    const int zb = z / p.zt, ztap = z % p.zt;
+    const float* A = p.A + (long)zb * p.a_z;
+    const float* B = p.B + (long)zb * p.b_z;
+    float* C = p.C + (long)zb * p.c_z + (long)ztap * p.c_ztap;
+    const float* bias = p.bias ? p.bias + (long)zb * p.bias_z : nullptr;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int li = lane & 31, lq = lane >> 5;
+
+    // K range of this workgroup (split-K over blockIdx.y)
+    const int nk_all = p.K / BK;
+    const int per_split = (nk_all + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int kb0 = blockIdx.y * per_split;
+    const int nk = min(nk_all, kb0 + per_split);
+
+    f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn + j * 32 + li;
-            if (col >= p.N) continue;
-            const float bv = bias ? bias[col] : 0.f;
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lq;
-                if (row >= p.M) continue;
-                float v = p.alpha * acc[i][j][r] + bv;
-                float* cp = C + (long)row * p.ldc + col;
-                if (p.beta != 0.f) v += p.beta * (*cp);
-                v = apply_act(p.act, v);
-                if (p.mask) v = p.mask[(long)row * p.ldmask + col] ? v * p.mask_scale : 0.f;
-                *cp = v;
-            }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (kb0 < nk) {
+        // ---- global side: descriptor `it` starts at the operand's slab `it` of this tile; a thread's offset inside every slab is
+        // the same, the K position rides in the scalar offset.  Extents are exact, so rows past the end of a K-contiguous operand
+        // read as zero without touching memory; a transposed operand clamps its row group (M % 4 == 0 there).
+        const long extA = TA ? ((long)(p.K - 1) * p.lda + p.M) * 4 : ((long)(p.M - 1) * p.lda + p.K) * 4;
+        const long extB = TB ? ((long)(p.K - 1) * p.ldb + p.N) * 4 : ((long)(p.N - 1) * p.ldb + p.K) * 4;
+        __amdgpu_buffer_rsrc_t rsrcA[4], rsrcB[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const long sa = (TA ? (long)it * p.lda + m0 : ((long)m0 + it * 32) * p.lda) * 4;
+            const long sb = (TB ? (long)it * p.ldb + n0 : ((long)n0 + it * 32) * p.ldb) * 4;
+            rsrcA[it] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(A)) + sa, 0,
+                                                          (int)max(0L, extA - sa), 0x00020000);
+            rsrcB[it] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(B)) + sb, 0,
+                                                          (int)max(0L, extB - sb), 0x00020000);
         }
+        const int q8 = tid >> 3, k8 = tid & 7;
+        const unsigned voffA = TA ? (unsigned)(((long)(4 * k8) * p.lda + min(4 * q8, max(p.M - m0 - 4, 0))) * 4)
+                                  : (unsigned)(((long)q8 * p.lda + 4 * k8) * 4);
+        const unsigned voffB = TB ? (unsigned)(((long)(4 * k8) * p.ldb + min(4 * q8, max(p.N - n0 - 4, 0))) * 4)
+                                  : (unsigned)(((long)q8 * p.ldb + 4 * k8) * 4);
+        const unsigned stepA = TA ? (unsigned)p.lda * (BK * 4) : BK * 4, stepB = TB ? (unsigned)p.ldb * (BK * 4) : BK * 4;
+        const unsigned lastA = (unsigned)(nk - 1) * stepA, lastB = (unsigned)(nk - 1) * stepB;
+        unsigned soffA = (unsigned)kb0 * stepA, soffB = (unsigned)kb0 * stepB;
+
+        // ---- LDS side.  Store address of the thread's first row (pipe_store adds rows / planes); fragment read addresses.
+        const int wrA = TA ? 4 * q8 : q8, wrB = TB ? 4 * q8 : q8;
+        const unsigned waA = wrA * SP_ROW_B + (((k8 >> 1) ^ ((wrA >> 2) & 3)) * 16) + (k8 & 1) * 8;
+        const unsigned waB = wrB * SP_ROW_B + (((k8 >> 1) ^ ((wrB >> 2) & 3)) * 16) + (k8 & 1) * 8;
+        unsigned ra[2][2], rb[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int rowa = wm + i * 32 + li, rowb = wn + i * 32 + li;
+                ra[ks][i] = rowa * SP_ROW_B + (((2 * ks + lq) ^ ((rowa >> 2) & 3)) * 16);
+                rb[ks][i] = rowb * SP_ROW_B + (((2 * ks + lq) ^ ((rowb >> 2) & 3)) * 16) + PP_OPERAND_B;
+            }
+
+        u32x4 RA[4], RB[4];
+        PipeTmp tmp;
+        bf16x8 f0a[2][3], f0b[2][3], f1a[2][3], f1b[2][3];
+
+        // prologue: tile kb0 -> stage 0, tile kb0 + 1 in flight, first fragments
+#pragma unroll
+        for (int it = 0; it < 4; ++it) { PP_LD(A, it) PP_LD(B, it) }
+        PP_NEXT(A) PP_NEXT(B)
+#define PP_NXT 0
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { PP_S1A(A, j) PP_S1B(A, j) PP_S2A(A, j) PP_S2B(A, j) }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { PP_ST(A, k) }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { PP_S1A(B, j) PP_S1B(B, j) PP_S2A(B, j) PP_S2B(B, j) }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { PP_ST(B, k) }
+#undef PP_NXT
+#pragma unroll
+        for (int it = 0; it < 4; ++it) { PP_LD(A, it) PP_LD(B, it) }
+        PP_NEXT(A) PP_NEXT(B)
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) { PP_RDA(f0, 0, i, pl, 0) PP_RDB(f0, 0, i, pl, 0) }
+
+        // K blocks in pairs (the stage is a compile-time constant inside each copy of the stream), an odd last block after the loop
+        for (int n = (nk - kb0) >> 1; n > 0; --n) {
+#define PP_CUR 0
+#define PP_NXT 1
+#include "gemm_pipe_body.inc"
+#undef PP_CUR
+#undef PP_NXT
+#define PP_CUR 1
+#define PP_NXT 0
+#include "gemm_pipe_body.inc"
+#undef PP_CUR
+#undef PP_NXT
+        }
+        if ((nk - kb0) & 1) {
+#define PP_CUR 0
+#define PP_NXT 1
+#include "gemm_pipe_body.inc"
+#undef PP_CUR
+#undef PP_NXT
+        }
+    }
+    tile_epilogue(p, acc, g_ws, C, bias, z, m0 + wm, n0 + wn, li, lq);
 }
 
 template <bool TA, bool TB>
@@ -529,15 +733,32 @@ MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     static bool attr_done = false;
     if (!attr_done) {   // > 64 KiB of dynamic LDS needs the opt-in attribute
-        const void* kernels[8] = {(const void*)gemm_mfma_kernel<false, false>, (const void*)gemm_mfma_kernel<false, true>,
-                                  (const void*)gemm_mfma_kernel<true, false>, (const void*)gemm_mfma_kernel<true, true>,
-                                  (const void*)gemm_split_kernel<false, false>, (const void*)gemm_split_kernel<false, true>,
-                                  (const void*)gemm_split_kernel<true, false>, (const void*)gemm_split_kernel<true, true>};
+        const void* kernels[12] = {(const void*)gemm_mfma_kernel<false, false>, (const void*)gemm_mfma_kernel<false, true>,
+                                   (const void*)gemm_mfma_kernel<true, false>, (const void*)gemm_mfma_kernel<true, true>,
+                                   (const void*)gemm_split_kernel<false, false>, (const void*)gemm_split_kernel<false, true>,
+                                   (const void*)gemm_split_kernel<true, false>, (const void*)gemm_split_kernel<true, true>,
+                                   (const void*)gemm_pipe_kernel<false, false>, (const void*)gemm_pipe_kernel<false, true>,
+                                   (const void*)gemm_pipe_kernel<true, false>, (const void*)gemm_pipe_kernel<true, true>};
         for (const void* k : kernels) MTTS_CHECK_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_done = true;
     }
     float* ws = g_ws_host ? g_ws_host + (size_t)region * (region_bytes / sizeof(float)) : nullptr;
-    if (exact_f32) {
+    // plain fp32 GEMMs with whole K blocks and 16-byte aligned operands run on the software-pipelined core (MTTS_GEMM_PIPE=0: off)
+    static const bool pipe_on = [] { const char* e = getenv("MTTS_GEMM_PIPE"); return !(e && e[0] == '0'); }();
+    const auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const long ext_a = p.transA ? ((long)(p.K - 1) * p.lda + p.M) : ((long)(p.M - 1) * p.lda + p.K);
+    const long ext_b = p.transB ? ((long)(p.K - 1) * p.ldb + p.N) : ((long)(p.N - 1) * p.ldb + p.K);
+    const bool pipe = pipe_on && !exact_f32 && p.precision != 1 && p.shift_mode == 0 && p.taps == 1 && p.K >= BK && p.K % BK == 0 &&
+                      (p.lda & 3) == 0 && (p.ldb & 3) == 0 && (p.a_z & 3) == 0 && (p.b_z & 3) == 0 && aligned16(p.A) && aligned16(p.B) &&
+                      p.lda >= (p.transA ? p.M : p.K) && p.ldb >= (p.transB ? p.N : p.K) && (!p.transA || (p.M & 3) == 0) &&
+                      (!p.transB || (p.N & 3) == 0) && ext_a < (1L << 29) && ext_b < (1L << 29);
+    if (pipe) {
+        const size_t ldsp = 2 * PP_OPERAND_B;
+        if (!p.transA && !p.transB) hipLaunchKernelGGL((gemm_pipe_kernel<false, false>), grid, dim3(256), ldsp, s, p, ws);
+        else if (!p.transA && p.transB) hipLaunchKernelGGL((gemm_pipe_kernel<false, true>), grid, dim3(256), ldsp, s, p, ws);
+        else if (p.transA && !p.transB) hipLaunchKernelGGL((gemm_pipe_kernel<true, false>), grid, dim3(256), ldsp, s, p, ws);
+        else hipLaunchKernelGGL((gemm_pipe_kernel<true, true>), grid, dim3(256), ldsp, s, p, ws);
+    } else if (exact_f32) {
         if (!p.transA && !p.transB) hipLaunchKernelGGL((gemm_mfma_kernel<false, false>), grid, dim3(256), lds, s, p, ws);
         else if (!p.transA && p.transB) hipLaunchKernelGGL((gemm_mfma_kernel<false, true>), grid, dim3(256), lds, s, p, ws);
         else if (p.transA && !p.transB) hipLaunchKernelGGL((gemm_mfma_kernel<true, false>), grid, dim3(256), lds, s, p, ws);

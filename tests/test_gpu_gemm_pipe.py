@@ -1,0 +1,100 @@
+"""Software-pipelined GEMM core (gemm_pipe_kernel, csrc/gemm.hip): plain fp32 GEMMs with whole 32-wide K blocks run on it by default.
+It must (a) stay at fp32-accumulation error against fp64 on every storage variant, ragged M / N, split-K and batched launches and
+every epilogue, and (b) return the SAME BITS as gemm_split_kernel (same products, same accumulation order), which a child process
+with MTTS_GEMM_PIPE=0 computes."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# (M, N, K): K a multiple of 32; ragged M / N; one-tile / long-K shapes that take the split-K path; a single K block
+SHAPES = [(333, 517, 1248), (128, 128, 32), (64, 40, 64), (1000, 81, 1024), (256, 384, 4096), (100, 2052, 96), (4, 8, 4096)]
+
+
+def _operands(M, N, K, variant, seed):
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    A = torch.randn(M, K, device='cuda', generator=g) * torch.exp2(torch.randint(-6, 6, (M, K), device='cuda', generator=g).float())
+    B = torch.randn(N, K, device='cuda', generator=g) * torch.exp2(torch.randint(-6, 6, (N, K), device='cuda', generator=g).float())
+    tA, tB = variant[0] == 't', variant[1] == 'n'
+    return A, B, (A.t().contiguous() if tA else A), (B.t().contiguous() if tB else B), tA, tB
+
+
+def _run(M, N, K, variant, seed, **epilogue):
+    from multilingual_text_to_speech_amd import kernels as Kn
+    A, B, a_st, b_st, tA, tB = _operands(M, N, K, variant, seed)
+    C = torch.full((M, N), 0.5, device='cuda')
+    Kn.gemm(a_st, b_st, C, M, N, K, M if tA else K, N if tB else K, N, transA=tA, transB=tB, **epilogue)
+    return A, B, C
+
+
+def _transposable(M, N, variant):
+    # a transposed operand is handed over with its row count as the leading dimension: float4 loads need it to be a multiple of 4
+    return (variant[0] != 't' or M % 4 == 0) and (variant[1] != 'n' or N % 4 == 0)
+
+
+@pytest.mark.parametrize('variant', ['nt', 'nn', 'tt', 'tn'])
+@pytest.mark.parametrize('shape', SHAPES)
+def test_pipelined_core_is_fp32_accurate(shape, variant):
+    M, N, K = shape
+    if not _transposable(M, N, variant):
+        pytest.skip('leading dimension of the transposed operand is not a multiple of 4: not a shape the library accepts vectorised')
+    A, B, C = _run(M, N, K, variant, seed=11)
+    ref = A.double() @ B.double().t()
+    scale = A.double().abs() @ B.double().abs().t()
+    err = ((C.double() - ref).abs() / scale).max().item()
+    err_torch = (((A @ B.t()).double() - ref).abs() / scale).max().item()
+    # the maximum over a few hundred thousand outputs fluctuates by tens of percent between two correct fp32 summation orders
+    assert err <= 2.0 * err_torch + 2.0 ** -24, f'{variant} {shape}: {err:.3e} (torch fp32: {err_torch:.3e})'
+
+
+def test_pipelined_core_epilogue_and_batch():
+    """alpha / beta / bias / activation / keep-mask epilogue and a grid.z batch (b_z, c_z strides) on the pipelined core."""
+    from multilingual_text_to_speech_amd import kernels as Kn
+    M, N, K = 200, 136, 256
+    A, B, a_st, b_st, _, _ = _operands(M, N, K, 'nt', 5)
+    bias = torch.randn(N, device='cuda')
+    mask = (torch.rand(M, N, device='cuda') > 0.3).to(torch.uint8)
+    C0 = torch.randn(M, N, device='cuda')
+    C = C0.clone()
+    Kn.gemm(a_st, b_st, C, M, N, K, K, K, N, alpha=0.5, beta=2.0, bias=bias, act=1, mask=mask, mask_scale=1.25)
+    ref = torch.relu(0.5 * (A.double() @ B.double().t()) + bias.double() + 2.0 * C0.double()) * mask.double() * 1.25
+    assert (C.double() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    # batch of 3 independent products through grid.z
+    G = 3
+    Ab = torch.randn(G, M, K, device='cuda')
+    Bb = torch.randn(G, N, K, device='cuda')
+    Cb = torch.empty(G, M, N, device='cuda')
+    Kn.gemm(Ab, Bb, Cb, M, N, K, K, K, N, batch=G, a_z=M * K, b_z=N * K, c_z=M * N)
+    refb = torch.matmul(Ab.double(), Bb.double().transpose(1, 2))
+    assert (Cb.double() - refb).abs().max().item() <= 1e-4 * refb.abs().max().item()
+
+
+_CHILD = r'''
+import sys, torch
+sys.path.insert(0, %(root)r)
+from tests.test_gpu_gemm_pipe import SHAPES, _run, _transposable
+out = {}
+for shape in SHAPES:
+    for variant in ('nt', 'nn', 'tt', 'tn'):
+        if _transposable(shape[0], shape[1], variant):
+            out[(shape, variant)] = _run(*shape, variant, seed=23)[2].cpu()
+torch.save(out, sys.argv[1])
+'''
+
+
+def test_pipelined_core_returns_the_bits_of_the_phase_alternating_core(tmp_path):
+    outs = {}
+    for mode in ('1', '0'):
+        path = str(tmp_path / f'gemm_{mode}.pt')
+        env = dict(os.environ, MTTS_GEMM_PIPE=mode)
+        r = subprocess.run([sys.executable, '-c', _CHILD % {'root': ROOT}, path], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs[mode] = torch.load(path)
+    assert outs['1'].keys() == outs['0'].keys() and len(outs['1']) >= 20
+    for key, c in outs['1'].items():
+        assert torch.equal(c, outs['0'][key]), f'{key}: pipelined and phase-alternating cores differ'
