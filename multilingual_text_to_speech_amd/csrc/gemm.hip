@@ -209,8 +209,54 @@ __device__ __forceinline__ void store_tile_split(char* lds, const Tile<TRANS>& t
     }
 }
 
-// Write one wave's 64x64 block of accumulators: raw partial tile into the split-K scratch, or the fused epilogue
-// (alpha, bias, beta * C, activation, keep-mask).  C/D layout of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+// Epilogue arithmetic of one element: alpha, bias, beta * C, activation, keep-mask.  Everything that is uniform over the launch is
+// decided outside the element loops (activation kind ACTK 0: none, 1: ReLU, 2: tanh / sigmoid as a template parameter; beta and the
+// mask as loop-invariant flags whose loads are skipped and whose arithmetic is branch-free): evaluated per element they cost a lone
+// wave ~60 branches per stored row - measured at 11 us per 128x128 tile, as much as eight K blocks.
+struct EpiFlags { bool beta, mask; float scale; };
+__device__ __forceinline__ EpiFlags epi_flags(const GemmArgs& p) { return {p.beta != 0.f, p.mask != nullptr, p.mask ? p.mask_scale : 1.f}; }
+template <int ACTK>
+__device__ __forceinline__ float epi_value(const GemmArgs& p, const EpiFlags& f, float acc, float bv, float c, unsigned m) {
+    float v = p.alpha * acc + bv;
+    v += p.beta * c;                       // c == 0 when beta == 0 (never loaded)
+    if (ACTK == 1) v = fmaxf(v, 0.0f);
+    if (ACTK == 2) v = apply_act(p.act, v);
+    return m ? v * f.scale : 0.f;          // m == 1, scale == 1 without a mask
+}
+
+// MFMA layout of a wave's 64x64 block: C/D of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+template <int ACTK>
+__device__ __forceinline__ void tile_epilogue_t(const GemmArgs& p, const f32x16 (&acc)[2][2], float* C, const float* bias, int row0, int col0,
+                                                int li, int lq) {
+    const EpiFlags f = epi_flags(p);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = col0 + j * 32 + li;
+            if (col >= p.N) continue;
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lq;
+                if (row >= p.M) continue;
+                float* cp = C + (long)row * p.ldc + col;
+                float c = 0.f; unsigned m = 1;
+                if (f.beta) c = *cp;
+                if (f.mask) m = p.mask[(long)row * p.ldmask + col];
+                *cp = epi_value<ACTK>(p, f, acc[i][j][r], bv, c, m);
+            }
+        }
+}
+
+#define MTTS_EPI_DISPATCH(FN, ...)                                          \
+    do {                                                                    \
+        if (p.act == MTTS_ACT_NONE) FN<0>(__VA_ARGS__);                      \
+        else if (p.act == MTTS_ACT_RELU) FN<1>(__VA_ARGS__);                 \
+        else FN<2>(__VA_ARGS__);                                             \
+    } while (0)
+
+// Write one wave's 64x64 block of accumulators: raw partial tile into the split-K scratch, or the fused epilogue.
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& p, const f32x16 (&acc)[2][2], float* g_ws, float* C, const float* bias,
                                               int z, int row0, int col0, int li, int lq) {
     if (gridDim.y > 1) {
@@ -229,25 +275,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& p, const f32x16 (&
             }
         return;
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = col0 + j * 32 + li;
-            if (col >= p.N) continue;
-            const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lq;
-                if (row >= p.M) continue;
-                float v = p.alpha * acc[i][j][r] + bv;
-                float* cp = C + (long)row * p.ldc + col;
-                if (p.beta != 0.f) v += p.beta * (*cp);
-                v = apply_act(p.act, v);
-                if (p.mask) v = p.mask[(long)row * p.ldmask + col] ? v * p.mask_scale : 0.f;
-                *cp = v;
-            }
-        }
+    MTTS_EPI_DISPATCH(tile_epilogue_t, p, acc, C, bias, row0, col0, li, lq);
 }
 
 template <bool TA, bool TB, int NPL = 3>
@@ -364,29 +392,41 @@ constexpr unsigned PP_SEL = 0x07060302u, PP_MASK = 0xffff0000u;
 
 struct PipeTmp { unsigned hx[8], hy[8], p1[8], p2[8], p3[8]; float rx[8], ry[8]; };
 
-// pair j of a thread's 16 elements: K-contiguous operand: float4 `j >> 1`, halves (x,y) / (z,w); transposed operand: the thread
-// holds k = 4 * (tid % 8) + it of rows 4 * (tid / 8) + {x,y,z,w}, pair j = row j >> 1, k-halves (0,1) / (2,3)
+// The thread's 16 elements are split pair by pair, in processing order n = 0..7.  K-contiguous operand: pair n = float4 `n >> 1`,
+// halves (x,y) / (z,w).  Transposed operand: the thread holds k = 4 * (tid % 8) + it of rows 4 * (tid / 8) + {x,y,z,w}; output row u
+// needs (k0,k1) and (k2,k3): pairs are taken k-half by k-half (n = 0..3: float4 0,1 of rows 0..3; n = 4..7: float4 2,3), so that
+// the first two float4 registers are free for the next loads after four pairs.  Pair index in the temporaries: 2 * row + half.
+template <bool T> __device__ __forceinline__ constexpr int pipe_pair(int n) { return T ? 2 * (n & 3) + (n >> 2) : n; }
 template <bool T> __device__ __forceinline__ unsigned pipe_x(const u32x4 (&R)[4], int j) { return T ? R[2 * (j & 1)][j >> 1] : R[j >> 1][2 * (j & 1)]; }
 template <bool T> __device__ __forceinline__ unsigned pipe_y(const u32x4 (&R)[4], int j) { return T ? R[2 * (j & 1) + 1][j >> 1] : R[j >> 1][2 * (j & 1) + 1]; }
 
-// LDS stores of a split tile, issued in six slots as soon as the planes they need exist (slot 0, 1: after the first split stage of
-// pairs 0-3 / 4-7; slots 2-5: after the second stage of pairs 2s-4, 2s-3).  K-contiguous operand: rows it and it + 1 of one plane
-// lie 2 KiB apart (one ds_write2st64_b64); transposed operand: row u = slot - 2 gets planes 0 + 1 and plane 2.
+// which float4 of the tile after next may be requested after processing step n (slot 8: right after step 4, slot 9: after step 7)
+template <bool T> __device__ __forceinline__ constexpr int pipe_load_slot(int n) {
+    return T ? (n == 3 ? 0 : (n == 8 ? 1 : (n == 7 ? 2 : (n == 9 ? 3 : -1)))) : ((n & 1) && n < 8 ? n >> 1 : -1);
+}
+
+// LDS stores of a split tile, issued as soon as the planes they need exist.  K-contiguous operand: rows it and it + 1 of one plane
+// lie 2 KiB apart (one ds_write2st64_b64): plane 0 after the first stage of pairs 0-3 / 4-7, planes 1 + 2 after their second
+// stage.  Transposed operand: row u is complete after second-stage step 4 + u.
 template <bool T>
-__device__ __forceinline__ void pipe_store(char* base, const PipeTmp& t, int slot) {
+__device__ __forceinline__ void pipe_store1(char* base, const PipeTmp& t, int n) {
     if (!T) {
-        const int u = slot < 2 ? 2 * slot : (slot == 3 ? 0 : 2);
-        if (slot < 2) {
-            *reinterpret_cast<uint2*>(base + u * 2048) = make_uint2(t.p1[2 * u], t.p1[2 * u + 1]);
-            *reinterpret_cast<uint2*>(base + (u + 1) * 2048) = make_uint2(t.p1[2 * u + 2], t.p1[2 * u + 3]);
-        } else if (slot == 3 || slot == 5) {
-            *reinterpret_cast<uint2*>(base + SP_PLANE_B + u * 2048) = make_uint2(t.p2[2 * u], t.p2[2 * u + 1]);
-            *reinterpret_cast<uint2*>(base + SP_PLANE_B + (u + 1) * 2048) = make_uint2(t.p2[2 * u + 2], t.p2[2 * u + 3]);
-            *reinterpret_cast<uint2*>(base + 2 * SP_PLANE_B + u * 2048) = make_uint2(t.p3[2 * u], t.p3[2 * u + 1]);
-            *reinterpret_cast<uint2*>(base + 2 * SP_PLANE_B + (u + 1) * 2048) = make_uint2(t.p3[2 * u + 2], t.p3[2 * u + 3]);
-        }
-    } else if (slot >= 2) {
-        const int u = slot - 2;
+        const int u = n == 3 ? 0 : 2;
+        *reinterpret_cast<uint2*>(base + u * 2048) = make_uint2(t.p1[2 * u], t.p1[2 * u + 1]);
+        *reinterpret_cast<uint2*>(base + (u + 1) * 2048) = make_uint2(t.p1[2 * u + 2], t.p1[2 * u + 3]);
+    }
+}
+template <bool T>
+__device__ __forceinline__ void pipe_store2(char* base, const PipeTmp& t, int n) {
+    if (!T) {
+        if (n != 3 && n != 7) return;
+        const int u = n == 3 ? 0 : 2;
+        *reinterpret_cast<uint2*>(base + SP_PLANE_B + u * 2048) = make_uint2(t.p2[2 * u], t.p2[2 * u + 1]);
+        *reinterpret_cast<uint2*>(base + SP_PLANE_B + (u + 1) * 2048) = make_uint2(t.p2[2 * u + 2], t.p2[2 * u + 3]);
+        *reinterpret_cast<uint2*>(base + 2 * SP_PLANE_B + u * 2048) = make_uint2(t.p3[2 * u], t.p3[2 * u + 1]);
+        *reinterpret_cast<uint2*>(base + 2 * SP_PLANE_B + (u + 1) * 2048) = make_uint2(t.p3[2 * u + 2], t.p3[2 * u + 3]);
+    } else if (n >= 4) {
+        const int u = n - 4;
         *reinterpret_cast<uint2*>(base + u * SP_ROW_B) = make_uint2(t.p1[2 * u], t.p1[2 * u + 1]);
         *reinterpret_cast<uint2*>(base + u * SP_ROW_B + SP_PLANE_B) = make_uint2(t.p2[2 * u], t.p2[2 * u + 1]);
         *reinterpret_cast<uint2*>(base + u * SP_ROW_B + 2 * SP_PLANE_B) = make_uint2(t.p3[2 * u], t.p3[2 * u + 1]);
@@ -397,20 +437,100 @@ __device__ __forceinline__ void pipe_store(char* base, const PipeTmp& t, int slo
 #define PP_MFMA(F, i, j, pa, pb) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F##a[i][pa], F##b[j][pb], acc[i][j], 0, 0, 0);
 #define PP_RDA(F, ks, i, pl, STG) F##a[i][pl] = *reinterpret_cast<const bf16x8*>(lds + ((STG) * PP_STAGE_B + (pl) * SP_PLANE_B) + ra[ks][i]);
 #define PP_RDB(F, ks, j, pl, STG) F##b[j][pl] = *reinterpret_cast<const bf16x8*>(lds + ((STG) * PP_STAGE_B + (pl) * SP_PLANE_B) + rb[ks][j]);
-#define PP_S1A(O, j) { tmp.hx[j] = pipe_x<T##O>(R##O, j) & PP_MASK; tmp.hy[j] = pipe_y<T##O>(R##O, j) & PP_MASK; }
-#define PP_S1B(O, j) { const unsigned ux = pipe_x<T##O>(R##O, j), uy = pipe_y<T##O>(R##O, j);                                  \
+#define PP_S1A(O, n) { constexpr int j = pipe_pair<T##O>(n); tmp.hx[j] = pipe_x<T##O>(R##O[PP_SET], j) & PP_MASK; tmp.hy[j] = pipe_y<T##O>(R##O[PP_SET], j) & PP_MASK; }
+#define PP_S1B(O, n) { constexpr int j = pipe_pair<T##O>(n); const unsigned ux = pipe_x<T##O>(R##O[PP_SET], j), uy = pipe_y<T##O>(R##O[PP_SET], j);   \
         tmp.rx[j] = __uint_as_float(ux) - __uint_as_float(tmp.hx[j]); tmp.ry[j] = __uint_as_float(uy) - __uint_as_float(tmp.hy[j]); \
         tmp.p1[j] = __builtin_amdgcn_perm(uy, ux, PP_SEL); }
-#define PP_S2A(O, j) { const unsigned vx = __float_as_uint(tmp.rx[j]), vy = __float_as_uint(tmp.ry[j]);                           \
+#define PP_S2A(O, n) { constexpr int j = pipe_pair<T##O>(n); const unsigned vx = __float_as_uint(tmp.rx[j]), vy = __float_as_uint(tmp.ry[j]); \
         tmp.hx[j] = vx & PP_MASK; tmp.hy[j] = vy & PP_MASK; tmp.p2[j] = __builtin_amdgcn_perm(vy, vx, PP_SEL); }
-#define PP_S2B(O, j) { const float sx = tmp.rx[j] - __uint_as_float(tmp.hx[j]), sy = tmp.ry[j] - __uint_as_float(tmp.hy[j]);      \
+#define PP_S2B(O, n) { constexpr int j = pipe_pair<T##O>(n);                                                                      \
+        const float sx = tmp.rx[j] - __uint_as_float(tmp.hx[j]), sy = tmp.ry[j] - __uint_as_float(tmp.hy[j]);                     \
         tmp.p3[j] = __builtin_amdgcn_perm(__float_as_uint(sy), __float_as_uint(sx), PP_SEL); }
-#define PP_LD(O, it) R##O[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc##O[it], voff##O, soff##O, 0);
+#define PP_LD(O, it) R##O[PP_SET][it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc##O[it], voff##O, soff##O, 0);
+#define PP_LDS(O, n) { constexpr int it = pipe_load_slot<T##O>(n); if constexpr (it >= 0) { PP_LD(O, it) } }
 #define PP_NEXT(O) soff##O = min(soff##O + step##O, last##O);
 #define PP_OFF_A 0
 #define PP_OFF_B PP_OPERAND_B
-#define PP_ST(O, k) pipe_store<T##O>(lds + (PP_NXT * PP_STAGE_B + PP_OFF_##O) + wa##O, tmp, k);
+#define PP_ST1(O, n) pipe_store1<T##O>(lds + (PP_NXT * PP_STAGE_B + PP_OFF_##O) + wa##O, tmp, n);
+#define PP_ST2(O, n) pipe_store2<T##O>(lds + (PP_NXT * PP_STAGE_B + PP_OFF_##O) + wa##O, tmp, n);
 #define PP_BARRIER __syncthreads();
+
+// Epilogue of the pipelined core.  A lone wave per SIMD has nothing to hide store latency behind, so the number of store instructions
+// counts: the wave's 64x64 block goes through its private slice of the (now idle) LDS - rows of 72 floats: conflict-free ds_write_b32
+// from the MFMA layout, conflict-free ds_read_b128 - and leaves as 16 global_store_dwordx4 per lane (four rows of 256 contiguous
+// bytes each) instead of 64 global_store_dword.  Per-tile overhead (scripts/dbg_gemm_k.py: time per tile = a + b * K blocks):
+// a = 15.7 us with the scalar, per-element-branching epilogue, 9.8 us now (5.3 us without any epilogue), b = 1.29 us.
+// Needs 16-byte aligned rows (leading dimension and N multiples of 4); anything else takes tile_epilogue.
+constexpr int EP_LD = 72;
+template <int ACTK>
+__device__ __forceinline__ void pipe_epilogue_rows(const GemmArgs& p, const float* T, float* out, long ld, const float* bias, int row0, int col,
+                                                   int c4, int rr) {
+    const EpiFlags f = epi_flags(p);
+    float4 v[16];
+#pragma unroll
+    for (int ps = 0; ps < 16; ++ps) v[ps] = *reinterpret_cast<const float4*>(T + (ps * 4 + rr) * EP_LD + 4 * c4);
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) bv = make_float4(bias[col], bias[col + 1], bias[col + 2], bias[col + 3]);
+#pragma unroll
+    for (int ps = 0; ps < 16; ++ps) {
+        const int row = row0 + ps * 4 + rr;
+        if (row >= p.M) continue;
+        float* cp = out + (long)row * ld + col;
+        float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f.beta) c = *reinterpret_cast<const float4*>(cp);
+        uchar4 m = make_uchar4(1, 1, 1, 1);
+        if (f.mask) m = *reinterpret_cast<const uchar4*>(p.mask + (long)row * p.ldmask + col);
+        float4 o;
+        o.x = epi_value<ACTK>(p, f, v[ps].x, bv.x, c.x, m.x);
+        o.y = epi_value<ACTK>(p, f, v[ps].y, bv.y, c.y, m.y);
+        o.z = epi_value<ACTK>(p, f, v[ps].z, bv.z, c.z, m.z);
+        o.w = epi_value<ACTK>(p, f, v[ps].w, bv.w, c.w, m.w);
+        *reinterpret_cast<float4*>(cp) = o;
+    }
+}
+
+__device__ __forceinline__ void pipe_epilogue(const GemmArgs& p, const f32x16 (&acc)[2][2], float* lds_f, float* g_ws, float* C,
+                                              const float* bias, int z, int row0, int col0, int lane, int wave) {
+    const bool raw = gridDim.y > 1;
+    float* out = raw ? g_ws + ((long)z * gridDim.y + blockIdx.y) * (long)p.M * p.N : C;
+    const long ld = raw ? p.N : p.ldc;
+    const bool vec = (ld & 3) == 0 && (p.N & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+                     (raw || !p.mask || ((p.ldmask & 3) == 0 && (reinterpret_cast<uintptr_t>(p.mask) & 3) == 0));
+    if (!vec) {
+        tile_epilogue(p, acc, g_ws, C, bias, z, row0, col0, lane & 31, lane >> 5);
+        return;
+    }
+    __syncthreads();                      // every wave has read its last fragments: the stages may be overwritten
+    float* T = lds_f + wave * (64 * EP_LD);
+    const int li = lane & 31, lq = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lq) * EP_LD + j * 32 + li] = acc[i][j][r];
+    __builtin_amdgcn_wave_barrier();      // same wave, in-order LDS queue: the reads below see the stores above
+    const int c4 = lane & 15, rr = lane >> 4;
+    const int col = col0 + 4 * c4;
+    if (col >= p.N) return;
+    if (raw) {
+#pragma unroll
+        for (int ps = 0; ps < 16; ++ps) {
+            const int rl = ps * 4 + rr;
+            if (row0 + rl < p.M) *reinterpret_cast<float4*>(out + (long)(row0 + rl) * ld + col) = *reinterpret_cast<const float4*>(T + rl * EP_LD + 4 * c4);
+        }
+        return;
+    }
+    MTTS_EPI_DISPATCH(pipe_epilogue_rows, p, T, out, ld, bias, row0, col, c4, rr);
+}
+
+#ifndef MTTS_PIPE_SETS
+#define MTTS_PIPE_SETS 1
+#endif
+#define PP_SET (PP_NXT % MTTS_PIPE_SETS)
+#ifndef MTTS_PIPE_BODY
+#define MTTS_PIPE_BODY "gemm_pipe_body.inc"      // scripts/ab_gemm_stream.sh builds variants of the stream
+#endif
 
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(GemmArgs p, float* g_ws) {
@@ -491,30 +611,39 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(GemmArgs p, float* g_
                 rb[ks][i] = rowb * SP_ROW_B + (((2 * ks + lq) ^ ((rowb >> 2) & 3)) * 16) + PP_OPERAND_B;
             }
 
-        u32x4 RA[4], RB[4];
+        // MTTS_PIPE_SETS register sets per operand.  1 (default): a tile is requested one K block (~1.3 us) before it is split.
+        // 2: tile kb0 + i lives in set i & 1 and is requested two blocks ahead (+32 VGPRs; no gain in isolation, 18 % of the wave
+        // cycles are s_waitcnt either way - they wait on LDS, not on memory).
+        u32x4 RA[MTTS_PIPE_SETS][4], RB[MTTS_PIPE_SETS][4];
         PipeTmp tmp;
         bf16x8 f0a[2][3], f0b[2][3], f1a[2][3], f1b[2][3];
 
-        // prologue: tile kb0 -> stage 0, tile kb0 + 1 in flight, first fragments
-#pragma unroll
-        for (int it = 0; it < 4; ++it) { PP_LD(A, it) PP_LD(B, it) }
-        PP_NEXT(A) PP_NEXT(B)
+        // prologue: tile kb0 -> stage 0, the next MTTS_PIPE_SETS tiles in flight, first fragments
 #define PP_NXT 0
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { PP_S1A(A, j) PP_S1B(A, j) PP_S2A(A, j) PP_S2B(A, j) }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) { PP_ST(A, k) }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { PP_S1A(B, j) PP_S1B(B, j) PP_S2A(B, j) PP_S2B(B, j) }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) { PP_ST(B, k) }
+        for (int it = 0; it < 4; ++it) { PP_LD(A, it) PP_LD(B, it) }
+        PP_NEXT(A) PP_NEXT(B)
 #undef PP_NXT
+#if MTTS_PIPE_SETS == 2
+#define PP_NXT 1
 #pragma unroll
         for (int it = 0; it < 4; ++it) { PP_LD(A, it) PP_LD(B, it) }
         PP_NEXT(A) PP_NEXT(B)
+#undef PP_NXT
+#endif
+#define PP_NXT 0
+#define PP_FILL(O, n) PP_S1A(O, n) PP_S1B(O, n) PP_S2A(O, n) PP_S2B(O, n)
+#define PP_FILL_ALL(O) PP_FILL(O, 0) PP_FILL(O, 1) PP_FILL(O, 2) PP_FILL(O, 3) PP_FILL(O, 4) PP_FILL(O, 5) PP_FILL(O, 6) PP_FILL(O, 7)          \
+        PP_ST1(O, 3) PP_ST1(O, 7) PP_ST2(O, 3) PP_ST2(O, 4) PP_ST2(O, 5) PP_ST2(O, 6) PP_ST2(O, 7)
+        PP_FILL_ALL(A)
+        PP_FILL_ALL(B)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) { PP_LD(A, it) PP_LD(B, it) }
+        PP_NEXT(A) PP_NEXT(B)
+#undef PP_NXT
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)       // every ks=0 fragment of stage 0 (the stream re-reads all but the first four: harmless)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) { PP_RDA(f0, 0, i, pl, 0) PP_RDB(f0, 0, i, pl, 0) }
 
@@ -522,24 +651,30 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(GemmArgs p, float* g_
         for (int n = (nk - kb0) >> 1; n > 0; --n) {
 #define PP_CUR 0
 #define PP_NXT 1
-#include "gemm_pipe_body.inc"
+#include MTTS_PIPE_BODY
 #undef PP_CUR
 #undef PP_NXT
 #define PP_CUR 1
 #define PP_NXT 0
-#include "gemm_pipe_body.inc"
+#include MTTS_PIPE_BODY
 #undef PP_CUR
 #undef PP_NXT
         }
         if ((nk - kb0) & 1) {
 #define PP_CUR 0
 #define PP_NXT 1
-#include "gemm_pipe_body.inc"
+#include MTTS_PIPE_BODY
 #undef PP_CUR
 #undef PP_NXT
         }
     }
+#ifdef MTTS_PIPE_NO_EPILOGUE          // ablation build (scripts/build_gemm_variant.sh): what the epilogue costs per tile
+    if (acc[0][0][0] == 123.456f) C[0] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1];
+#elif defined(MTTS_PIPE_SCALAR_EPILOGUE)
     tile_epilogue(p, acc, g_ws, C, bias, z, m0 + wm, n0 + wn, li, lq);
+#else
+    pipe_epilogue(p, acc, smem, g_ws, C, bias, z, m0 + wm, n0 + wn, lane, wave);
+#endif
 }
 
 template <bool TA, bool TB>
