@@ -446,9 +446,9 @@ __device__ __forceinline__ void pipe_store2(char* base, const PipeTmp& t, int n)
 #define PP_S2B(O, n) { constexpr int j = pipe_pair<T##O>(n);                                                                      \
         const float sx = tmp.rx[j] - __uint_as_float(tmp.hx[j]), sy = tmp.ry[j] - __uint_as_float(tmp.hy[j]);                     \
         tmp.p3[j] = __builtin_amdgcn_perm(__float_as_uint(sy), __float_as_uint(sx), PP_SEL); }
-#define PP_LD(O, it) R##O[PP_SET][it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc##O[it], voff##O, soff##O, 0);
+#define PP_LD(O, it) R##O[PP_SET][it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc##O[it], voff##O[it], soff##O, 0);
 #define PP_LDS(O, n) { constexpr int it = pipe_load_slot<T##O>(n); if constexpr (it >= 0) { PP_LD(O, it) } }
-#define PP_NEXT(O) soff##O = min(soff##O + step##O, last##O);
+#define PP_NEXT(O) next##O();
 #define PP_OFF_A 0
 #define PP_OFF_B PP_OPERAND_B
 #define PP_ST1(O, n) pipe_store1<T##O>(lds + (PP_NXT * PP_STAGE_B + PP_OFF_##O) + wa##O, tmp, n);
@@ -532,7 +532,13 @@ __device__ __forceinline__ void pipe_epilogue(const GemmArgs& p, const f32x16 (&
 #define MTTS_PIPE_BODY "gemm_pipe_body.inc"      // scripts/ab_gemm_stream.sh builds variants of the stream
 #endif
 
-template <bool TA, bool TB>
+// CONV: 0 plain GEMM; the implicit-GEMM forms of a 1-D convolution over channel-last activations (kernels.conv1d_fwd / conv1d_bwd):
+//   1 forward  (shift_mode 1): A = activations, K = (tap, channel); tap t reads row r + shift_t, zero outside the sequence
+//   2 dgrad    (shift_mode 1, transposed weights with a tap stride b_tap)
+//   3 wgrad    (shift_mode 2): both operands transposed, K = activation rows; B's row k is read at k + shift_z, zero outside
+// A K block never straddles two taps (Kc % 32 == 0).  Rows that must read as zero get the offset 0x80000000: beyond every
+// descriptor's num_records, the buffer load returns zeros without touching memory.
+template <bool TA, bool TB, int CONV = 0>
 __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(GemmArgs p, float* g_ws) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* lds = reinterpret_cast<char*>(smem);
@@ -574,28 +580,90 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(GemmArgs p, float* g_
 
     if (kb0 < nk) {
         // ---- global side: descriptor `it` starts at the operand's slab `it` of this tile; a thread's offset inside every slab is
-        // the same, the K position rides in the scalar offset.  Extents are exact, so rows past the end of a K-contiguous operand
-        // read as zero without touching memory; a transposed operand clamps its row group (M % 4 == 0 there).
-        const long extA = TA ? ((long)(p.K - 1) * p.lda + p.M) * 4 : ((long)(p.M - 1) * p.lda + p.K) * 4;
-        const long extB = TB ? ((long)(p.K - 1) * p.ldb + p.N) * 4 : ((long)(p.N - 1) * p.ldb + p.K) * 4;
+        // the same, the K position rides in the scalar offset.  Plain GEMM: extents are exact, so rows past the end of a K-contiguous
+        // operand read as zero without touching memory; a transposed operand clamps its row group (M % 4 == 0 there).
+        constexpr unsigned OOB = 0x80000000u;
+        const bool shiftA = CONV == 1 || CONV == 2, shiftB = CONV == 3;
+        const long extA = shiftA ? 0x7fffffffL : (TA ? ((long)(p.K - 1) * p.lda + p.M) * 4 : ((long)(p.M - 1) * p.lda + p.K) * 4);
+        const long extB = (shiftB || CONV == 2) ? 0x7fffffffL : (TB ? ((long)(p.K - 1) * p.ldb + p.N) * 4 : ((long)(p.N - 1) * p.ldb + p.K) * 4);
+        // shifted operands: the most negative row shift goes into the descriptor base so that the scalar offset stays >= 0
+        const int sh_first = p.shift0, sh_last = p.shift0 + (p.taps - 1) * p.dshift;
+        const int min_sh = shiftA ? min(sh_first, sh_last) : 0;
+        const int shift_z = p.shift0 + ztap * p.dshift;
         __amdgpu_buffer_rsrc_t rsrcA[4], rsrcB[4];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const long sa = (TA ? (long)it * p.lda + m0 : ((long)m0 + it * 32) * p.lda) * 4;
-            const long sb = (TB ? (long)it * p.ldb + n0 : ((long)n0 + it * 32) * p.ldb) * 4;
+            const long sa = (TA ? (long)it * p.lda + m0 : ((long)m0 + it * 32 + min_sh) * p.lda) * 4;
+            const long sb = (TB ? ((long)it + (shiftB ? shift_z : 0)) * p.ldb + n0 : ((long)n0 + it * 32) * p.ldb) * 4;
             rsrcA[it] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(A)) + sa, 0,
-                                                          (int)max(0L, extA - sa), 0x00020000);
+                                                          (int)(shiftA ? extA : max(0L, extA - sa)), 0x00020000);
             rsrcB[it] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(B)) + sb, 0,
-                                                          (int)max(0L, extB - sb), 0x00020000);
+                                                          (int)((shiftB || CONV == 2) ? extB : max(0L, extB - sb)), 0x00020000);
         }
         const int q8 = tid >> 3, k8 = tid & 7;
-        const unsigned voffA = TA ? (unsigned)(((long)(4 * k8) * p.lda + min(4 * q8, max(p.M - m0 - 4, 0))) * 4)
-                                  : (unsigned)(((long)q8 * p.lda + 4 * k8) * 4);
-        const unsigned voffB = TB ? (unsigned)(((long)(4 * k8) * p.ldb + min(4 * q8, max(p.N - n0 - 4, 0))) * 4)
-                                  : (unsigned)(((long)q8 * p.ldb + 4 * k8) * 4);
+        const unsigned voffA0 = TA ? (unsigned)(((long)(4 * k8) * p.lda + min(4 * q8, max(p.M - m0 - 4, 0))) * 4)
+                                   : (unsigned)(((long)q8 * p.lda + 4 * k8) * 4);
+        const unsigned voffB0 = TB ? (unsigned)(((long)(4 * k8) * p.ldb + min(4 * q8, max(p.N - n0 - 4, 0))) * 4)
+                                   : (unsigned)(((long)q8 * p.ldb + 4 * k8) * 4);
+        unsigned voffA[4] = {voffA0, voffA0, voffA0, voffA0}, voffB[4] = {voffB0, voffB0, voffB0, voffB0};
         const unsigned stepA = TA ? (unsigned)p.lda * (BK * 4) : BK * 4, stepB = TB ? (unsigned)p.ldb * (BK * 4) : BK * 4;
         const unsigned lastA = (unsigned)(nk - 1) * stepA, lastB = (unsigned)(nk - 1) * stepB;
         unsigned soffA = (unsigned)kb0 * stepA, soffB = (unsigned)kb0 * stepB;
+
+        // K-position state of the shifted forms
+        const int nbt = CONV == 1 || CONV == 2 ? p.Kc / BK : 1;        // K blocks per tap
+        int cbA = kb0 % nbt, tapA = kb0 / nbt, cbB = cbA, tapB = tapA;   // block inside the tap, tap
+        int leftA = nk - kb0 - 1, leftB = leftA;                         // further blocks the load stream may advance to
+        int lA[4];                                                       // CONV 1, 2: sequence position of the thread's rows
+        unsigned l0B = 0;                                                // CONV 3: sequence position of the thread's first k row
+        auto set_voffA = [&](int sh) {                                   // rows whose shifted source lies outside the sequence read zero
+#pragma unroll
+            for (int it = 0; it < 4; ++it) voffA[it] = (unsigned)(lA[it] + sh) < (unsigned)p.seq_len ? voffA0 : OOB;
+        };
+        auto set_voffB = [&]() {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const unsigned w = l0B + it, t = min(w, w - (unsigned)p.seq_len);          // (l0B + it) mod seq_len
+                voffB[it] = (t + (unsigned)shift_z) < (unsigned)p.seq_len ? voffB0 : OOB;
+            }
+        };
+        if (shiftA) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int r = m0 + it * 32 + q8;
+                lA[it] = r < p.M ? r % p.seq_len : 0x40000000;
+            }
+            const int sh = p.shift0 + tapA * p.dshift;
+            soffA = (unsigned)(((long)(sh - min_sh) * p.lda + cbA * BK) * 4);
+            set_voffA(sh);
+        }
+        if (CONV == 2) soffB = (unsigned)(((long)cbB * BK * p.ldb + (long)tapB * p.b_tap) * 4);
+        if (shiftB) { l0B = (unsigned)((kb0 * BK + 4 * k8) % p.seq_len); set_voffB(); }
+        auto nextA = [&]() {
+            if (!shiftA) { soffA = min(soffA + stepA, lastA); return; }
+            if (leftA <= 0) return;
+            --leftA;
+            if (++cbA == nbt) {
+                cbA = 0; ++tapA;
+                const int sh = p.shift0 + tapA * p.dshift;
+                soffA = (unsigned)((long)(sh - min_sh) * p.lda * 4);
+                set_voffA(sh);
+            } else soffA += BK * 4;
+        };
+        auto nextB = [&]() {
+            if (CONV == 2) {
+                if (leftB <= 0) return;
+                --leftB;
+                if (++cbB == nbt) { cbB = 0; ++tapB; soffB = (unsigned)((long)tapB * p.b_tap * 4); }
+                else soffB += stepB;
+            } else if (shiftB) {
+                if (leftB <= 0) return;
+                --leftB;
+                soffB += stepB;
+                l0B += BK; l0B = min(l0B, l0B - (unsigned)p.seq_len);          // seq_len >= 32: one wrap at most
+                set_voffB();
+            } else soffB = min(soffB + stepB, lastB);
+        };
 
         // ---- LDS side.  Store address of the thread's first row (pipe_store adds rows / planes); fragment read addresses.
         const int wrA = TA ? 4 * q8 : q8, wrB = TB ? 4 * q8 : q8;
@@ -868,7 +936,8 @@ MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     static bool attr_done = false;
     if (!attr_done) {   // > 64 KiB of dynamic LDS needs the opt-in attribute
-        const void* kernels[12] = {(const void*)gemm_mfma_kernel<false, false>, (const void*)gemm_mfma_kernel<false, true>,
+        const void* kernels[15] = {(const void*)gemm_pipe_kernel<false, false, 1>, (const void*)gemm_pipe_kernel<false, true, 2>,
+                                   (const void*)gemm_pipe_kernel<true, true, 3>,(const void*)gemm_mfma_kernel<false, false>, (const void*)gemm_mfma_kernel<false, true>,
                                    (const void*)gemm_mfma_kernel<true, false>, (const void*)gemm_mfma_kernel<true, true>,
                                    (const void*)gemm_split_kernel<false, false>, (const void*)gemm_split_kernel<false, true>,
                                    (const void*)gemm_split_kernel<true, false>, (const void*)gemm_split_kernel<true, true>,
@@ -883,13 +952,23 @@ MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
     const auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     const long ext_a = p.transA ? ((long)(p.K - 1) * p.lda + p.M) : ((long)(p.M - 1) * p.lda + p.K);
     const long ext_b = p.transB ? ((long)(p.K - 1) * p.ldb + p.N) : ((long)(p.N - 1) * p.ldb + p.K);
-    const bool pipe = pipe_on && !exact_f32 && p.precision != 1 && p.shift_mode == 0 && p.taps == 1 && p.K >= BK && p.K % BK == 0 &&
-                      (p.lda & 3) == 0 && (p.ldb & 3) == 0 && (p.a_z & 3) == 0 && (p.b_z & 3) == 0 && aligned16(p.A) && aligned16(p.B) &&
-                      p.lda >= (p.transA ? p.M : p.K) && p.ldb >= (p.transB ? p.N : p.K) && (!p.transA || (p.M & 3) == 0) &&
-                      (!p.transB || (p.N & 3) == 0) && ext_a < (1L << 29) && ext_b < (1L << 29);
-    if (pipe) {
+    const bool pipe_common = pipe_on && !exact_f32 && p.precision != 1 && p.K >= BK && p.K % BK == 0 && (p.lda & 3) == 0 && (p.ldb & 3) == 0 &&
+                             (p.a_z & 3) == 0 && (p.b_z & 3) == 0 && aligned16(p.A) && aligned16(p.B) && (!p.transA || (p.M & 3) == 0) &&
+                             (!p.transB || (p.N & 3) == 0) && ext_a < (1L << 29) && ext_b < (1L << 29);
+    // 0: plain, 1-3: the convolution forms (see gemm_pipe_kernel), -1: not a shape of the pipelined core
+    int pipe = -1;
+    if (pipe_common) {
+        if (p.shift_mode == 0 && p.taps == 1 && p.lda >= (p.transA ? p.M : p.K) && p.ldb >= (p.transB ? p.N : p.K)) pipe = 0;
+        else if (p.shift_mode == 1 && !p.transA && p.Kc % BK == 0 && !p.transB) pipe = 1;
+        else if (p.shift_mode == 1 && !p.transA && p.Kc % BK == 0 && p.transB && (p.b_tap & 3) == 0) pipe = 2;
+        else if (p.shift_mode == 2 && p.transA && p.transB && p.taps == 1 && p.seq_len >= BK) pipe = 3;
+    }
+    if (pipe >= 0) {
         const size_t ldsp = 2 * PP_OPERAND_B;
-        if (!p.transA && !p.transB) hipLaunchKernelGGL((gemm_pipe_kernel<false, false>), grid, dim3(256), ldsp, s, p, ws);
+        if (pipe == 1) hipLaunchKernelGGL((gemm_pipe_kernel<false, false, 1>), grid, dim3(256), ldsp, s, p, ws);
+        else if (pipe == 2) hipLaunchKernelGGL((gemm_pipe_kernel<false, true, 2>), grid, dim3(256), ldsp, s, p, ws);
+        else if (pipe == 3) hipLaunchKernelGGL((gemm_pipe_kernel<true, true, 3>), grid, dim3(256), ldsp, s, p, ws);
+        else if (!p.transA && !p.transB) hipLaunchKernelGGL((gemm_pipe_kernel<false, false>), grid, dim3(256), ldsp, s, p, ws);
         else if (!p.transA && p.transB) hipLaunchKernelGGL((gemm_pipe_kernel<false, true>), grid, dim3(256), ldsp, s, p, ws);
         else if (p.transA && !p.transB) hipLaunchKernelGGL((gemm_pipe_kernel<true, false>), grid, dim3(256), ldsp, s, p, ws);
         else hipLaunchKernelGGL((gemm_pipe_kernel<true, true>), grid, dim3(256), ldsp, s, p, ws);

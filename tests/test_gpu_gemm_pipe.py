@@ -1,7 +1,7 @@
 """Software-pipelined GEMM core (gemm_pipe_kernel, csrc/gemm.hip): plain fp32 GEMMs with whole 32-wide K blocks run on it by default.
 It must (a) stay at fp32-accumulation error against fp64 on every storage variant, ragged M / N, split-K and batched launches and
-every epilogue, and (b) return the SAME BITS as gemm_split_kernel (same products, same accumulation order), which a child process
-with MTTS_GEMM_PIPE=0 computes."""
+every epilogue, for plain products and for the three implicit-GEMM forms of a convolution, and (b) return the SAME BITS as
+gemm_split_kernel (same products, same accumulation order), which a child process with MTTS_GEMM_PIPE=0 computes."""
 import os
 import subprocess
 import sys
@@ -74,15 +74,52 @@ def test_pipelined_core_epilogue_and_batch():
     assert (Cb.double() - refb).abs().max().item() <= 1e-4 * refb.abs().max().item()
 
 
+# (groups, Cg, Og, k, dilation, N, L): channel counts multiples of 32 and N * L a multiple of 32 put the forward, input-gradient and
+# weight-gradient GEMMs of a convolution on the pipelined core (CONV 1, 2, 3); L < 32 keeps the weight gradient on the old core
+CONV_CASES = [(1, 64, 96, 5, 1, 4, 40), (2, 32, 64, 3, 3, 2, 48), (1, 128, 32, 4, 1, 3, 32), (1, 64, 64, 31, 1, 2, 64),
+              (5, 32, 32, 5, 1, 1, 96), (1, 32, 32, 5, 1, 8, 20), (1, 512, 512, 5, 1, 2, 80)]
+
+
+def _conv_case(case, seed):
+    from multilingual_text_to_speech_amd import kernels as Kn
+    groups, Cg, Og, k, dil, N_, L = case
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N_, L, Cg * groups, generator=g).cuda()
+    w = (torch.randn(Og * groups, Cg, k, generator=g) / (Cg * k) ** 0.5).cuda()
+    dy = torch.randn(N_, L, Og * groups, generator=g).cuda()
+    wp = Kn.pack_conv_weight(w)
+    y = Kn.conv1d_fwd(x, wp, k, dil, groups)
+    dx, dwp = Kn.conv1d_bwd(x, wp, dy, k, dil, groups)
+    return x, w, dy, y, dx, Kn.unpack_conv_weight(dwp, Og * groups, Cg, k)
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_pipelined_core_convolutions_match_torch(case):
+    groups, Cg, Og, k, dil, N_, L = case
+    x, w, dy, y, dx, dw = _conv_case(case, 7)
+    xr = x.double().transpose(1, 2).requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    pl = (k - 1) * dil // 2
+    yr = torch.nn.functional.conv1d(torch.nn.functional.pad(xr, (pl, (k - 1) * dil - pl)), wr, dilation=dil, groups=groups)
+    yr.backward(dy.double().transpose(1, 2))
+    tol = lambda ref: 2e-5 * max(1.0, ref.abs().max().item())
+    assert (y.double() - yr.transpose(1, 2)).abs().max().item() <= tol(yr), case
+    assert (dx.double() - xr.grad.transpose(1, 2)).abs().max().item() <= tol(xr.grad), case
+    assert (dw.double() - wr.grad).abs().max().item() <= tol(wr.grad) * (N_ * L) ** 0.5, case
+
+
 _CHILD = r'''
 import sys, torch
 sys.path.insert(0, %(root)r)
-from tests.test_gpu_gemm_pipe import SHAPES, _run, _transposable
+from tests.test_gpu_gemm_pipe import SHAPES, CONV_CASES, _run, _transposable, _conv_case
 out = {}
 for shape in SHAPES:
     for variant in ('nt', 'nn', 'tt', 'tn'):
         if _transposable(shape[0], shape[1], variant):
             out[(shape, variant)] = _run(*shape, variant, seed=23)[2].cpu()
+for case in CONV_CASES:
+    for name, t in zip(('y', 'dx', 'dw'), _conv_case(case, 29)[3:]):
+        out[(case, name)] = t.cpu()
 torch.save(out, sys.argv[1])
 '''
 
@@ -95,6 +132,6 @@ def test_pipelined_core_returns_the_bits_of_the_phase_alternating_core(tmp_path)
         r = subprocess.run([sys.executable, '-c', _CHILD % {'root': ROOT}, path], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         outs[mode] = torch.load(path)
-    assert outs['1'].keys() == outs['0'].keys() and len(outs['1']) >= 20
+    assert outs['1'].keys() == outs['0'].keys() and len(outs['1']) >= 40
     for key, c in outs['1'].items():
         assert torch.equal(c, outs['0'][key]), f'{key}: pipelined and phase-alternating cores differ'
