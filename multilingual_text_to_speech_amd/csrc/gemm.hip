@@ -913,7 +913,8 @@ MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
         const int nkb = cdiv(p.K, BK);
         if (g_ws_host && tiles < 512 && nkb >= 32) {
             static const long helper_target = [] { const char* e = getenv("MTTS_HELPER_SPLIT_TARGET"); const long v = e ? atol(e) : 0; return v > 0 ? v : 512L; }();
-            const long target = region == 0 ? 1024 : helper_target;        // helper streams: fill the chip twice over
+            static const long main_target = [] { const char* e = getenv("MTTS_MAIN_SPLIT_TARGET"); const long v = e ? atol(e) : 0; return v > 0 ? v : 1024L; }();
+            const long target = region == 0 ? main_target : helper_target;
             S = (int)((target + tiles - 1) / tiles);
             if (S > nkb / 16) S = nkb / 16;
             if (S > 32) S = 32;
