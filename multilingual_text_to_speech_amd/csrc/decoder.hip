@@ -38,6 +38,10 @@ static SkSeg seg_h(const float* rowmajor, const float* packed, int t, int B, int
 // Chain B of the fast schedule for steps [c0, c1): generator-LSTM input gates (batched), the recurrent steps and the
 // frame/stop projection (batched).  Runs on its own low-priority stream behind chain A (see side_stream()).
 static bool gen_uses_lstep(const DecoderArgs& a) {
+    // MTTS_GEN_SKINNY=1 (experiment): the generator LSTM's recurrent step as ONE launch of the round-1 kernel (16 gate columns per
+    // workgroup over the whole K = H, fused cell) instead of the K-split gate GEMM + cell kernel pair
+    static const bool skinny = [] { const char* e = getenv("MTTS_GEN_SKINNY"); return e && e[0] == '1'; }();
+    if (skinny) return false;
     return a.fast && a.gen_w2p && a.gen_bias_u && a.gen_w_ih_u && a.gate_part_gen && (a.H & 31) == 0;
 }
 
