@@ -580,6 +580,7 @@ typedef struct TacoLossArgs {
     float g;                   /* guided attention tolerance */
     float pos_weight;          /* 100 in the reference */
     float gscale;              /* upstream gradient of the total loss (1 for loss.backward()) */
+    const float* post_target;  /* [B,M,T] target of the post-net output when it differs from `target` (NULL: the same tensor) */
 } TacoLossArgs;
 
 int mtts_tacotron_loss(const TacoLossArgs* args, void* stream);

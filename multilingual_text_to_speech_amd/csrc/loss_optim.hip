@@ -25,7 +25,7 @@ __global__ __launch_bounds__(LT) void loss_kernel(TacoLossArgs p, float* __restr
     const float inv_nm = 1.f / (float)nm;
     for (long i = i0; i < nm; i += stride) {
         const float t = p.target[i];
-        const float d1 = p.pre[i] - t, d2 = p.post[i] - t;
+        const float d1 = p.pre[i] - t, d2 = p.post[i] - (p.post_target ? p.post_target[i] : t);
         s_pre += d1 * d1; s_post += d2 * d2;
         p.d_pre[i] = 4.f * d1 * inv_nm * p.gscale;            // d(2*mean)
         p.d_post[i] = 2.f * d2 * inv_nm * p.gscale;

@@ -1,6 +1,5 @@
 """Adversarial speaker classifier with gradient reversal; reference modules/classifier.py:6-69."""
 import torch
-from torch.nn import functional as F
 from torch.nn import Sequential, Linear, Module
 
 from .. import kernels as K
@@ -35,12 +34,5 @@ class ReversalClassifier(Module):
     @staticmethod
     def loss(input_lengths, speakers, prediction, embeddings=None):
         """Cross entropy over valid characters (padding -> ignore_index); reference modules/classifier.py:62-69."""
-        if prediction.is_cuda:       # value + gradient in one HIP kernel
-            from ..optim import MaskedCrossEntropyFn
-            return MaskedCrossEntropyFn.apply(prediction, speakers, input_lengths, 1.0)
-        ignore_index = -100
-        ml = torch.max(input_lengths)
-        input_mask = torch.arange(ml, device=input_lengths.device)[None, :] < input_lengths[:, None]
-        target = speakers.repeat(ml, 1).transpose(0, 1).clone()
-        target[~input_mask] = ignore_index
-        return F.cross_entropy(prediction.transpose(1, 2), target, ignore_index=ignore_index)
+        from ..optim import MaskedCrossEntropyFn       # value + gradient in one HIP kernel (mtts_masked_cross_entropy); GPU tensors only
+        return MaskedCrossEntropyFn.apply(prediction, speakers, input_lengths, 1.0)

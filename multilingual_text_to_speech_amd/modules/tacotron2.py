@@ -7,7 +7,6 @@ arithmetic is dispatched to libmtts_hip; there is no CPU execution path.
 import os
 
 import torch
-from torch.nn import functional as F
 from torch.nn import Sequential, ModuleList, Linear, Embedding, Module
 
 from .. import kernels as K
@@ -314,46 +313,21 @@ class TacotronLoss(Module):
         self._g *= self._gamma
         self._g_steps = max(0, self._g_steps - 1)
 
-    def _guided_attention(self, alignments, input_lengths, target_lengths):
-        """Same weights as tacotron2.py:443-457, built for the whole batch at once (no per-sample Python loop)."""
-        if self._g_steps == 0:
-            return 0
-        dev = alignments.device
-        B, T, L = alignments.shape
-        f = target_lengths.to(dev).float().view(B, 1, 1)
-        l = input_lengths.to(dev).float().view(B, 1, 1)
-        gf = torch.arange(T, dtype=torch.float, device=dev).view(1, T, 1)
-        gl = torch.arange(L, dtype=torch.float, device=dev).view(1, 1, L)
-        weights = 1 - torch.exp(-(gl / l - gf / f) ** 2 / (2 * self._g ** 2))
-        weights = weights * (gf < f) * (gl < l)
-        loss = torch.sum(weights * alignments, dim=(1, 2))
-        return torch.mean(loss / target_lengths.to(dev).float())
-
     def forward(self, source_length, target_length, pre_prediction, pre_target, post_prediction, post_target, stop, target_stop,
                 alignment, speaker, speaker_prediction, encoder_outputs, classifier):
         pre_target.requires_grad = False
         post_target.requires_grad = False
         target_stop.requires_grad = False
-        if pre_prediction.is_cuda and pre_target is post_target:
-            # fused HIP path: all four terms and their gradients in one pass (mtts_tacotron_loss)
-            from ..optim import TacotronLossFn
-            ga_on = bool(hp.guided_attention_loss) and self._g_steps > 0
-            v = TacotronLossFn.apply(pre_prediction, post_prediction, stop, alignment if hp.guided_attention_loss else None,
-                                     pre_target, target_stop, source_length, target_length, self._g, ga_on, 100.0)
-            losses = {'mel_pre': v[0], 'mel_pos': v[1], 'stop_token': v[2]}
-            total = v[4]
-            if hp.guided_attention_loss:
-                losses['guided_att'] = v[3] if ga_on else 0
-        else:
-            stop_balance = torch.tensor([100], device=stop.device, dtype=torch.float32)
-            losses = {
-                'mel_pre': 2 * F.mse_loss(pre_prediction, pre_target),
-                'mel_pos': F.mse_loss(post_prediction, post_target),
-                'stop_token': F.binary_cross_entropy_with_logits(stop, target_stop, pos_weight=stop_balance) / (hp.num_mels + 2),
-            }
-            if hp.guided_attention_loss:
-                losses['guided_att'] = self._guided_attention(alignment, source_length, target_length)
-            total = sum(losses.values())
+        # all four terms and their gradients in one pass of the library's loss kernel (mtts_tacotron_loss); no torch fallback
+        from ..optim import TacotronLossFn
+        ga_on = bool(hp.guided_attention_loss) and self._g_steps > 0
+        v = TacotronLossFn.apply(pre_prediction, post_prediction, stop, alignment if hp.guided_attention_loss else None,
+                                 pre_target, target_stop, source_length, target_length, self._g, ga_on, 100.0,
+                                 None if post_target is pre_target else post_target)
+        losses = {'mel_pre': v[0], 'mel_pos': v[1], 'stop_token': v[2]}
+        total = v[4]
+        if hp.guided_attention_loss:
+            losses['guided_att'] = v[3] if ga_on else 0
         if hp.reversal_classifier:
             losses['lang_class'] = ReversalClassifier.loss(source_length, speaker, speaker_prediction) * \
                 (hp.reversal_classifier_w / (hp.num_mels + 2))

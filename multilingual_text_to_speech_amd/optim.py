@@ -13,9 +13,10 @@ class TacotronLossFn(torch.autograd.Function):
     (reference modules/tacotron2.py:443-485).  Returns the five-vector (mel_pre, mel_pos, stop_token, guided_att, total)."""
 
     @staticmethod
-    def forward(ctx, pre, post, stop, align, target, stop_target, text_len, target_len, g, ga_on, pos_weight):
+    def forward(ctx, pre, post, stop, align, target, stop_target, text_len, target_len, g, ga_on, pos_weight, post_target=None):
         require_gpu(pre, post, stop, target)
         pre, post, stop, target, stop_target = (t.contiguous() for t in (pre, post, stop, target, stop_target))
+        post_target = None if post_target is None or post_target is target else post_target.contiguous()
         align = align.contiguous() if align is not None else None
         B, M, T = pre.shape
         dev = pre.device
@@ -28,6 +29,7 @@ class TacotronLossFn(torch.autograd.Function):
         tl = text_len.to(device=dev, dtype=torch.int32).contiguous()
         fl = target_len.to(device=dev, dtype=torch.int32).contiguous()
         a.pre, a.post, a.target, a.stop, a.stop_target, a.align = ptr(pre), ptr(post), ptr(target), ptr(stop), ptr(stop_target), ptr(align)
+        a.post_target = ptr(post_target)
         a.text_len, a.target_len = ptr(tl), ptr(fl)
         a.d_pre, a.d_post, a.d_stop, a.d_align, a.partials, a.out = ptr(d_pre), ptr(d_post), ptr(d_stop), ptr(d_align), ptr(partials), ptr(out)
         a.B, a.M, a.T, a.L, a.nblk = B, M, T, (align.shape[2] if align is not None else 0), nblk
@@ -42,7 +44,7 @@ class TacotronLossFn(torch.autograd.Function):
         # d(total)/d(x): every term enters `total` with weight 1, so the upstream scale is dout[4] plus the per-term entries
         s = dout[4]
         return ((dout[0] + s) * d_pre, (dout[1] + s) * d_post, (dout[2] + s) * d_stop,
-                None if d_align is None else (dout[3] + s) * d_align, None, None, None, None, None, None, None)
+                None if d_align is None else (dout[3] + s) * d_align, None, None, None, None, None, None, None, None)
 
 
 class MaskedCrossEntropyFn(torch.autograd.Function):

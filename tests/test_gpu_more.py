@@ -280,6 +280,18 @@ def test_fused_loss_and_adam_match_torch():
         assert abs(a.item() - b.item()) <= 1e-5 * max(1.0, abs(b.item()))
     for a, x in zip(got, (pre, post, stop, align)):
         assert (a - x.grad).abs().max().item() <= 1e-6 + 1e-4 * x.grad.abs().max().item()
+    # a post-net target that is not the decoder's target (TacotronLoss.forward takes both; the reference passes the same tensor)
+    for x in (pre, post, stop, align):
+        x.grad = None
+    tgt2 = torch.randn(B, M, T, generator=g).cuda()
+    v2 = TacotronLossFn.apply(pre, post, stop, align, tgt, st, tl, fl, 0.25, True, 100.0, tgt2)
+    v2[4].backward()
+    got_post = post.grad.clone()
+    post.grad = None
+    ref_pos = F.mse_loss(post, tgt2)
+    ref_pos.backward()
+    assert abs(v2[1].item() - ref_pos.item()) <= 1e-5 * max(1.0, abs(ref_pos.item())) and abs(v2[0].item() - ref_terms[0].item()) <= 1e-5
+    assert (got_post - post.grad).abs().max().item() <= 1e-6 + 1e-4 * post.grad.abs().max().item()
 
     torch.manual_seed(0)
     ps = [torch.randn(300, 70).cuda(), torch.randn(5).cuda(), torch.randn(70000).cuda()]
