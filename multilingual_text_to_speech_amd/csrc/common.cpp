@@ -81,11 +81,17 @@ StreamCtx* ctx_locked(hipStream_t s) {
     return c;
 }
 
-hipStream_t low_priority_stream() {
+// which: 0 = side stream (generator chain), 1 = weight-gradient stream.  MTTS_SIDE_PRIO / MTTS_WGRAD_PRIO = "hi" | "mid" override the
+// least priority both get by default (tuning knob, scripts/ab_multi.sh).
+hipStream_t low_priority_stream(int which) {
     int lo = 0, hi = 0;
-    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = 0;          // lo = least priority
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;      // lo = least priority (numerically largest)
+    int prio = lo;
+    const char* e = getenv(which == 0 ? "MTTS_SIDE_PRIO" : "MTTS_WGRAD_PRIO");
+    if (e && e[0] == 'h') prio = hi;
+    else if (e && e[0] == 'm') prio = (lo + hi) / 2;
     hipStream_t st = nullptr;
-    if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, lo) != hipSuccess) st = nullptr;
+    if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio) != hipSuccess) st = nullptr;
     return st;
 }
 }  // namespace
@@ -94,7 +100,7 @@ hipStream_t low_priority_stream() {
 hipStream_t side_stream(hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_mu);
     StreamCtx* c = ctx_locked(s);
-    if (!c->side) c->side = low_priority_stream();
+    if (!c->side) c->side = low_priority_stream(0);
     return c->side;
 }
 
@@ -102,7 +108,7 @@ hipStream_t side_stream(hipStream_t s) {
 hipStream_t wgrad_stream(hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_mu);
     StreamCtx* c = ctx_locked(s);
-    if (!c->wgrad) c->wgrad = low_priority_stream();
+    if (!c->wgrad) c->wgrad = low_priority_stream(1);
     return c->wgrad;
 }
 
