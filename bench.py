@@ -30,6 +30,7 @@ import os
 import sys
 import time
 
+os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')      # kernel arguments in device memory: -2 % per train step (read when the HIP runtime loads, i.e. before torch)
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

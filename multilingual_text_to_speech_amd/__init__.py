@@ -3,7 +3,11 @@
     import multilingual_text_to_speech_amd as mtts
     mtts.install_aliases()            # optional: `from modules.tacotron2 import Tacotron`, `from params.params import Params`
 """
+import os
 import sys
+
+# The HIP runtime reads this flag when it is loaded (with torch): it only takes effect if the package is imported before torch.
+os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
 
 __version__ = "0.1.0"
 

@@ -9,8 +9,10 @@ Griffin-Lim vocoding need packages outside the hot path, so with hp.use_phonemes
 `de` | `de-10,fr-9,de` (code switching by character counts) | `fr*0.75:de*0.25` (blend).
 """
 import argparse
+import os
 import sys
 
+os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')      # kernel arguments in device memory: -2 % per train step (read when the HIP runtime loads, i.e. before torch)
 import numpy as np
 import torch
 

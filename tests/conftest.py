@@ -1,6 +1,7 @@
 import os
 import sys
 
+os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')      # kernel arguments in device memory: -2 % per train step (read when the HIP runtime loads, i.e. before torch)
 import pytest
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))

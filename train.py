@@ -16,6 +16,7 @@ import math
 import os
 import time
 
+os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')      # kernel arguments in device memory: -2 % per train step (read when the HIP runtime loads, i.e. before torch)
 import torch
 
 from bench import synthetic_batch, train_step
