@@ -462,17 +462,17 @@ __device__ __forceinline__ void pipe_store2(char* base, const PipeTmp& t, int n)
 // a = 15.7 us with the scalar, per-element-branching epilogue, 9.8 us now (5.3 us without any epilogue), b = 1.29 us.
 // Needs 16-byte aligned rows (leading dimension and N multiples of 4); anything else takes tile_epilogue.
 constexpr int EP_LD = 72;
-template <int ACTK>
-__device__ __forceinline__ void pipe_epilogue_rows(const GemmArgs& p, const float* T, float* out, long ld, const float* bias, int row0, int col,
-                                                   int c4, int rr) {
+template <int ACTK, int NPS>
+__device__ __forceinline__ void pipe_rows_impl(const GemmArgs& p, const float* T, float* out, long ld, const float* bias, int row0, int col,
+                                               int c4, int rr) {
     const EpiFlags f = epi_flags(p);
-    float4 v[16];
+    float4 v[NPS];
 #pragma unroll
-    for (int ps = 0; ps < 16; ++ps) v[ps] = *reinterpret_cast<const float4*>(T + (ps * 4 + rr) * EP_LD + 4 * c4);
+    for (int ps = 0; ps < NPS; ++ps) v[ps] = *reinterpret_cast<const float4*>(T + (ps * 4 + rr) * EP_LD + 4 * c4);
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (bias) bv = make_float4(bias[col], bias[col + 1], bias[col + 2], bias[col + 3]);
 #pragma unroll
-    for (int ps = 0; ps < 16; ++ps) {
+    for (int ps = 0; ps < NPS; ++ps) {
         const int row = row0 + ps * 4 + rr;
         if (row >= p.M) continue;
         float* cp = out + (long)row * ld + col;
@@ -487,6 +487,16 @@ __device__ __forceinline__ void pipe_epilogue_rows(const GemmArgs& p, const floa
         o.w = epi_value<ACTK>(p, f, v[ps].w, bv.w, c.w, m.w);
         *reinterpret_cast<float4*>(cp) = o;
     }
+}
+template <int ACTK>
+__device__ __forceinline__ void pipe_epilogue_rows(const GemmArgs& p, const float* T, float* out, long ld, const float* bias, int row0, int col,
+                                                   int c4, int rr) {
+    pipe_rows_impl<ACTK, 16>(p, T, out, ld, bias, row0, col, c4, rr);
+}
+template <int ACTK>
+__device__ __forceinline__ void pipe_epilogue_rows_half(const GemmArgs& p, const float* T, float* out, long ld, const float* bias, int row0,
+                                                        int col, int c4, int rr) {
+    pipe_rows_impl<ACTK, 8>(p, T, out, ld, bias, row0, col, c4, rr);
 }
 
 __device__ __forceinline__ void pipe_epilogue(const GemmArgs& p, const f32x16 (&acc)[2][2], float* lds_f, float* g_ws, float* C,
@@ -745,6 +755,160 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(GemmArgs p, float* g_
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// gemm_pipe_persist_kernel (MTTS_GEMM_PERSIST=1): the same stream as gemm_pipe_kernel, but 256 workgroups walk ALL tiles of a plain
+// GEMM and the load stream runs across tile boundaries: while a tile's last K blocks are multiplied, the next tile's first two
+// blocks are already being fetched and split, so only the epilogue remains of the ~9.5 us a tile costs outside its K loop.
+// The stage of a K block is a compile-time constant of the stream, hence every tile takes an EVEN number of blocks: an odd K range
+// is padded with one block of zeros (descriptors with num_records 0 make every load return 0).  At a tile boundary stage 0 already
+// holds the next tile's first block, so the epilogue transposes through the free stage-1 halves of the LDS image, 32 rows at a time.
+// Plain GEMMs without split-K / grid.z and with a vectorisable epilogue only (host side checks).
+// Status: bit-identical to the other cores (tests/test_gpu_gemm_pipe.py) but NOT faster yet - 10.3 us + 1.35 us per K block per tile
+// against 9.4 + 1.28 (scripts/dbg_gemm_k.py): the tile-switch state spills scalar registers and the branches in the stream cost
+// 5 % of the main loop - hence opt-in.
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_pipe_persist_kernel(GemmArgs p, float* g_ws) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* lds = reinterpret_cast<char*>(smem);
+    const int ntx = (p.N + BN - 1) / BN, nty = (p.M + BM - 1) / BM;
+    const int nt = ntx * nty, G = gridDim.x;
+    const int n_my = (nt - (int)blockIdx.x + G - 1) / G;                 // tiles blockIdx.x, blockIdx.x + G, ...
+    const float* A = p.A; const float* B = p.B;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int li = lane & 31, lq = lane >> 5;
+    const int nkb = p.K / BK, nkb_p = nkb + (nkb & 1);
+    const int q8 = tid >> 3, k8 = tid & 7;
+    auto tile_of = [&](int i, int& m0, int& n0) {
+        int id = blockIdx.x + i * G;
+        const int q = nt / 8, r = nt % 8, xcd = id % 8, idx = id / 8;       // XCD-aware tile order (see gemm_mfma_kernel)
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        m0 = (id / ntx) * BM; n0 = (id % ntx) * BN;
+    };
+    const long extA = TA ? ((long)(p.K - 1) * p.lda + p.M) * 4 : ((long)(p.M - 1) * p.lda + p.K) * 4;
+    const long extB = TB ? ((long)(p.K - 1) * p.ldb + p.N) * 4 : ((long)(p.N - 1) * p.ldb + p.K) * 4;
+    const unsigned stepA = TA ? (unsigned)p.lda * (BK * 4) : BK * 4, stepB = TB ? (unsigned)p.ldb * (BK * 4) : BK * 4;
+
+    // load-stream state per operand: tile ordinal, block inside the (padded) tile, descriptors, offsets
+    __amdgpu_buffer_rsrc_t rsrcA[4], rsrcB[4];
+    unsigned voffA[4], voffB[4], soffA = 0, soffB = 0;
+    int tiA = 0, tiB = 0, blkA = 0, blkB = 0;
+    auto set_tile_A = [&](int i, bool zero) {
+        int m0, n0; tile_of(i, m0, n0);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const long sa = (TA ? (long)it * p.lda + m0 : ((long)m0 + it * 32) * p.lda) * 4;
+            rsrcA[it] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(A)) + sa, 0,
+                                                          zero ? 0 : (int)max(0L, extA - sa), 0x00020000);
+        }
+        const unsigned v = TA ? (unsigned)(((long)(4 * k8) * p.lda + min(4 * q8, max(p.M - m0 - 4, 0))) * 4) : (unsigned)(((long)q8 * p.lda + 4 * k8) * 4);
+        voffA[0] = voffA[1] = voffA[2] = voffA[3] = v;
+    };
+    auto set_tile_B = [&](int i, bool zero) {
+        int m0, n0; tile_of(i, m0, n0);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const long sb = (TB ? (long)it * p.ldb + n0 : ((long)n0 + it * 32) * p.ldb) * 4;
+            rsrcB[it] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(B)) + sb, 0,
+                                                          zero ? 0 : (int)max(0L, extB - sb), 0x00020000);
+        }
+        const unsigned v = TB ? (unsigned)(((long)(4 * k8) * p.ldb + min(4 * q8, max(p.N - n0 - 4, 0))) * 4) : (unsigned)(((long)q8 * p.ldb + 4 * k8) * 4);
+        voffB[0] = voffB[1] = voffB[2] = voffB[3] = v;
+    };
+    auto nextA = [&]() {
+        ++blkA;
+        if (blkA == nkb_p) { blkA = 0; ++tiA; soffA = 0; set_tile_A(min(tiA, n_my - 1), tiA >= n_my); }
+        else if (blkA == nkb) set_tile_A(min(tiA, n_my - 1), true);          // the zero block that makes the count even
+        else soffA += stepA;
+    };
+    auto nextB = [&]() {
+        ++blkB;
+        if (blkB == nkb_p) { blkB = 0; ++tiB; soffB = 0; set_tile_B(min(tiB, n_my - 1), tiB >= n_my); }
+        else if (blkB == nkb) set_tile_B(min(tiB, n_my - 1), true);
+        else soffB += stepB;
+    };
+    set_tile_A(0, false); set_tile_B(0, false);
+
+    const int wrA = TA ? 4 * q8 : q8, wrB = TB ? 4 * q8 : q8;
+    const unsigned waA = wrA * SP_ROW_B + (((k8 >> 1) ^ ((wrA >> 2) & 3)) * 16) + (k8 & 1) * 8;
+    const unsigned waB = wrB * SP_ROW_B + (((k8 >> 1) ^ ((wrB >> 2) & 3)) * 16) + (k8 & 1) * 8;
+    unsigned ra[2][2], rb[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rowa = wm + i * 32 + li, rowb = wn + i * 32 + li;
+            ra[ks][i] = rowa * SP_ROW_B + (((2 * ks + lq) ^ ((rowa >> 2) & 3)) * 16);
+            rb[ks][i] = rowb * SP_ROW_B + (((2 * ks + lq) ^ ((rowb >> 2) & 3)) * 16) + PP_OPERAND_B;
+        }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    u32x4 RA[MTTS_PIPE_SETS][4], RB[MTTS_PIPE_SETS][4];
+    PipeTmp tmp;
+    bf16x8 f0a[2][3], f0b[2][3], f1a[2][3], f1b[2][3];
+
+    // prologue (once per workgroup): block 0 of the first tile -> stage 0, block 1 in flight, first fragments
+#define PP_NXT 0
+#pragma unroll
+    for (int it = 0; it < 4; ++it) { PP_LD(A, it) PP_LD(B, it) }
+    PP_NEXT(A) PP_NEXT(B)
+    PP_FILL_ALL(A)
+    PP_FILL_ALL(B)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) { PP_LD(A, it) PP_LD(B, it) }
+    PP_NEXT(A) PP_NEXT(B)
+#undef PP_NXT
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) { PP_RDA(f0, 0, i, pl, 0) PP_RDB(f0, 0, i, pl, 0) }
+
+    // epilogue scratch of this wave: 32 rows x 72 floats inside the stage-1 half of operand A's (waves 0, 1) or B's (waves 2, 3) image
+    float* T = reinterpret_cast<float*>(lds + (wave < 2 ? PP_STAGE_B : PP_OPERAND_B + PP_STAGE_B) + (wave & 1) * (32 * EP_LD * 4));
+    const int c4 = lane & 15, rr = lane >> 4;
+    for (int ti = 0; ti < n_my; ++ti) {
+        for (int n = nkb_p >> 1; n > 0; --n) {
+#define PP_CUR 0
+#define PP_NXT 1
+#include MTTS_PIPE_BODY
+#undef PP_CUR
+#undef PP_NXT
+#define PP_CUR 1
+#define PP_NXT 0
+#include MTTS_PIPE_BODY
+#undef PP_CUR
+#undef PP_NXT
+        }
+        // stage 1 is free now (every wave passed the last block barrier after its last read of it); stage 0 holds the next tile
+        int m0, n0; tile_of(ti, m0, n0);
+        const int col = n0 + wn + 4 * c4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * lq) * EP_LD + j * 32 + li] = acc[i][j][r];
+            __builtin_amdgcn_wave_barrier();
+            if (col < p.N) MTTS_EPI_DISPATCH(pipe_epilogue_rows_half, p, T, p.C, (long)p.ldc, p.bias, m0 + wm + i * 32, col, c4, rr);
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        __syncthreads();                  // the next block's split stores go into stage 1
+    }
+}
+
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs p, float* g_ws) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -937,7 +1101,9 @@ MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     static bool attr_done = false;
     if (!attr_done) {   // > 64 KiB of dynamic LDS needs the opt-in attribute
-        const void* kernels[15] = {(const void*)gemm_pipe_kernel<false, false, 1>, (const void*)gemm_pipe_kernel<false, true, 2>,
+        const void* kernels[19] = {(const void*)gemm_pipe_persist_kernel<false, false>, (const void*)gemm_pipe_persist_kernel<false, true>,
+                                   (const void*)gemm_pipe_persist_kernel<true, false>, (const void*)gemm_pipe_persist_kernel<true, true>,
+                                   (const void*)gemm_pipe_kernel<false, false, 1>, (const void*)gemm_pipe_kernel<false, true, 2>,
                                    (const void*)gemm_pipe_kernel<true, true, 3>,(const void*)gemm_mfma_kernel<false, false>, (const void*)gemm_mfma_kernel<false, true>,
                                    (const void*)gemm_mfma_kernel<true, false>, (const void*)gemm_mfma_kernel<true, true>,
                                    (const void*)gemm_split_kernel<false, false>, (const void*)gemm_split_kernel<false, true>,
@@ -964,7 +1130,18 @@ MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
         else if (p.shift_mode == 1 && !p.transA && p.Kc % BK == 0 && p.transB && (p.b_tap & 3) == 0) pipe = 2;
         else if (p.shift_mode == 2 && p.transA && p.transB && p.taps == 1 && p.seq_len >= BK) pipe = 3;
     }
-    if (pipe >= 0) {
+    // persistent variant (opt-in, MTTS_GEMM_PERSIST=1): plain GEMMs with more tiles than CUs, no split-K / grid.z, vectorisable epilogue
+    static const bool persist_on = [] { const char* e = getenv("MTTS_GEMM_PERSIST"); return e && e[0] == '1'; }();
+    const bool persist = persist_on && pipe == 0 && S == 1 && p.batch * p.zt == 1 && (long)ntx * nty > 256 && (p.ldc & 3) == 0 && (p.N & 3) == 0 &&
+                         aligned16(p.C) && (!p.mask || ((p.ldmask & 3) == 0 && (reinterpret_cast<uintptr_t>(p.mask) & 3) == 0));
+    if (persist) {
+        const size_t ldsp = 2 * PP_OPERAND_B;
+        const dim3 gp(256);
+        if (!p.transA && !p.transB) hipLaunchKernelGGL((gemm_pipe_persist_kernel<false, false>), gp, dim3(256), ldsp, s, p, ws);
+        else if (!p.transA && p.transB) hipLaunchKernelGGL((gemm_pipe_persist_kernel<false, true>), gp, dim3(256), ldsp, s, p, ws);
+        else if (p.transA && !p.transB) hipLaunchKernelGGL((gemm_pipe_persist_kernel<true, false>), gp, dim3(256), ldsp, s, p, ws);
+        else hipLaunchKernelGGL((gemm_pipe_persist_kernel<true, true>), gp, dim3(256), ldsp, s, p, ws);
+    } else if (pipe >= 0) {
         const size_t ldsp = 2 * PP_OPERAND_B;
         if (pipe == 1) hipLaunchKernelGGL((gemm_pipe_kernel<false, false, 1>), grid, dim3(256), ldsp, s, p, ws);
         else if (pipe == 2) hipLaunchKernelGGL((gemm_pipe_kernel<false, true, 2>), grid, dim3(256), ldsp, s, p, ws);
