@@ -763,9 +763,9 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(GemmArgs p, float* g_
 // is padded with one block of zeros (descriptors with num_records 0 make every load return 0).  At a tile boundary stage 0 already
 // holds the next tile's first block, so the epilogue transposes through the free stage-1 halves of the LDS image, 32 rows at a time.
 // Plain GEMMs without split-K / grid.z and with a vectorisable epilogue only (host side checks).
-// Status: bit-identical to the other cores (tests/test_gpu_gemm_pipe.py) but NOT faster yet - 10.3 us + 1.35 us per K block per tile
-// against 9.4 + 1.28 (scripts/dbg_gemm_k.py): the tile-switch state spills scalar registers and the branches in the stream cost
-// 5 % of the main loop - hence opt-in.
+// Status: bit-identical to the other cores (tests/test_gpu_gemm_pipe.py) but NOT faster yet - 10.1 us + 1.33 us per K block per tile
+// against 9.4 + 1.28 (scripts/dbg_gemm_k.py): the branches in the stream cost ~4 % of the main loop and the two-pass epilogue with
+// its barrier costs what launch + prologue + one-pass epilogue did - hence opt-in.
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256, 2) void gemm_pipe_persist_kernel(GemmArgs p, float* g_ws) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -789,43 +789,43 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_persist_kernel(GemmArgs p, f
     const long extB = TB ? ((long)(p.K - 1) * p.ldb + p.N) * 4 : ((long)(p.N - 1) * p.ldb + p.K) * 4;
     const unsigned stepA = TA ? (unsigned)p.lda * (BK * 4) : BK * 4, stepB = TB ? (unsigned)p.ldb * (BK * 4) : BK * 4;
 
-    // load-stream state per operand: tile ordinal, block inside the (padded) tile, descriptors, offsets
+    // load-stream state per operand: tile ordinal, K blocks until the next event (zero block / tile switch), ONE descriptor whose base
+    // is the tile's first row, per-slab offsets in VGPRs (four descriptors per operand spilled scalar registers), K position in soff
     __amdgpu_buffer_rsrc_t rsrcA[4], rsrcB[4];
     unsigned voffA[4], voffB[4], soffA = 0, soffB = 0;
-    int tiA = 0, tiB = 0, blkA = 0, blkB = 0;
+    int tiA = 0, tiB = 0, cntA = nkb, cntB = nkb;
+    bool padA = (nkb & 1) != 0, padB = padA;
     auto set_tile_A = [&](int i, bool zero) {
         int m0, n0; tile_of(i, m0, n0);
+        const long sa = (TA ? (long)m0 : (long)m0 * p.lda) * 4;
+        rsrcA[0] = rsrcA[1] = rsrcA[2] = rsrcA[3] =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(A)) + sa, 0, zero ? 0 : (int)max(0L, extA - sa), 0x00020000);
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const long sa = (TA ? (long)it * p.lda + m0 : ((long)m0 + it * 32) * p.lda) * 4;
-            rsrcA[it] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(A)) + sa, 0,
-                                                          zero ? 0 : (int)max(0L, extA - sa), 0x00020000);
-        }
-        const unsigned v = TA ? (unsigned)(((long)(4 * k8) * p.lda + min(4 * q8, max(p.M - m0 - 4, 0))) * 4) : (unsigned)(((long)q8 * p.lda + 4 * k8) * 4);
-        voffA[0] = voffA[1] = voffA[2] = voffA[3] = v;
+        for (int it = 0; it < 4; ++it)
+            voffA[it] = TA ? (unsigned)(((long)(4 * k8 + it) * p.lda + min(4 * q8, max(p.M - m0 - 4, 0))) * 4)
+                           : (unsigned)(((long)(q8 + 32 * it) * p.lda + 4 * k8) * 4);
     };
     auto set_tile_B = [&](int i, bool zero) {
         int m0, n0; tile_of(i, m0, n0);
+        const long sb = (TB ? (long)n0 : (long)n0 * p.ldb) * 4;
+        rsrcB[0] = rsrcB[1] = rsrcB[2] = rsrcB[3] =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(B)) + sb, 0, zero ? 0 : (int)max(0L, extB - sb), 0x00020000);
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const long sb = (TB ? (long)it * p.ldb + n0 : ((long)n0 + it * 32) * p.ldb) * 4;
-            rsrcB[it] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(B)) + sb, 0,
-                                                          zero ? 0 : (int)max(0L, extB - sb), 0x00020000);
-        }
-        const unsigned v = TB ? (unsigned)(((long)(4 * k8) * p.ldb + min(4 * q8, max(p.N - n0 - 4, 0))) * 4) : (unsigned)(((long)q8 * p.ldb + 4 * k8) * 4);
-        voffB[0] = voffB[1] = voffB[2] = voffB[3] = v;
+        for (int it = 0; it < 4; ++it)
+            voffB[it] = TB ? (unsigned)(((long)(4 * k8 + it) * p.ldb + min(4 * q8, max(p.N - n0 - 4, 0))) * 4)
+                           : (unsigned)(((long)(q8 + 32 * it) * p.ldb + 4 * k8) * 4);
     };
     auto nextA = [&]() {
-        ++blkA;
-        if (blkA == nkb_p) { blkA = 0; ++tiA; soffA = 0; set_tile_A(min(tiA, n_my - 1), tiA >= n_my); }
-        else if (blkA == nkb) set_tile_A(min(tiA, n_my - 1), true);          // the zero block that makes the count even
-        else soffA += stepA;
+        soffA += stepA;
+        if (--cntA != 0) return;
+        if (padA) { padA = false; cntA = 1; set_tile_A(min(tiA, n_my - 1), true); }          // the zero block that makes the count even
+        else { ++tiA; soffA = 0; cntA = nkb; padA = (nkb & 1) != 0; set_tile_A(min(tiA, n_my - 1), tiA >= n_my); }
     };
     auto nextB = [&]() {
-        ++blkB;
-        if (blkB == nkb_p) { blkB = 0; ++tiB; soffB = 0; set_tile_B(min(tiB, n_my - 1), tiB >= n_my); }
-        else if (blkB == nkb) set_tile_B(min(tiB, n_my - 1), true);
-        else soffB += stepB;
+        soffB += stepB;
+        if (--cntB != 0) return;
+        if (padB) { padB = false; cntB = 1; set_tile_B(min(tiB, n_my - 1), true); }
+        else { ++tiB; soffB = 0; cntB = nkb; padB = (nkb & 1) != 0; set_tile_B(min(tiB, n_my - 1), tiB >= n_my); }
     };
     set_tile_A(0, false); set_tile_B(0, false);
 
