@@ -1,11 +1,15 @@
-// fp32 GEMM for gfx950, two interchangeable cores behind one argument block:
-//   * gemm_split_kernel (default): every fp32 operand element is split EXACTLY into three bf16 values
-//     x = h1 + h2 + h3 (+ < 2^-24 |x|) while its tile is written to LDS, and the product is evaluated on the bf16 matrix
-//     cores as a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1 with fp32 accumulation (v_mfma_f32_32x32x16_bf16).  The dropped
-//     terms are <= 2^-23 |ab|, i.e. below one fp32 rounding of the product; measured error against fp64 is at or below
-//     that of an fp32 fma chain (scripts/mb/mb_gemm_split.hip, tests/test_gpu_more.py).  Six bf16 MFMAs cost 6/16 of
-//     the matrix-pipe cycles of the fp32 MFMA they replace: 150-185 TFLOP/s-equivalent sustained vs 101-112.
-//   * gemm_mfma_kernel (MTTS_GEMM_EXACT_F32=1): v_mfma_f32_32x32x2_f32, exact f32 products, 157 TF peak.
+// fp32 GEMM for gfx950, one argument block, three cores:
+//   * gemm_pipe_kernel (default for whole 32-wide K blocks and 16-byte aligned operands; plain GEMMs and the three implicit-GEMM
+//     forms of a 1-D convolution): every fp32 operand element is split EXACTLY into three bf16 values x = h1 + h2 + h3
+//     (+ < 2^-24 |x|) while its tile is written to LDS, and the product is evaluated on the bf16 matrix cores as
+//     a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1 with fp32 accumulation (v_mfma_f32_32x32x16_bf16).  The dropped terms are
+//     <= 2^-23 |ab|, below one fp32 rounding of the product; measured error against fp64 is at or below that of an fp32 fma
+//     chain (tests/test_gpu_more.py, tests/test_gpu_gemm_pipe.py).  One workgroup per CU runs a software pipeline: split, LDS
+//     stores, global loads and fragment reads of the next tiles are issued in the shadow of the current tile's MFMAs
+//     (generated stream, gemm_pipe_body.inc): 165-192 TFLOP/s-equivalent sustained.
+//   * gemm_split_kernel: the same arithmetic, phase-alternating (MFMA | barrier | split + stores | barrier), for every other
+//     shape and, with one bf16 plane, for the bf16 path: 145-155 TFLOP/s-equivalent with two workgroups per CU.
+//   * gemm_mfma_kernel (MTTS_GEMM_EXACT_F32=1): v_mfma_f32_32x32x2_f32, exact f32 products, 101-112 sustained (157 TF peak).
 //
 //   C[M,N] = epilogue( alpha * sum_k A(m,k) * B(n,k) )
 //
