@@ -299,7 +299,9 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
             k.dgates_out = g.dG_gen + t * B4H; k.ld_dgates = 4 * H;
             k.dg_pack_out = g.dG_gen_p ? g.dG_gen_p + t * Bp4H : nullptr;
             bwd_reg(a, k, a.gen_hmask, a.gen_cmask, t);
+#ifndef MTTS_DBG_SKIP_GEN_STEPS        // timing experiment only (wrong results): chain A's cost without chain B's step kernels
             MTTS_TRY(skinny_launch(k, sb));
+#endif
             if (t > 0) {
                 SkinnyArgs q; memset(&q, 0, sizeof(q));
                 q.nseg = 1; q.B = B; q.N = H; q.ksplit = ksb;
@@ -307,7 +309,9 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
                 if (g.dG_gen_p) { q.seg[0].x = g.dG_gen_p + t * Bp4H; q.seg[0].xpack = 1; }
                 if (g.gen_w_hh_Tp) { q.seg[0].w = g.gen_w_hh_Tp; q.seg[0].wpack = 1; }
                 q.out = g.part_gen; q.ldo = H; q.out_ks = BH;
+#ifndef MTTS_DBG_SKIP_GEN_STEPS
                 MTTS_TRY(skinny_launch(q, sb));
+#endif
             }
         }
         // input gradients of the generator LSTM for this chunk: dHA = dG_gen W_ih[:, :H];  dctx_all[1:] += dG_gen W_ih[:, H:]
