@@ -276,6 +276,9 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
         GemmArgs q; memset(&q, 0, sizeof(q));
         q.taps = 1; q.batch = 1; q.zt = 1; q.alpha = 1.f; q.mask_scale = 1.f; q.nosplit = 2; q.transA = 1; q.transB = 1;
         q.A = dY; q.lda = ldy; q.M = Mw; q.B = X; q.ldb = ldx; q.N = Nw; q.C = dW; q.ldc = ldw; q.K = rows; q.Kc = rows; q.beta = beta;
+#ifdef MTTS_DBG_SKIP_WGRAD            // timing experiment only (wrong gradients): what the third stream's weight-gradient GEMMs cost the step
+        return 0;
+#endif
         return mtts_gemm_ex(&q, sw);
     };
     {
