@@ -346,6 +346,66 @@ def cpu_baseline(seconds_budget=30.0):
                        f'{L} chars -> {T} frames, {len(times)} steps, median of steady steps, flush-denormal on')
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-exec this script under torch.distributed.run (one rank per GPU,
+    rendezvous on 127.0.0.1 with a free port) with the same arguments; the children print the JSON line themselves (rank 0)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC only on this platform (RCCL needs it)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def stub_main(args):
+    """MTTS_BENCH_STUB=1 (tests/test_bench_launch.py): the launch / barrier / max-over-ranks / one-JSON-line protocol of main()
+    on a stub step over gloo on CPU, so that the N > 1 plumbing is exercised where there is no GPU."""
+    import torch.distributed as dist
+    from multilingual_text_to_speech_amd import dist as D
+    rank, world, _ = D.init(backend='gloo')
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    torch.manual_seed(0)
+    model = torch.nn.Linear(8, 8)
+    D.broadcast_parameters(model)
+    buckets = D.GradientBuckets(model.parameters(), bucket_bytes=64) if world > 1 else None
+    x = torch.randn(args.batch, 8, generator=torch.Generator().manual_seed(1 + rank))
+
+    def step():
+        model.zero_grad()
+        model(x).pow(2).mean().backward()
+        if buckets is not None:
+            buckets.all_reduce()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    t = torch.tensor([time.perf_counter() - t0])
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        frames = args.batch * args.frames * world * args.steps
+        print(json.dumps({'metric': 'stub', 'value': round(frames / float(t), 1), 'unit': 'mel-frames/s', 'n_gpus': world,
+                          'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * float(t) / args.steps, 3),
+                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'stub',
+                          'config': {'workload': 'stub step (launch protocol test)', 'global_batch': args.batch * world,
+                                     'parallelism': f'dp{world}'}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -366,6 +426,12 @@ def main():
     if args.traffic_probe:
         return traffic_probe(args)
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: launch the ranks ourselves (one process per GPU) and relay rank 0's JSON line
+        raise SystemExit(self_launch(args.gpus))
+    if os.environ.get('MTTS_BENCH_STUB') == '1':
+        return stub_main(args)
+
     from multilingual_text_to_speech_amd import _C, dist as D
     from multilingual_text_to_speech_amd.params import presets, Params as hp
     from multilingual_text_to_speech_amd.modules.tacotron2 import Tacotron, TacotronLoss
@@ -374,7 +440,8 @@ def main():
         _C.set_precision('bf16')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (the hot path has no CPU fallback)')
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: pass the same N to torch.distributed.run and to --gpus')
     device = torch.device('cuda', local)
     presets.apply(args.preset, speaker_number=91)
     G = hp.language_number if hp.encoder_type in ('generated', 'convolutional') else 1

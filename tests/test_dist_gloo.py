@@ -101,3 +101,54 @@ def test_shard_bounds_respects_language_groups():
     assert shard_bounds(240, 3, 8, groups=5) == (90, 120)
     with pytest.raises(ValueError):
         shard_bounds(256, 0, 8, groups=5)        # BASELINE's 256 is not divisible by 5 languages x 8 ranks
+
+
+# ---- train.evaluate: validation batches dealt round-robin to the ranks, all ranks get the single-process means ------------------
+class _StubModel(torch.nn.Module):
+    def forward(self, text, text_length, target, target_length, speakers, languages, tf):
+        return target * 0.5, target * 0.25, target.sum(1), None, None, None
+
+
+class _StubCrit:
+    def __call__(self, tl, ml, pre, tgt, post, tgt2, stop, stop_t, align, spk, spk_pred, enc, cls):
+        parts = {'mel_pre': (pre - tgt).pow(2).mean(), 'mel_pos': (post - tgt).pow(2).mean(), 'stop_token': stop.abs().mean()}
+        return sum(parts.values()), parts
+
+
+def _eval_batches():
+    g = torch.Generator().manual_seed(5)
+    out = []
+    for i in range(5):                                   # odd count: the ranks get 3 and 2 batches
+        mel = torch.randn(2, 4, 6 + i, generator=g)
+        out.append((torch.zeros(2, 3, dtype=torch.long), torch.tensor([3, 3]), mel, None, torch.tensor([6 + i] * 2),
+                    torch.zeros(2, 6 + i), None, None))
+    return out
+
+
+def _worker_eval(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    from multilingual_text_to_speech_amd import dist as D
+    import train
+    D.init(backend='gloo')
+    res = train.evaluate(None, _eval_batches(), _StubModel(), _StubCrit(), torch.device('cpu'), rank, world)
+    torch.save(res, f'{out}/e{rank}.pt')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_evaluation_equals_single_process(tmp_path):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import train
+    single = train.evaluate(None, _eval_batches(), _StubModel(), _StubCrit(), torch.device('cpu'))
+    port = _free_port()
+    mp.spawn(_worker_eval, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        got = torch.load(f'{tmp_path}/e{r}.pt')
+        assert set(got) == set(single)
+        for k in single:
+            assert abs(got[k] - single[k]) <= 1e-6 * max(1.0, abs(single[k])), (k, got[k], single[k])

@@ -166,14 +166,22 @@ def make_loader(hp, ds, train, rank, world, workers):
     return DataLoader(ds, batch_sampler=sampler, collate_fn=collate, num_workers=workers), sampler
 
 
-def evaluate(hp, data, model, crit, device):
+EVAL_TERMS = ('mel_pre', 'mel_pos', 'stop_token', 'guided_att', 'lang_class')      # the loss dictionary of TacotronLoss.forward
+
+
+def evaluate(hp, data, model, crit, device, rank=0, world=1):
     """Validation loss with teacher forcing (train.py:100-126,155-160): mean of the per-batch loss terms.  The reference also
-    reports mel-cepstral distortion of a free-running pass and alignment plots; both need its audio stack (absent here)."""
+    reports mel-cepstral distortion of a free-running pass and alignment plots; both need its audio stack (absent here).
+    Data parallel: the batches are the reference's full (unsharded) validation batches; rank r takes batches r, r + world, ...
+    and the per-term sums and the batch count are all-reduced, so every rank works (no rank idles in a barrier while rank 0
+    evaluates - a long validation pass would otherwise run into the collective watchdog) and all ranks return the same means."""
     from multilingual_text_to_speech_amd import data as DT
     model.eval()
     sums, n = {}, 0
     with torch.no_grad():
-        for collated in data:
+        for i, collated in enumerate(data):
+            if i % world != rank:
+                continue
             b = DT.batch_to_device(collated, device)
             post, pre, stop, align, spk, enc = model(b['text'], b['text_length'], b['target'], b['target_length'], b['speakers'],
                                                      b['languages'], 1.0)
@@ -183,6 +191,12 @@ def evaluate(hp, data, model, crit, device):
                 sums[k] = sums.get(k, 0.0) + float(v)
             n += 1
     model.train()
+    if world > 1:
+        keys = sorted(EVAL_TERMS)
+        t = torch.tensor([sums.get(k, 0.0) for k in keys] + [float(n)], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t)
+        n = int(t[-1].item())
+        sums = {k: float(v) for k, v in zip(keys, t[:-1]) if k in sums or v != 0.0}
     return {k: v / max(n, 1) for k, v in sums.items()}
 
 
@@ -212,16 +226,14 @@ def train_on_dataset(args, hp, datasets, model, opt, crit, buckets, rank, world,
         check_device_errors(device)
         if hp.learning_rate_decay_start - hp.learning_rate_decay_each < epoch * len(train_data):
             sched.step()
+        # validation over the full (unsharded) batches of the reference's single-process evaluate(), dealt round-robin to the ranks
+        eval_losses = evaluate(hp, eval_data, model, crit, device, rank, world) if eval_data is not None else {}
         if rank == 0:
-            # validation on rank 0 with the full (unsharded) batches, like the reference's single-process evaluate()
-            eval_losses = evaluate(hp, eval_data, model, crit, device) if eval_data is not None else {}
             eval_loss = sum(eval_losses.values()) if eval_losses else float(loss.item())
             print(f'epoch {epoch}: train loss {loss.item():.4f}  eval loss {eval_loss:.4f}  '
                   f'{frames * world / (time.time() - t0):.0f} frames/s', flush=True)
             if (epoch + 1) % hp.checkpoint_each_epochs == 0:
                 DT.save_checkpoint(os.path.join(ckpt_dir, f'{hp.version}_loss-{epoch}-{eval_loss:2.3f}'), epoch, model, opt, sched, crit)
-        if world > 1:
-            torch.distributed.barrier()
 
 
 if __name__ == '__main__':
