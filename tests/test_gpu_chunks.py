@@ -36,6 +36,19 @@ def test_mixed_teacher_forcing_train_step_at_real_widths(preset, B):
     run_train_step_case(preset, B, 20, T, {}, teacher=teacher)
 
 
+def test_generated_training_train_step_at_real_widths():
+    """BASELINE configs[2] (params/generated_training.json: G = 10 languages, generator_dim 20, bottleneck 8, language embedding
+    32): full train step (forward, loss, every parameter gradient) at the real widths, two samples per language group,
+    T = 49 (one chunk boundary)."""
+    run_train_step_case('generated_training', 20, 30, 49, {})
+
+
+def test_roofline_b240_shape_forward_matches_oracle():
+    """The shape `roofline_b240` is quoted on - generated_switching, batch 240 (48 per language group, four 64-row MFMA tiles
+    with a ragged last one), 120 characters - forward only over 48 frames: mel outputs and alignments against the CPU oracle."""
+    run_train_step_case('generated_switching', 240, 120, 48, {}, check_grads=False)
+
+
 def test_benchmark_shape_forward_matches_oracle():
     """The benchmark's own shape - shared_training, batch 64, 120 characters -> 600 frames (13 chunks), train mode with all
     dropout draws injected - forward only: mel outputs and alignments against the CPU oracle."""
