@@ -390,6 +390,10 @@ typedef struct DecoderArgs {
     float* gate_part_gen;  /* mtts_lstm_step_partial_floats(B, H, H) floats */
     float* prenet_wp[2];   /* free-running steps: MFMA-tile-order copies of the two prenet weights ([P, M] and [P, P]; M, P % 16 == 0) */
     int precision;         /* 0: fp32 (3-way bf16 split products); 1: bf16 operands in the step GEMMs */
+    /* exchange / synchronisation workspace of the persistent recurrence kernels (csrc/persist.hip): zero-initialised by the caller
+       once, mtts_decoder_persist_ws_bytes(B, L, H, Dm, A) bytes; NULL -> per-step launches everywhere */
+    void* persist_ws;
+    long persist_ws_bytes;
 } DecoderArgs;
 
 int mtts_decoder_fwd(const DecoderArgs* args, void* stream);
@@ -399,6 +403,14 @@ int mtts_decoder_fwd(const DecoderArgs* args, void* stream);
  * stream.  *replayed (nullable) = 1 when a graph ran.  Replaces the per-step Python / kernel-launch loop of
  * Decoder.inference (modules/tacotron2.py:216-219,178-207) for BASELINE configs[4]. */
 int mtts_decoder_fwd_graphed(const DecoderArgs* args, void* stream, int* replayed);
+/* Persistent (weights-stationary, one launch for all steps) recurrences of the teacher-forced schedule (csrc/persist.hip; replace the
+ * per-step LSTMCell / attention launches of Decoder._decode, modules/tacotron2.py:180-193).  mtts_decoder_fwd uses them when
+ * DecoderArgs.persist_ws is set, the shape fits (H = 1024, B <= 64, fp32) and MTTS_PERSIST != 0.
+ * mtts_decoder_persist_ws_bytes: size of that workspace (the caller zero-fills it once after allocating it).
+ * mtts_decoder_persist_status: synchronises `stream` and returns the device error word of the workspace
+ * (0 = ok, 2 = a grid barrier gave up; results of that decode are invalid), -1 on a runtime error. */
+long mtts_decoder_persist_ws_bytes(int B, int L, int H, int Dm, int A);
+int mtts_decoder_persist_status(const void* persist_ws, void* stream);
 
 /* ---- bidirectional LSTM over padded batch with packed-sequence semantics ----------------------------------
  * Replaces nn.LSTM(bidirectional) + pack/pad of modules/encoder.py:41-44. */

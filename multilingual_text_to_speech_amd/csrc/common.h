@@ -129,5 +129,9 @@ int ksplit_gemm_launch(const float* x, int K, int ldx, const void* wp, int B, in
 bool attn_bwd_fast_supported(const AttnBwdArgs& p, int max_part);
 int lstm_step2_launch(const LstmStepArgs& a, const LstmStepArgs& b, hipStream_t s);
 int sum_slabs(const float* part, int n, long stride, int ldp, const float* bias, float* out, int rows, int cols, int ldo, int act, hipStream_t s);
+// persistent recurrences (persist.hip)
+bool persist_enabled();
+bool pgen_supported(const DecoderArgs& a);
+int pgen_launch(const DecoderArgs& a, int t0, int t1, hipStream_t s);
 int prenet2_launch(const float* x, int ldx, int Kin, const float* w1, const float* b1, const float* w2, const float* b2, const uint8_t* m1,
                    const uint8_t* m2, float scale, float* y1, float* y2, int B, int P, hipStream_t s);

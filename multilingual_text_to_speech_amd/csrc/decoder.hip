@@ -217,8 +217,11 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
     const int CH = decoder_chunk();
     static const bool want_fuse2 = [] { const char* e = getenv("MTTS_FUSE2"); return e && e[0] == '1'; }();
     const bool fuse2 = use_ls && gen_uses_lstep(a) && want_fuse2;
-    hipStream_t sb = (a.fast && !fuse2) ? side_stream(s) : nullptr;
-    if (a.fast && !fuse2 && !sb) return mtts_fail("decoder: cannot create the side stream");
+    // persistent generator LSTM (persist.hip): chain B runs AFTER chain A as input GEMM (all steps) -> one persistent launch
+    // -> projection GEMM (all steps), everything on the caller's stream
+    const bool pg = a.fast && !fuse2 && gen_uses_lstep(a) && pgen_supported(a);
+    hipStream_t sb = (a.fast && !fuse2 && !pg) ? side_stream(s) : nullptr;
+    if (a.fast && !fuse2 && !pg && !sb) return mtts_fail("decoder: cannot create the side stream");
     for (int t = a.t0; t < a.t1; ++t) {
         if (fuse2 && t > a.t0 && ((t - a.t0) % CH) == 0) MTTS_TRY(gen_pre(a, t - CH, t, 0, s));      // input gates of the chunk chain B enters now
         const bool teach = a.frames_in && a.teacher && a.teacher[t];
@@ -357,7 +360,7 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
                 }
             }
         }
-        if (a.fast && !fuse2 && (((t + 1 - a.t0) % CH) == 0 || t + 1 == a.t1)) {
+        if (a.fast && !fuse2 && !pg && (((t + 1 - a.t0) % CH) == 0 || t + 1 == a.t1)) {
             const int c1 = t + 1, c0 = a.t0 + ((c1 - a.t0 - 1) / CH) * CH;
             hipEvent_t ev = pool_event(s);
             MTTS_CHECK_HIP(hipEventRecord(ev, s));
@@ -369,6 +372,11 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
         const int last0 = a.t0 + ((nsteps - 1) / CH) * CH;                 // first step of the last (possibly ragged) chunk
         MTTS_TRY(gen_pre(a, last0, a.t1, 0, s));
         MTTS_TRY(gen_steps(a, nsteps > CH ? a.t1 - CH : a.t0, a.t1, s));
+        return gen_proj(a, a.t0, a.t1, 0, s);
+    }
+    if (pg) {
+        MTTS_TRY(gen_pre(a, a.t0, a.t1, 0, s));
+        MTTS_TRY(pgen_launch(a, a.t0, a.t1, s));
         return gen_proj(a, a.t0, a.t1, 0, s);
     }
     if (a.fast) {     // join: the caller's stream continues after chain B

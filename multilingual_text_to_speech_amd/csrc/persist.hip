@@ -1,0 +1,683 @@
+// Persistent (weights-stationary) decoder recurrences for MI355X: ONE launch runs all T steps of a recurrence.
+//
+// Why: a teacher-forced decoder step is two all-to-all exchanges (LSTM columns <-> attention samples) around ~10 us of
+// streaming.  As separate launches every exchange costs a kernel boundary (~2.7 us measured in this decoder) plus the ramp and
+// drain of a full-chip grid (~4 us), and every step re-streams 42 MB of recurrent weights from HBM / Infinity Cache.  MI355X has
+// 256 CUs x (512 KiB of vector registers + 160 KiB of LDS) = 168 MiB of on-chip storage: the recurrent weights of a decoder LSTM
+// (25.7 MB for [W_ih[:, P:] | W_hh], 16.8 MB for the generator's W_hh) stay ON CHIP for the whole decode, split by gate columns
+// over the 256 workgroups (one per CU), and the only per-step global traffic is the [B, K] activation exchange (0.25-0.4 MB,
+// L2-served) behind a two-level grid barrier (2.3 us measured, scripts/mb/mb_pbar.hip; broadcast reads 105-125 GB/s per CU,
+// scripts/mb/mb_bcast.hip).
+//
+// Kernels
+//   pgen_kernel  generator LSTM of the teacher-forced schedule (reference modules/tacotron2.py:187-188 with the input projection
+//                hoisted into one GEMM): per step  gates = pre_gen[t] + h_gen[t] W_hh^T -> cell -> h_gen[t+1]; 1 barrier per step.
+//   pdec_kernel  attention LSTM + location-sensitive attention (reference modules/tacotron2.py:184-186, modules/attention.py:39-86,
+//                modules/layers.py:18-47): per step
+//                  phase 1 (column role: workgroup c owns LSTM units [4c, 4c+4)):  gates = pre_att[t] + [ctx_t | h_t] W^T -> cell
+//                           -> h_{t+1} (row-major + exchange layout)                                        | grid barrier
+//                  phase 2 (sample role: workgroup (b, j) owns sample b, attention channels [32j, 32j+32) and context columns
+//                           [j Dm/4, (j+1) Dm/4)):  q = W_q[32j.., :] h_{t+1}[b]; partial energies over its 32 channels (location
+//                           filter bank on MFMA, exact 3-way bf16 split) -> 4-way exchange of the partial energies (tagged 8-byte
+//                           granules) -> masked softmax, cumulative alignment (stays in LDS), context columns -> ctx_{t+1}
+//                                                                                                            | grid barrier
+// Arithmetic is the step kernels' (lstm_step.hip): fp32 operands split exactly into three bf16 planes, six
+// v_mfma_f32_16x16x32_bf16 terms per product, fp32 accumulation; the cell / attention math is fp32.
+//
+// Inter-workgroup data follows MI355X_MICROARCH.md (visibility): producers store write-through (sc1) and drain (s_waitcnt vmcnt(0))
+// before the barrier arrive, consumers read with sc1 loads (L1 bypass), flags are relaxed agent-scope atomics, every spin is bounded
+// and raises a device error word instead of hanging.  Results do not depend on dispatch order or placement; blockIdx % 8 == XCD is
+// used for speed only (barrier groups).
+#include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+namespace {
+
+constexpr int PS_THREADS = 512;
+constexpr int PS_WGS = 256;                 // one workgroup per CU; 4 LSTM units (16 gate columns) each: H = 1024
+constexpr int PS_ERR_OFF = 4096, PS_XP_OFF = 8192;      // workspace: [counters: 4 groups x 8 x 128 B][error word][exchange ...]
+constexpr unsigned PS_SPIN_MAX = 1u << 22;  // ~0.5 s of polling before a barrier gives up (error word, no hang)
+#define PS_RLX __ATOMIC_RELAXED
+#define PS_AGENT __HIP_MEMORY_SCOPE_AGENT
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ps_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x27000);
+}
+__device__ __forceinline__ float4 ps_ld16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {       // L1-bypassing 16-byte load
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void ps_st16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float4 x) {  // write-through 16-byte store
+    u32x4 v; v.x = __float_as_uint(x.x); v.y = __float_as_uint(x.y); v.z = __float_as_uint(x.z); v.w = __float_as_uint(x.w);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, 16);
+}
+
+// exact 3-way split of two floats into three packed bf16 pairs (truncation; residuals are exact in fp32) - as lstm_step.hip
+__device__ __forceinline__ void ps_split_pair(float x, float y, unsigned& p1, unsigned& p2, unsigned& p3) {
+    const unsigned ux = __float_as_uint(x), uy = __float_as_uint(y);
+    const float rx = x - __uint_as_float(ux & 0xffff0000u), ry = y - __uint_as_float(uy & 0xffff0000u);
+    const unsigned vx = __float_as_uint(rx), vy = __float_as_uint(ry);
+    const float sx = rx - __uint_as_float(vx & 0xffff0000u), sy = ry - __uint_as_float(vy & 0xffff0000u);
+    p1 = __builtin_amdgcn_perm(uy, ux, 0x07060302u);
+    p2 = __builtin_amdgcn_perm(vy, vx, 0x07060302u);
+    p3 = __builtin_amdgcn_perm(__float_as_uint(sy), __float_as_uint(sx), 0x07060302u);
+}
+union PsFrag { bf16x8 v; unsigned u[4]; };
+struct PsFrag3 { PsFrag p[3]; };
+__device__ __forceinline__ PsFrag3 ps_split8(const float4& lo, const float4& hi) {      // 8 consecutive k -> 3 bf16 planes
+    PsFrag3 f;
+    ps_split_pair(lo.x, lo.y, f.p[0].u[0], f.p[1].u[0], f.p[2].u[0]);
+    ps_split_pair(lo.z, lo.w, f.p[0].u[1], f.p[1].u[1], f.p[2].u[1]);
+    ps_split_pair(hi.x, hi.y, f.p[0].u[2], f.p[1].u[2], f.p[2].u[2]);
+    ps_split_pair(hi.z, hi.w, f.p[0].u[3], f.p[1].u[3], f.p[2].u[3]);
+    return f;
+}
+// acc += A B^T with fp32 accuracy: six bf16 MFMA terms, small ones first
+__device__ __forceinline__ f32x4 ps_mma6(const PsFrag3& a, const PsFrag3& b, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p[2].v, b.p[0].v, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p[0].v, b.p[2].v, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p[1].v, b.p[1].v, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p[1].v, b.p[0].v, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p[0].v, b.p[1].v, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p[0].v, b.p[0].v, acc, 0, 0, 0);
+    return acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Exchange layout ("XP") of an activation matrix X[rows][K] (K % 32 == 0): the MFMA A-fragment order of v_mfma_f32_16x16x32,
+//   float index = ((((rt * nkb + kb) * 2 + hf) * 64) + (q4 * 16 + i16)) * 4 + e     row = 16 rt + i16,  k = 32 kb + 8 q4 + 4 hf + e
+// so that a wave reads the fragment (rt, kb) as two fully contiguous 1 KiB loads and a producer that owns 4 consecutive columns
+// (k % 4 == 0) of one row writes exactly one 16-byte quantum.
+// ---------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned ps_xp_off(int row, int k, int nkb) {        // BYTE offset of the 16-byte quantum holding k .. k+3
+    const int rt = row >> 4, i16 = row & 15, kb = k >> 5, j = k & 31, q4 = j >> 3, hf = (j >> 2) & 1;
+    return (unsigned)((((((rt * nkb + kb) * 2 + hf) * 64) + (q4 * 16 + i16)) * 4) * 4);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Grid barrier: two levels (8 groups by blockIdx % 8, observed = XCD; correctness does not depend on it), monotonic counters
+// zeroed by the host before the launch, relaxed agent-scope atomics, sc1 payload drained by every wave before the arrive.
+// Returns false when the spin bound was hit or another workgroup reported an error (every workgroup then leaves the kernel).
+// ---------------------------------------------------------------------------------------------------------------------------
+struct PsSync { unsigned* cnt; unsigned* err; };      // cnt[0] global, cnt[32 * (1 + g)] group g; err: device error word (0 = ok)
+
+
+__device__ __forceinline__ bool ps_barrier(const PsSync& s, unsigned epoch) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned nwg = gridDim.x, ng = 8, g = blockIdx.x % ng, gsz = nwg / ng;
+        const unsigned prev = __hip_atomic_fetch_add(s.cnt + 32 * (1 + g), 1u, PS_RLX, PS_AGENT);
+        if (prev + 1 == epoch * gsz) __hip_atomic_fetch_add(s.cnt, 1u, PS_RLX, PS_AGENT);
+        const unsigned target = epoch * ng;
+        unsigned spins = 0;
+        while (__hip_atomic_load(s.cnt, PS_RLX, PS_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 1023u) == 0 && (spins > PS_SPIN_MAX || __hip_atomic_load(s.err, PS_RLX, PS_AGENT) != 0)) {
+                __hip_atomic_store(s.err, 2u, PS_RLX, PS_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    return __hip_atomic_load(s.err, PS_RLX, PS_AGENT) == 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Phase 1: partial gate pre-activations of this workgroup's 16 columns.
+//   wave w takes the k-blocks [nkb w / 8, nkb (w+1) / 8) (at most NBW), streams the matching fragments of X (all RT row tiles)
+//   from the exchange buffer (sc1 loads, DEPTH blocks in flight), takes its weight fragments from LDS and leaves its
+//   [16 RT rows x 16 columns] partial sums in red[w][row][col].
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int NBW, int RT, int DEPTH>
+__device__ __forceinline__ void ps_gates(__amdgpu_buffer_rsrc_t xr, int nkb, const float4* __restrict__ wl, float* __restrict__ red) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int k0 = (nkb * wave) >> 3, k1 = (nkb * (wave + 1)) >> 3;
+    float4 xa[DEPTH][RT][2];
+    // fragment (rt, kb): byte offset ((rt * nkb + kb) * 2 + hf) * 1024 + lane * 16; blocks past k1 read out of range (= 0)
+    auto issue = [&](int j, int slot) {
+        const int kb = k0 + j;
+        const bool ok = kb < k1;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const unsigned off = ok ? (unsigned)((((rt * nkb + kb) * 2 + hf) * 1024) + lane * 16) : 0xfffffff0u;
+                xa[slot][rt][hf] = ps_ld16_sc1(xr, off);
+            }
+    };
+#pragma unroll
+    for (int j = 0; j < DEPTH && j < NBW; ++j) issue(j, j);
+    __builtin_amdgcn_sched_barrier(0);          // keep the whole burst ahead of the first use (hipcc would sink loads next to their uses)
+    f32x4 acc[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+        const int kb = min(k0 + j, nkb - 1);
+        const float4 w0 = wl[(kb * 2 + 0) * 64 + lane], w1 = wl[(kb * 2 + 1) * 64 + lane];
+        const PsFrag3 wb = ps_split8(w0, w1);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const PsFrag3 a = ps_split8(xa[j % DEPTH][rt][0], xa[j % DEPTH][rt][1]);
+            acc[rt] = ps_mma6(a, wb, acc[rt]);
+        }
+        if (j + DEPTH < NBW) { issue(j + DEPTH, j % DEPTH); __builtin_amdgcn_sched_barrier(0); }
+    }
+    // D layout: column = lane & 15, row = 4 (lane >> 4) + r
+    float* out = red + wave * (64 * 16);
+    const int i16 = lane & 15, q4 = lane >> 4;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(16 * rt + 4 * q4 + r) * 16 + i16] = acc[rt][r];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// LSTM cell for (row, unit) = (tid >> 2, tid & 3), tid < 4 B: sums the 8 partials, adds the hoisted projection and the bias,
+// applies dropout / zoneout (reference modules/layers.py:26-47) and returns the h that recurs.  c / h of the previous step live
+// in the caller's registers.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct PsCellCfg { int zone; float hscale, zh, zc; };
+
+__device__ __forceinline__ void ps_cell(const float* __restrict__ red, int row, int uu, float4 g4, const float4 pre4, float& c_state, float& h_state,
+                                        int hm, int cm, bool has_hmask, const PsCellCfg& cfg, float4& gates_act) {
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        const float4 v = *reinterpret_cast<const float4*>(red + w * (64 * 16) + row * 16 + 4 * uu);
+        g4.x += v.x; g4.y += v.y; g4.z += v.z; g4.w += v.w;
+    }
+    g4.x += pre4.x; g4.y += pre4.y; g4.z += pre4.z; g4.w += pre4.w;
+    const float ig = sigmoidf_(g4.x), fg = sigmoidf_(g4.y), gg = tanhf_(g4.z), og = sigmoidf_(g4.w);
+    const float cp = c_state, hp = h_state;
+    const float cn = fg * cp + ig * gg;
+    const float hn = og * tanhf_(cn);
+    float ho, co = cn;
+    if (cfg.zone == 1) { ho = hm ? hn : hp; co = cm ? cn : cp; }
+    else if (cfg.zone == 2) { ho = cfg.zh * hp + (1.f - cfg.zh) * hn; co = cfg.zc * cp + (1.f - cfg.zc) * cn; }
+    else ho = has_hmask ? (hm ? hn * cfg.hscale : 0.f) : hn;
+    c_state = co; h_state = ho;
+    gates_act = make_float4(ig, fg, gg, og);
+}
+
+// the four units of a row sit in four consecutive lanes (uu = lane & 3): gather them into lane uu == 0 as one float4
+__device__ __forceinline__ float4 ps_quad_gather(float v) {
+    float4 r;
+    r.x = dpp_f<0x00>(v);      // quad_perm [0,0,0,0]
+    r.y = dpp_f<0x55>(v);      // quad_perm [1,1,1,1]
+    r.z = dpp_f<0xAA>(v);      // quad_perm [2,2,2,2]
+    r.w = dpp_f<0xFF>(v);      // quad_perm [3,3,3,3]
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// pgen: generator LSTM, recurrent part
+// ---------------------------------------------------------------------------------------------------------------------------
+struct PsGen {
+    int B, H, t0, t1;
+    const float* w_packed;      // mtts_lstm_pack_weights(fp32) of W_hh: [4H/16 column groups][nkb][2][64][4]
+    const float* bias_u;        // [4H] unit-major
+    const float* pre;           // [T][B][4H] unit-major hoisted input projection
+    float* h; float* c;         // [T+1][B][H]
+    float* gates;               // [T][B][4H] gate-major (i | f | g | o) or NULL
+    const uint8_t* hmask; const uint8_t* cmask;
+    PsCellCfg cell;
+    float* xp;                  // [2][64 rows][H] exchange (XP layout)
+    PsSync sync;
+    unsigned long long* prof;   // NULL in production
+};
+
+template <int RT>
+__global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void pgen_kernel(PsGen p) {
+    extern __shared__ __attribute__((aligned(16))) char psm[];
+    const int tid = threadIdx.x, c = blockIdx.x;
+    const int H = p.H, B = p.B, nkb = H >> 5, N = 4 * H;
+    float4* wl = reinterpret_cast<float4*>(psm);                       // [nkb][2][64] float4 = nkb * 2 KiB
+    float* red = reinterpret_cast<float*>(psm + (size_t)nkb * 2048);    // [8][64][16]
+    // ---- stationary weights -> LDS
+    {
+        const float4* src = reinterpret_cast<const float4*>(p.w_packed) + (size_t)c * nkb * 128;
+        for (int i = tid; i < nkb * 128; i += PS_THREADS) wl[i] = src[i];
+    }
+    const int row = tid >> 2, uu = tid & 3, u = 4 * c + uu;
+    const bool cellthr = tid < 4 * B;
+    const int rowc = cellthr ? row : 0;
+    const unsigned xp_bytes = (unsigned)(64 * H * 4);
+    float c_state = 0.f, h_state = 0.f;
+    const float4 bias4 = *reinterpret_cast<const float4*>(p.bias_u + 4 * u);
+    if (cellthr) {
+        c_state = p.c[((size_t)p.t0 * B + row) * H + u];
+        h_state = p.h[((size_t)p.t0 * B + row) * H + u];
+    }
+    {   // publish h[t0] in the exchange layout
+        const float4 h4 = ps_quad_gather(h_state);
+        if (cellthr && uu == 0) ps_st16_sc1(ps_rsrc(p.xp + (size_t)(p.t0 & 1) * 64 * H, xp_bytes), ps_xp_off(row, 4 * c, nkb), h4);
+    }
+    unsigned epoch = 0;
+    if (!ps_barrier(p.sync, ++epoch)) return;
+    for (int t = p.t0; t < p.t1; ++t) {
+        // operands that do not depend on the exchange: requested first
+        const float4 pre4 = *reinterpret_cast<const float4*>(p.pre + ((size_t)t * B + rowc) * N + 4 * u);
+        const int hm = (p.hmask && cellthr) ? (int)p.hmask[((size_t)t * B + row) * H + u] : 1;
+        const int cm = (p.cmask && cellthr) ? (int)p.cmask[((size_t)t * B + row) * H + u] : 1;
+        ps_gates<4, RT, 4>(ps_rsrc(p.xp + (size_t)(t & 1) * 64 * H, xp_bytes), nkb, wl, red);
+        __syncthreads();
+        float4 ga;
+        if (cellthr) ps_cell(red, row, uu, bias4, pre4, c_state, h_state, hm, cm, p.hmask != nullptr, p.cell, ga);
+        const float4 h4 = ps_quad_gather(h_state);
+        if (cellthr) {
+            const size_t o = ((size_t)(t + 1) * B + row) * H + u;
+            p.c[o] = c_state;
+            if (uu == 0) {
+                *reinterpret_cast<float4*>(p.h + o) = h4;
+                ps_st16_sc1(ps_rsrc(p.xp + (size_t)((t + 1) & 1) * 64 * H, xp_bytes), ps_xp_off(row, 4 * c, nkb), h4);
+            }
+            if (p.gates) {
+                float* go = p.gates + ((size_t)t * B + row) * N + u;
+                go[0] = ga.x; go[H] = ga.y; go[2 * H] = ga.z; go[3 * H] = ga.w;
+            }
+        }
+        if (!ps_barrier(p.sync, ++epoch)) return;       // also orders the reads of red before the next step's writes
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// pgen3: the same recurrence, software-pipelined ROUND-ROBIN over the 16-row groups of the batch (the samples of a batch do not
+// interact in an LSTM, so a batch of 64 is four independent recurrences).  One "group-step" = the gate GEMM of one row group for one
+// time step.  While group g's h_{t+1} travels (write-through drain, counter atomic, poll), the workgroup runs the group-steps of the
+// other groups; the grid-barrier latency and the first-byte latency of the exchange reads leave the critical path:
+//   * group-step i: seven waves multiply (k-blocks dealt over the seven), having issued the loads of group-step i+1 FIRST (two
+//     register buffers, ping-pong); the eighth wave - wave g' of the previous group g' - runs that group's LSTM cell, publishes,
+//     drains its stores and arrives, all in the shadow of the others' MFMAs (the cell wave of a group never multiplies in the
+//     group-step right after its own);
+//   * barrier = 8 counters per group (blockIdx % 8), arrive = one non-returning atomic per workgroup and publish, wait = every wave
+//     samples the 8 counters (lanes 0-7) one group-step ahead of need;
+//   * weights stay in LDS as three bf16 planes in MFMA B-fragment order (split once per launch); ONE __syncthreads per group-step.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct PsBar2 { unsigned* cnt; unsigned* err; };      // cnt[(g * 8 + x) * 32]: counter x of row group g
+
+__device__ __forceinline__ void ps_arrive(const PsBar2& b, int g) {      // one lane; the wave has drained its stores
+    __hip_atomic_fetch_add(b.cnt + (g * 8 + (blockIdx.x & 7)) * 32, 1u, PS_RLX, PS_AGENT);
+}
+__device__ __forceinline__ unsigned ps_sample(const PsBar2& b, int g) {   // lanes 0-7: one counter each; other lanes: "reached"
+    const int lane = threadIdx.x & 63;
+    return lane < 8 ? __hip_atomic_load(b.cnt + (g * 8 + lane) * 32, PS_RLX, PS_AGENT) : 0xffffffffu;
+}
+// wave-wide wait; returns false on timeout / foreign error
+__device__ __forceinline__ bool ps_wait(const PsBar2& b, int g, unsigned target) {
+    unsigned spins = 0;
+    for (;;) {
+        if (__all(ps_sample(b, g) >= target)) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 1023u) == 0 && (spins > PS_SPIN_MAX || __hip_atomic_load(b.err, PS_RLX, PS_AGENT) != 0)) {
+            if ((threadIdx.x & 63) == 0) __hip_atomic_store(b.err, 2u, PS_RLX, PS_AGENT);
+            return false;
+        }
+    }
+}
+
+#ifdef PS_PROF
+#define PS_PROF_WORDS (2 * PS_PROF)
+#else
+#define PS_PROF_WORDS 0
+#endif
+#ifdef PS_PROF      // micro-benchmark builds only: workgroup 0 stamps the shader clock into LDS (no VMEM traffic), dumped at exit
+#define PS_STAMP(buf, slot, who) do { if (blockIdx.x == 0 && (who) && (slot) < PS_PROF) (buf)[slot] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PS_STAMP(buf, slot, who) do { } while (0)
+#endif
+
+// Exchange layout of the pipelined kernels ("XQ"): the producer splits its fp32 values ONCE into the three bf16 planes and every
+// consumer loads finished MFMA A-fragments (no per-consumer split arithmetic: 256 workgroups read what one wrote).  One 16-row
+// region: [k-block][plane][64 lanes][8 bf16], lane = 16 q4 + i16 holds row i16, k = 32 kb + 8 q4 .. + 7:
+//   byte offset = ((kb * 3 + pl) * 64 + q4 * 16 + i16) * 16 + (k & 4) * 2       for the four bf16 of k .. k+3 (k % 4 == 0)
+template <int NBW> struct PsLoads { u32x4 x[NBW][3]; };
+
+__device__ __forceinline__ unsigned ps_xq_off(int i16, int k, int pl) {
+    const int kb = k >> 5, j = k & 31, q4 = j >> 3;
+    return (unsigned)(((kb * 3 + pl) * 64 + q4 * 16 + i16) * 16 + (j & 4) * 2);
+}
+// publish four consecutive columns k .. k+3 of row i16 (three 8-byte write-through stores)
+__device__ __forceinline__ void ps_xq_store4(__amdgpu_buffer_rsrc_t r, int i16, int k, float4 v) {
+    unsigned a[3], b[3];
+    ps_split_pair(v.x, v.y, a[0], a[1], a[2]);
+    ps_split_pair(v.z, v.w, b[0], b[1], b[2]);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+        u32x2 w; w.x = a[pl]; w.y = b[pl];
+        __builtin_amdgcn_raw_buffer_store_b64(w, r, ps_xq_off(i16, k, pl), 0, 16);
+    }
+}
+
+// one k-block of the next group-step's fragments (blocks past k1 read out of range = 0)
+template <int NBW>
+__device__ __forceinline__ void ps_issue_block(PsLoads<NBW>& ld, int j, __amdgpu_buffer_rsrc_t xr, int k0, int k1, int lane) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+        ld.x[j][pl] = __builtin_amdgcn_raw_buffer_load_b128(xr, (k0 + j < k1) ? (unsigned)((((k0 + j) * 3 + pl) * 1024) + lane * 16) : 0xfffffff0u, 0, 16);
+}
+template <int NBW>
+__device__ __forceinline__ void ps_issue16(PsLoads<NBW>& ld, __amdgpu_buffer_rsrc_t xr, int k0, int k1, int lane) {
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) ps_issue_block<NBW>(ld, j, xr, k0, k1, lane);
+}
+
+// [16 rows x 16 columns] partial over the k-blocks [k0, k0 + NBW) held in `buf`; with PREFETCH the fragment registers of a block are
+// refilled with the NEXT group-step's block (k-range [nk0, nk1) of region nxr) as soon as its six MFMAs have been issued - one
+// register buffer serves both group-steps.  Two accumulators: consecutive MFMAs never depend on each other.
+template <int NBW, bool PREFETCH>
+__device__ __forceinline__ void ps_mma16(PsLoads<NBW>& buf, int nkb, int k0, const uint4* __restrict__ wpl, float* __restrict__ red_w, int lane,
+                                         __amdgpu_buffer_rsrc_t nxr, int nk0, int nk1) {
+    f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+        const int kb = min(k0 + j, nkb - 1);
+        PsFrag wb[3], a[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            const uint4 w = wpl[(kb * 3 + pl) * 64 + lane];
+            wb[pl].u[0] = w.x; wb[pl].u[1] = w.y; wb[pl].u[2] = w.z; wb[pl].u[3] = w.w;
+            a[pl].u[0] = buf.x[j][pl].x; a[pl].u[1] = buf.x[j][pl].y; a[pl].u[2] = buf.x[j][pl].z; a[pl].u[3] = buf.x[j][pl].w;
+        }
+        // six terms, small ones first, alternating accumulators
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2].v, wb[0].v, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0].v, wb[2].v, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1].v, wb[1].v, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1].v, wb[0].v, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0].v, wb[1].v, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0].v, wb[0].v, acc1, 0, 0, 0);
+        if (PREFETCH) ps_issue_block<NBW>(buf, j, nxr, nk0, nk1, lane);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const int i16 = lane & 15, q4 = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red_w[(4 * q4 + r) * 16 + i16] = acc0[r] + acc1[r];
+}
+
+template <int NG>
+__global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void pgen3_kernel(PsGen p) {
+    extern __shared__ __attribute__((aligned(16))) char psm[];
+    constexpr int NACT = NG >= 2 ? 7 : 8;                     // multiplying waves per group-step
+    constexpr int NBW = NG >= 2 ? 5 : 4;                      // k-blocks per multiplying wave (nkb = 32)
+    const int tid = threadIdx.x, lane = tid & 63, c = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = p.H, B = p.B, nkb = H >> 5, N = 4 * H;
+    uint4* wpl = reinterpret_cast<uint4*>(psm);                                        // [nkb][3][64] x 16 B
+    float* red = reinterpret_cast<float*>(psm + (size_t)nkb * 3072);                   // [NG][8][16][16]
+#ifdef PS_PROF
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(red + NG * 8 * 256);
+#endif
+    const PsBar2 bar{p.sync.cnt, p.sync.err};
+    // ---- stationary weights: fp32 packed slice -> three bf16 planes in LDS; partial-sum slots start at zero
+    {
+        const float4* src = reinterpret_cast<const float4*>(p.w_packed) + (size_t)c * nkb * 128;
+        for (int i = tid; i < nkb * 64; i += PS_THREADS) {
+            const int kb = i >> 6, l = i & 63;
+            const PsFrag3 f = ps_split8(src[(kb * 2 + 0) * 64 + l], src[(kb * 2 + 1) * 64 + l]);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) wpl[(kb * 3 + pl) * 64 + l] = make_uint4(f.p[pl].u[0], f.p[pl].u[1], f.p[pl].u[2], f.p[pl].u[3]);
+        }
+        for (int i = tid; i < NG * 8 * 256; i += PS_THREADS) red[i] = 0.f;
+    }
+    // ---- cell role: wave g (< NG) owns the 16 rows x 4 units of row group g; lane -> (local row, unit)
+    const bool cellwave = wave < NG;
+    const int rl = lane >> 2, uu = lane & 3, u = 4 * c + uu;
+    const int row = 16 * wave + rl;
+    const bool cellthr = cellwave && row < B;
+    const int rowc = cellthr ? row : 0;
+    const unsigned xg_bytes = (unsigned)(nkb * 3072);                               // one (group, parity) exchange region (XQ layout)
+    auto xregion = [&](int g, int par) { return ps_rsrc(reinterpret_cast<char*>(p.xp) + (size_t)(g * 2 + par) * xg_bytes, xg_bytes); };
+    float c_state = 0.f, h_state = 0.f;
+    const float4 bias4 = *reinterpret_cast<const float4*>(p.bias_u + 4 * u);
+    if (cellthr) {
+        c_state = p.c[((size_t)p.t0 * B + row) * H + u];
+        h_state = p.h[((size_t)p.t0 * B + row) * H + u];
+    }
+    if (cellwave) {   // publish h[t0] (rows local to the group), arrive
+        const float4 h4 = ps_quad_gather(h_state);
+        if (cellthr && uu == 0) ps_xq_store4(xregion(wave, p.t0 & 1), rl, 4 * c, h4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) ps_arrive(bar, wave);
+    }
+    __syncthreads();
+    const unsigned per_pub = PS_WGS / 8;                      // arrivals per counter and publish
+    const int n_gs = (p.t1 - p.t0) * NG;
+    // k-range of `wave` in a group-step of group g: the cell wave of the PREVIOUS group (wave (g + NG - 1) % NG) does not multiply
+    auto krange = [&](int g, int& k0, int& k1) {
+        if (NG == 1) { k0 = (nkb * wave) >> 3; k1 = (nkb * (wave + 1)) >> 3; return; }
+        const int wp = (g + NG - 1) % NG;
+        if (wave == wp) { k0 = k1 = 0; return; }
+        const int r = wave - (wave > wp ? 1 : 0);
+        k0 = (nkb * r) / NACT; k1 = (nkb * (r + 1)) / NACT;
+    };
+    // operands of the cell this wave will run for time step tc (issued one group-step ahead)
+    float4 pre4 = make_float4(0.f, 0.f, 0.f, 0.f); unsigned hm = 1, cm = 1;
+    auto cell_prefetch = [&](int tc) {
+        pre4 = *reinterpret_cast<const float4*>(p.pre + ((size_t)tc * B + rowc) * N + 4 * u);
+        const size_t mo = ((size_t)tc * B + rowc) * H + u;
+        hm = p.hmask ? (unsigned)p.hmask[mo] : 1u;
+        cm = p.cmask ? (unsigned)p.cmask[mo] : 1u;
+    };
+    // LSTM cell of (group = this wave, time tc): partial sums -> gates -> state; publishes h[tc + 1]
+    auto cell = [&](int tc) {
+        const float* redg = red + wave * (8 * 256);
+        float4 g4 = bias4;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const float4 v = *reinterpret_cast<const float4*>(redg + w * 256 + rl * 16 + 4 * uu);
+            g4.x += v.x; g4.y += v.y; g4.z += v.z; g4.w += v.w;
+        }
+        g4.x += pre4.x; g4.y += pre4.y; g4.z += pre4.z; g4.w += pre4.w;
+        const float ig = sigmoidf_(g4.x), fg = sigmoidf_(g4.y), gg = tanhf_(g4.z), og = sigmoidf_(g4.w);
+        const float cp = c_state, hp = h_state;
+        const float cn = fg * cp + ig * gg;
+        const float hn = og * tanhf_(cn);
+        float ho, co = cn;
+        if (p.cell.zone == 1) { ho = hm ? hn : hp; co = cm ? cn : cp; }
+        else if (p.cell.zone == 2) { ho = p.cell.zh * hp + (1.f - p.cell.zh) * hn; co = p.cell.zc * cp + (1.f - p.cell.zc) * cn; }
+        else ho = p.hmask ? (hm ? hn * p.cell.hscale : 0.f) : hn;
+        c_state = co; h_state = ho;
+        const float4 h4 = ps_quad_gather(h_state);
+        if (cellthr) {
+            const size_t o = ((size_t)(tc + 1) * B + row) * H + u;
+            if (uu == 0) {
+                ps_xq_store4(xregion(wave, (tc + 1) & 1), rl, 4 * c, h4);
+                *reinterpret_cast<float4*>(p.h + o) = h4;
+            }
+            p.c[o] = c_state;
+            if (p.gates) {
+                float* go = p.gates + ((size_t)tc * B + row) * N + u;
+                go[0] = ig; go[H] = fg; go[2 * H] = gg; go[3 * H] = og;
+            }
+        }
+    };
+    // Only wave 7 touches the global counters (2048 pollers on eight cache lines would serialise behind each other): it samples
+    // them in the middle of its MFMA loop for the publish the NEXT group-step's prefetch needs, posts `seen[g] = publish number`
+    // to LDS before the group-step's __syncthreads, and is the one that spins when a publish is late.
+    volatile unsigned* seen = reinterpret_cast<volatile unsigned*>(red + NG * 8 * 256 + PS_PROF_WORDS);      // [NG] + [1] error flag
+    if (tid < 8) seen[tid] = 0;
+    __syncthreads();
+    auto wait_pub = [&](int g, unsigned pub) -> bool {
+        if (seen[g] >= pub) return true;
+        if (wave == 7) {
+            if (!ps_wait(bar, g, pub * per_pub)) { if (lane == 0) seen[NG] = 1; return false; }
+            if (lane == 0) seen[g] = pub;
+            return true;
+        }
+        unsigned spins = 0;
+        while (seen[g] < pub) {
+            __builtin_amdgcn_s_sleep(1);
+            if (seen[NG] != 0 || ++spins > (PS_SPIN_MAX << 2)) return false;
+        }
+        return true;
+    };
+    PsLoads<NBW> buf;
+    // group-step i: group g = i % NG, time t = t0 + i / NG, inputs = publish (i / NG + 1) of group g
+    auto gstep = [&](int i) -> bool {
+        const int g = i % NG, t = p.t0 + i / NG;
+        const int in = i + 1, gn = in % NG, tn = p.t0 + in / NG;
+        const bool has_next = in < n_gs;
+        PS_STAMP(stamps, 4 * i + 0, tid == 64 * 5);
+        if (NG >= 2 && wave == (g + NG - 1) % NG) {
+            // ---- cell wave of the previous group-step: cell, publish, drain, arrive - beside the others' MFMAs
+            if (i > 0) {
+                cell(p.t0 + (i - 1) / NG);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) ps_arrive(bar, wave);
+            }
+            if (has_next) {      // this wave multiplies again in the next group-step
+                int k0, k1; krange(gn, k0, k1);
+                if (!wait_pub(gn, (unsigned)(in / NG + 1))) return false;
+                ps_issue16<NBW>(buf, xregion(gn, tn & 1), k0, k1, lane);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            // ---- multiplying wave: loads of the NEXT group-step first, then this group-step's MFMAs
+            const bool want = NG >= 2 && has_next && wave != g;      // (wave g runs group g's cell during the next group-step)
+            const unsigned pubn = (unsigned)(in / NG + 1);
+            int kn0 = 0, kn1 = 0;
+            if (want) krange(gn, kn0, kn1);
+            const bool early = want && seen[gn] >= pubn;              // the next group-step's inputs have already landed
+            if (wave == g && cellwave) cell_prefetch(t);
+            __builtin_amdgcn_sched_barrier(0);
+            PS_STAMP(stamps, 4 * i + 1, tid == 64 * 5);
+            int k0, k1; krange(g, k0, k1);
+            if (early) ps_mma16<NBW, true>(buf, nkb, k0, wpl, red + (g * 8 + wave) * 256, lane, xregion(gn, tn & 1), kn0, kn1);
+            else ps_mma16<NBW, false>(buf, nkb, k0, wpl, red + (g * 8 + wave) * 256, lane, xregion(gn, tn & 1), kn0, kn1);
+            PS_STAMP(stamps, 4 * i + 2, tid == 64 * 5);
+            if (want && !early) {      // the publish was late: wait for it now, behind this group-step's arithmetic
+                if (!wait_pub(gn, pubn)) return false;
+                ps_issue16<NBW>(buf, xregion(gn, tn & 1), kn0, kn1, lane);
+            }
+            if (NG >= 2 && wave == 7 && i + 2 < n_gs) {      // what the prefetch of the next group-step will need
+                const int g2 = (i + 2) % NG; const unsigned pub2 = (unsigned)((i + 2) / NG + 1);
+                if (__all(ps_sample(bar, g2) >= pub2 * per_pub) && lane == 0) seen[g2] = pub2;
+            }
+        }
+        __syncthreads();
+        PS_STAMP(stamps, 4 * i + 3, tid == 64 * 5);
+        if (NG == 1) {      // single group: nothing to overlap with - cell, drain, arrive, and the partial sums are free again
+            if (wave == 0) { cell(t); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) ps_arrive(bar, 0); }
+            __syncthreads();
+            if (has_next) {
+                int k0, k1; krange(0, k0, k1);
+                if (!wait_pub(0, (unsigned)(in + 1))) return false;
+                ps_issue16<NBW>(buf, xregion(0, tn & 1), k0, k1, lane);
+            }
+        }
+        return true;
+    };
+    // prologue: loads of group-step 0
+    if (n_gs > 0 && !(NG >= 2 && wave == NG - 1)) {
+        int k0, k1; krange(0, k0, k1);
+        if (!wait_pub(0, 1u)) return;
+        ps_issue16<NBW>(buf, xregion(0, p.t0 & 1), k0, k1, lane);
+    }
+    for (int i = 0; i < n_gs; ++i)
+        if (!gstep(i)) return;
+    if (NG >= 2 && n_gs > 0 && wave == (n_gs - 1) % NG) cell(p.t1 - 1);      // the last group-step's cell
+#ifdef PS_PROF
+    __syncthreads();
+    if (p.prof && blockIdx.x == 0) for (int i = tid; i < PS_PROF; i += PS_THREADS) p.prof[i] = stamps[i];
+#endif
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------------
+static bool ps_device_ok() {
+    static int cus = [] {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        return prop.multiProcessorCount;
+    }();
+    return cus >= PS_WGS;
+}
+
+// MTTS_PERSIST=0 switches the persistent recurrences off (the per-step launch schedule then runs everywhere)
+bool persist_enabled() {
+    static const bool on = [] { const char* e = getenv("MTTS_PERSIST"); return !(e && e[0] == '0'); }();
+    return on && ps_device_ok();
+}
+
+// bytes of the exchange / synchronisation workspace a decoder call hands to the persistent kernels (DecoderArgs.persist_ws)
+MTTS_API long mtts_decoder_persist_ws_bytes(int B, int L, int H, int Dm, int A) {
+    (void)B; (void)A;
+    const long sync = PS_XP_OFF;                                   // barrier counters + error word
+    const long xp_gen = 4L * 2 * (H / 32) * 3072;                  // generator LSTM exchange: 4 row groups x 2 parities, bf16 planes
+    const long xp_att = 2L * 64 * (Dm + H) * 4;                    // attention LSTM exchange [ctx | h]
+    const long eg = 64L * 4 * ((L + 127) / 128 * 128) * 8;         // partial-energy granules
+    return sync + xp_gen + xp_att + eg + 1024;
+}
+
+bool pgen_supported(const DecoderArgs& a) {
+    return persist_enabled() && a.fast && a.precision == 0 && a.H == 4 * PS_WGS && a.B >= 1 && a.B <= 64 && a.persist_ws &&
+           a.gen_w2p && a.gen_bias_u && a.pre_gen && a.persist_ws_bytes >= mtts_decoder_persist_ws_bytes(a.B, a.L, a.H, a.Dm, a.A);
+}
+
+unsigned long long* g_ps_prof = nullptr;      // timeline buffer of the micro-benchmark harness (NULL in the library)
+
+// generator LSTM steps [t0, t1) in one launch (h_gen[t0] / c_gen[t0] are the initial state)
+int pgen_launch(const DecoderArgs& a, int t0, int t1, hipStream_t s) {
+    MTTS_REQUIRE(pgen_supported(a), "pgen_launch: unsupported shape");
+    if (t1 <= t0) return 0;
+    PsGen p; memset(&p, 0, sizeof(p));
+    p.B = a.B; p.H = a.H; p.t0 = t0; p.t1 = t1;
+    p.w_packed = (const float*)a.gen_w2p; p.bias_u = a.gen_bias_u; p.pre = a.pre_gen;
+    p.h = a.h_gen; p.c = a.c_gen; p.gates = a.gates_gen;
+    if (a.zone) {
+        if (a.training) { p.cell.zone = 1; p.hmask = a.gen_hmask; p.cmask = a.gen_cmask; }
+        else { p.cell.zone = 2; p.cell.zh = a.p_hidden; p.cell.zc = a.p_cell; }
+    } else if (a.training && a.gen_hmask && a.p_hidden > 0.f) {
+        p.hmask = a.gen_hmask; p.cell.hscale = 1.f / (1.f - a.p_hidden);
+    }
+    char* ws = (char*)a.persist_ws;
+    p.sync.cnt = (unsigned*)ws; p.sync.err = (unsigned*)(ws + PS_ERR_OFF);
+    p.xp = (float*)(ws + PS_XP_OFF);
+    p.prof = g_ps_prof;
+    MTTS_CHECK_HIP(hipMemsetAsync(ws, 0, PS_ERR_OFF, s));           // counters (the error word is sticky until the host reads it)
+    const int RT = (a.B + 15) / 16;
+    static const int variant = [] { const char* e = getenv("MTTS_PGEN"); return e ? atoi(e) : 2; }();
+    if (variant != 1) {      // round-robin pipeline over the 16-row groups
+        size_t lds3 = (size_t)(a.H / 32) * 3072 + (size_t)RT * 8 * 256 * 4 + 64;
+#ifdef PS_PROF
+        lds3 += PS_PROF * 8;
+#endif
+#define PGEN3_GO(G)                                                                                                          \
+    {                                                                                                                        \
+        MTTS_CHECK_HIP(hipFuncSetAttribute((const void*)pgen3_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); \
+        hipLaunchKernelGGL((pgen3_kernel<G>), dim3(PS_WGS), dim3(PS_THREADS), lds3, s, p);                                   \
+    }
+        if (RT == 1) PGEN3_GO(1) else if (RT == 2) PGEN3_GO(2) else if (RT == 3) PGEN3_GO(3) else PGEN3_GO(4)
+#undef PGEN3_GO
+        MTTS_CHECK_LAUNCH("pgen3_kernel");
+        return 0;
+    }
+    const size_t lds = (size_t)(a.H / 32) * 2048 + 8 * 64 * 16 * 4;
+#define PGEN_GO(R)                                                                                                          \
+    {                                                                                                                       \
+        MTTS_CHECK_HIP(hipFuncSetAttribute((const void*)pgen_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(pgen_kernel<R>, dim3(PS_WGS), dim3(PS_THREADS), lds, s, p);                                      \
+    }
+    if (RT == 1) PGEN_GO(1) else if (RT == 2) PGEN_GO(2) else if (RT == 3) PGEN_GO(3) else PGEN_GO(4)
+#undef PGEN_GO
+    MTTS_CHECK_LAUNCH("pgen_kernel");
+    return 0;
+}
+
+// device error word of the last persistent launch on this workspace (0 = ok, 2 = a grid barrier timed out); synchronises
+MTTS_API int mtts_decoder_persist_status(const void* persist_ws, void* stream) {
+    unsigned v = 0;
+    if (hipMemcpyAsync(&v, (const char*)persist_ws + PS_ERR_OFF, 4, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return -1;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
+    return (int)v;
+}

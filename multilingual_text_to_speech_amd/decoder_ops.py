@@ -74,6 +74,12 @@ class DecoderState:
         self.att_w_hh_p = e(4 * H * H) if hp_ok else None
         self.gen_w_hh_p = e(4 * H * H) if hp_ok else None
         self.w_query_p = e(((A + 15) & ~15) * H) if hp_ok else None
+        # exchange / barrier workspace of the persistent recurrence kernels (csrc/persist.hip), zero-filled once
+        self.persist_ws = None
+        if fast:
+            lib().mtts_decoder_persist_ws_bytes.restype = ctypes.c_long
+            nb = int(lib().mtts_decoder_persist_ws_bytes(B, L, H, Dm, A))
+            self.persist_ws = torch.zeros(nb, dtype=torch.uint8, device=device)
         self._args = (B, L, dims, device, n_prenet, save_gates, fast, kq, precision)
 
     _PER_STEP = ('prenet_act', 'h_att', 'c_att', 'h_gen', 'c_gen', 'ctx', 'cum', 'align', 'gates_att', 'gates_gen', 'out', 'pre_att',
@@ -94,7 +100,7 @@ class DecoderState:
             else:
                 cur[:old.shape[0]].copy_(old)
         for name in ('U', 'Mt', 'PL', 'qpart', 'att_w_ctx_p', 'att_w_hh_p', 'gen_w_hh_p', 'w_query_p', 'att_w2p', 'att_bias_u', 'att_w_pre_u',
-                     'gate_part', 'gen_w2p', 'gen_bias_u', 'gen_w_ih_u', 'gate_part_gen', 'prenet_wp'):      # per-call constants
+                     'gate_part', 'gen_w2p', 'gen_bias_u', 'gen_w_ih_u', 'gate_part_gen', 'prenet_wp', 'persist_ws'):      # per-call constants
             setattr(new, name, getattr(self, name))
         return new
 
@@ -125,6 +131,8 @@ def fill_decoder_args(a, st, w, memory, lengths32, frames_in, teacher_host, mask
                  'w_query_p', 'att_w2p', 'att_bias_u', 'att_w_pre_u', 'gate_part', 'gen_w2p', 'gen_bias_u', 'gen_w_ih_u', 'gate_part_gen'):
         setattr(a, name, ptr(getattr(st, name)))
     a.kq, a.fast, a.precision = st.kq, int(st.fast), st.precision
+    ws = getattr(st, 'persist_ws', None)
+    a.persist_ws, a.persist_ws_bytes = ptr(ws), (ws.numel() if ws is not None else 0)
     return a
 
 
