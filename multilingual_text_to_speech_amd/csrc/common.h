@@ -133,5 +133,7 @@ int sum_slabs(const float* part, int n, long stride, int ldp, const float* bias,
 bool persist_enabled();
 bool pgen_supported(const DecoderArgs& a);
 int pgen_launch(const DecoderArgs& a, int t0, int t1, hipStream_t s);
+bool pdec_supported(const DecoderArgs& a);
+int pdec_launch(const DecoderArgs& a, int t0, int t1, hipStream_t s);
 int prenet2_launch(const float* x, int ldx, int Kin, const float* w1, const float* b1, const float* w2, const float* b2, const uint8_t* m1,
                    const uint8_t* m2, float scale, float* y1, float* y2, int B, int P, hipStream_t s);

@@ -222,7 +222,10 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
     const bool pg = a.fast && !fuse2 && gen_uses_lstep(a) && pgen_supported(a);
     hipStream_t sb = (a.fast && !fuse2 && !pg) ? side_stream(s) : nullptr;
     if (a.fast && !fuse2 && !pg && !sb) return mtts_fail("decoder: cannot create the side stream");
-    for (int t = a.t0; t < a.t1; ++t) {
+    // persistent attention LSTM + attention (persist.hip): chain A of the fast schedule as ONE launch
+    const bool pd = pg && use_ls && pdec_supported(a);
+    if (pd) MTTS_TRY(pdec_launch(a, a.t0, a.t1, s));
+    for (int t = a.t0; t < a.t1 && !pd; ++t) {
         if (fuse2 && t > a.t0 && ((t - a.t0) % CH) == 0) MTTS_TRY(gen_pre(a, t - CH, t, 0, s));      // input gates of the chunk chain B enters now
         const bool teach = a.frames_in && a.teacher && a.teacher[t];
         if (!teach) {

@@ -39,7 +39,7 @@ namespace {
 
 constexpr int PS_THREADS = 512;
 constexpr int PS_WGS = 256;                 // one workgroup per CU; 4 LSTM units (16 gate columns) each: H = 1024
-constexpr int PS_ERR_OFF = 4096, PS_XP_OFF = 8192;      // workspace: [counters: 4 groups x 8 x 128 B][error word][exchange ...]
+constexpr int PS_ERR_OFF = 8192, PS_XP_OFF = 16384;     // workspace: [counters: 4 groups x (1 + 8) x 128 B][error word][exchange ...]
 constexpr unsigned PS_SPIN_MAX = 1u << 22;  // ~0.5 s of polling before a barrier gives up (error word, no hang)
 #define PS_RLX __ATOMIC_RELAXED
 #define PS_AGENT __HIP_MEMORY_SCOPE_AGENT
@@ -70,6 +70,12 @@ union PsFrag { bf16x8 v; unsigned u[4]; };
 struct PsFrag3 { PsFrag p[3]; };
 __device__ __forceinline__ PsFrag3 ps_split8(const float4& lo, const float4& hi) {      // 8 consecutive k -> 3 bf16 planes
     PsFrag3 f;
+#if defined(PS_EXP) && PS_EXP == 3      // timing experiment (wrong numbers): no split arithmetic
+    f.p[0].u[0] = __float_as_uint(lo.x); f.p[0].u[1] = __float_as_uint(lo.y); f.p[0].u[2] = __float_as_uint(lo.z); f.p[0].u[3] = __float_as_uint(lo.w);
+    f.p[1].u[0] = __float_as_uint(hi.x); f.p[1].u[1] = __float_as_uint(hi.y); f.p[1].u[2] = __float_as_uint(hi.z); f.p[1].u[3] = __float_as_uint(hi.w);
+    f.p[2] = f.p[0];
+    return f;
+#endif
     ps_split_pair(lo.x, lo.y, f.p[0].u[0], f.p[1].u[0], f.p[2].u[0]);
     ps_split_pair(lo.z, lo.w, f.p[0].u[1], f.p[1].u[1], f.p[2].u[1]);
     ps_split_pair(hi.x, hi.y, f.p[0].u[2], f.p[1].u[2], f.p[2].u[2]);
@@ -105,6 +111,34 @@ __device__ __forceinline__ unsigned ps_xp_off(int row, int k, int nkb) {        
 // ---------------------------------------------------------------------------------------------------------------------------
 struct PsSync { unsigned* cnt; unsigned* err; };      // cnt[0] global, cnt[32 * (1 + g)] group g; err: device error word (0 = ok)
 
+
+// arrive half: every wave drains its write-through stores, one lane bumps the counters (call BEFORE issuing loads that need not be
+// complete at the barrier: the drain waits for everything this wave has in flight)
+__device__ __forceinline__ void ps_bar_arrive(const PsSync& s, unsigned epoch) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned nwg = gridDim.x, ng = 8, g = blockIdx.x % ng, gsz = nwg / ng;
+        const unsigned prev = __hip_atomic_fetch_add(s.cnt + 32 * (1 + g), 1u, PS_RLX, PS_AGENT);
+        if (prev + 1 == epoch * gsz) __hip_atomic_fetch_add(s.cnt, 1u, PS_RLX, PS_AGENT);
+    }
+}
+// wait half (thread 0 polls the top counter)
+__device__ __forceinline__ bool ps_bar_wait(const PsSync& s, unsigned epoch) {
+    if (threadIdx.x == 0) {
+        const unsigned target = epoch * 8u;
+        unsigned spins = 0;
+        while (__hip_atomic_load(s.cnt, PS_RLX, PS_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 1023u) == 0 && (spins > PS_SPIN_MAX || __hip_atomic_load(s.err, PS_RLX, PS_AGENT) != 0)) {
+                __hip_atomic_store(s.err, 2u, PS_RLX, PS_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    return __hip_atomic_load(s.err, PS_RLX, PS_AGENT) == 0;
+}
 
 __device__ __forceinline__ bool ps_barrier(const PsSync& s, unsigned epoch) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -157,15 +191,21 @@ __device__ __forceinline__ void ps_gates(__amdgpu_buffer_rsrc_t xr, int nkb, con
     f32x4 acc[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // (MFMA and split VALU of one SIMD do not overlap on gfx950 with 16x16x32 tiles - measured with software-pipelined and with
+    //  hand-interleaved streams: their times add, 8.2k + 5.4k cycles per phase at K = 1568, B = 64 - so the loop stays simple.)
 #pragma unroll
     for (int j = 0; j < NBW; ++j) {
         const int kb = min(k0 + j, nkb - 1);
-        const float4 w0 = wl[(kb * 2 + 0) * 64 + lane], w1 = wl[(kb * 2 + 1) * 64 + lane];
-        const PsFrag3 wb = ps_split8(w0, w1);
+        const PsFrag3 wb = ps_split8(wl[(kb * 2 + 0) * 64 + lane], wl[(kb * 2 + 1) * 64 + lane]);
+        // two row tiles at a time: their six-term chains alternate, so no MFMA waits for the one issued just before it
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            const PsFrag3 a = ps_split8(xa[j % DEPTH][rt][0], xa[j % DEPTH][rt][1]);
-            acc[rt] = ps_mma6(a, wb, acc[rt]);
+        for (int r0 = 0; r0 < RT; r0 += 2) {
+            PsFrag3 a[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) a[m] = ps_split8(xa[j % DEPTH][min(r0 + m, RT - 1)][0], xa[j % DEPTH][min(r0 + m, RT - 1)][1]);
+#define PS_MM(PA, PB) _Pragma("unroll") for (int m = 0; m < 2; ++m) if (r0 + m < RT) acc[r0 + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m].p[PA].v, wb.p[PB].v, acc[r0 + m], 0, 0, 0);
+            PS_MM(2, 0) PS_MM(0, 2) PS_MM(1, 1) PS_MM(1, 0) PS_MM(0, 1) PS_MM(0, 0)
+#undef PS_MM
         }
         if (j + DEPTH < NBW) { issue(j + DEPTH, j % DEPTH); __builtin_amdgcn_sched_barrier(0); }
     }
@@ -327,6 +367,9 @@ __device__ __forceinline__ bool ps_wait(const PsBar2& b, int g, unsigned target)
 #else
 #define PS_PROF_WORDS 0
 #endif
+#ifdef PS_PROF
+__device__ unsigned long long* g_ps_prof_dev = nullptr;
+#endif
 #ifdef PS_PROF      // micro-benchmark builds only: workgroup 0 stamps the shader clock into LDS (no VMEM traffic), dumped at exit
 #define PS_STAMP(buf, slot, who) do { if (blockIdx.x == 0 && (who) && (slot) < PS_PROF) (buf)[slot] = __builtin_readcyclecounter(); } while (0)
 #else
@@ -348,6 +391,9 @@ __device__ __forceinline__ void ps_xq_store4(__amdgpu_buffer_rsrc_t r, int i16, 
     unsigned a[3], b[3];
     ps_split_pair(v.x, v.y, a[0], a[1], a[2]);
     ps_split_pair(v.z, v.w, b[0], b[1], b[2]);
+#if defined(PS_EXP) && PS_EXP == 1      // timing experiment (wrong layout): one 16-byte store per row instead of three 8-byte ones
+    { u32x4 w; w.x = a[0]; w.y = b[0]; w.z = a[1]; w.w = b[1]; __builtin_amdgcn_raw_buffer_store_b128(w, r, ps_xq_off(i16, k & ~7, 0), 0, 16); return; }
+#endif
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
         typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
@@ -589,6 +635,505 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// pgen4: dataflow form of the pipelined recurrence.  Workgroup = 8 MULTIPLIER waves + one SERVICE wave per 16-row group (12 waves):
+//   multiplier wave w  owns the k-blocks [nkb w / 8, nkb (w + 1) / 8) for good: its weight planes (bf16 x 3) live in its REGISTERS for
+//                      the whole decode (no LDS or global weight traffic per step at all); per group-step it multiplies the prefetched
+//                      fragments, refills each fragment register with the next group-step's data the moment its MFMAs are issued,
+//                      leaves its partial sums in LDS and bumps the group's `done` counter (LDS atomic);
+//   service wave g     waits for done[g] (LDS), runs the LSTM cell of its 16 rows x 4 units, publishes h (XQ planes, write-through),
+//                      drains, arrives at the group's grid counters, polls them and posts `seen[g]` (LDS) when the publish has landed
+//                      from every workgroup - the multipliers only ever look at LDS.
+// No s_barrier after start-up: every wait is a data-flow condition, so the grid-barrier latency of one row group is covered by the
+// other groups' arithmetic.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int PS4_THREADS = 768;
+
+template <int NG>
+__global__ __launch_bounds__(PS4_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void pgen4_kernel(PsGen p) {
+    extern __shared__ __attribute__((aligned(16))) char psm[];
+    constexpr int NBW = 4;                                    // k-blocks per multiplier wave (nkb = 32)
+    const int tid = threadIdx.x, lane = tid & 63, c = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = p.H, B = p.B, nkb = H >> 5, N = 4 * H;
+    float* red = reinterpret_cast<float*>(psm);                                        // [NG][8][16][16]
+    volatile unsigned* done = reinterpret_cast<volatile unsigned*>(red + NG * 8 * 256);   // [4]  multiplier waves finished, per group (monotonic)
+    volatile unsigned* seen = done + 4;                                                // [4]  publish number that has landed, per group
+    volatile unsigned* lerr = done + 8;
+#ifdef PS_PROF
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(const_cast<unsigned*>(done) + 16);
+#endif
+    const PsBar2 bar{p.sync.cnt, p.sync.err};
+    if (tid < 12) done[tid] = 0;
+    __syncthreads();
+    const unsigned per_pub = PS_WGS / 8;
+    const int n_steps = p.t1 - p.t0, n_gs = n_steps * NG;
+    const unsigned xg_bytes = (unsigned)(nkb * 3072);
+    auto xregion = [&](int g, int par) { return ps_rsrc(reinterpret_cast<char*>(p.xp) + (size_t)(g * 2 + par) * xg_bytes, xg_bytes); };
+
+    if (wave >= 8) {
+        // =========================== service wave of row group g ===========================
+        const int g = wave - 8;
+        if (g >= NG) return;
+        const int rl = lane >> 2, uu = lane & 3, u = 4 * c + uu, row = 16 * g + rl;
+        const bool valid = row < B;
+        const int rowc = valid ? row : 0;
+        const float4 bias4 = *reinterpret_cast<const float4*>(p.bias_u + 4 * u);
+        float c_state = valid ? p.c[((size_t)p.t0 * B + row) * H + u] : 0.f;
+        float h_state = valid ? p.h[((size_t)p.t0 * B + row) * H + u] : 0.f;
+        // Two-level arrive (as ps_barrier): the counters that take 32 atomics per publish are polled by nobody; the polled word
+        // (top counter of the group) takes 8.  sub[g][x] = cnt[(g * 9 + 1 + x) * 32], top[g] = cnt[g * 9 * 32].
+        unsigned* top = bar.cnt + (g * 9) * 32;
+        unsigned* sub = bar.cnt + (g * 9 + 1 + (blockIdx.x & 7)) * 32;
+        auto arrive = [&](unsigned pub) {
+            if (lane == 0) {
+                const unsigned prev = __hip_atomic_fetch_add(sub, 1u, PS_RLX, PS_AGENT);
+                if (prev + 1 == pub * per_pub) __hip_atomic_fetch_add(top, 1u, PS_RLX, PS_AGENT);
+            }
+        };
+        auto land = [&](unsigned pub) -> bool {      // wait until publish `pub` of this group has arrived everywhere, then tell the multipliers
+            unsigned spins = 0;
+            while (__hip_atomic_load(top, PS_RLX, PS_AGENT) < pub * 8u) {
+                __builtin_amdgcn_s_sleep(1);
+                if ((++spins & 1023u) == 0 && (spins > PS_SPIN_MAX || __hip_atomic_load(bar.err, PS_RLX, PS_AGENT) != 0)) {
+                    if (lane == 0) { __hip_atomic_store(bar.err, 2u, PS_RLX, PS_AGENT); *lerr = 1; }
+                    return false;
+                }
+            }
+            if (lane == 0) seen[g] = pub;
+            return true;
+        };
+        {
+            const float4 h4 = ps_quad_gather(h_state);
+            if (valid && uu == 0) ps_xq_store4(xregion(g, p.t0 & 1), rl, 4 * c, h4);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            arrive(1u);
+            if (!land(1u)) return;
+        }
+        for (int s = 0; s < n_steps; ++s) {
+            const int t = p.t0 + s;
+            const float4 pre4 = *reinterpret_cast<const float4*>(p.pre + ((size_t)t * B + rowc) * N + 4 * u);
+            const size_t mo = ((size_t)t * B + rowc) * H + u;
+            const unsigned hm = p.hmask ? (unsigned)p.hmask[mo] : 1u, cm = p.cmask ? (unsigned)p.cmask[mo] : 1u;
+            {   // the eight partial sums of this group-step are in LDS
+                unsigned spins = 0;
+                while (done[g] < 8u * (unsigned)(s + 1)) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (*lerr != 0 || ++spins > (PS_SPIN_MAX << 2)) { if (lane == 0) { *lerr = 1; __hip_atomic_store(bar.err, 2u, PS_RLX, PS_AGENT); } return; }
+                }
+            }
+            PS_STAMP(stamps, 512 + 4 * s + 0, g == 0 && lane == 0);
+            const float* redg = red + g * (8 * 256);
+            float4 g4 = bias4;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const float4 v = *reinterpret_cast<const float4*>(redg + w * 256 + rl * 16 + 4 * uu);
+                g4.x += v.x; g4.y += v.y; g4.z += v.z; g4.w += v.w;
+            }
+            g4.x += pre4.x; g4.y += pre4.y; g4.z += pre4.z; g4.w += pre4.w;
+            const float ig = sigmoidf_(g4.x), fg = sigmoidf_(g4.y), gg = tanhf_(g4.z), og = sigmoidf_(g4.w);
+            const float cp = c_state, hp = h_state;
+            const float cn = fg * cp + ig * gg;
+            const float hn = og * tanhf_(cn);
+            float ho, co = cn;
+            if (p.cell.zone == 1) { ho = hm ? hn : hp; co = cm ? cn : cp; }
+            else if (p.cell.zone == 2) { ho = p.cell.zh * hp + (1.f - p.cell.zh) * hn; co = p.cell.zc * cp + (1.f - p.cell.zc) * cn; }
+            else ho = p.hmask ? (hm ? hn * p.cell.hscale : 0.f) : hn;
+            c_state = co; h_state = ho;
+            const float4 h4 = ps_quad_gather(h_state);
+            if (valid && uu == 0) ps_xq_store4(xregion(g, (t + 1) & 1), rl, 4 * c, h4);
+            PS_STAMP(stamps, 512 + 4 * s + 1, g == 0 && lane == 0);
+            if (s + 1 < n_steps) {      // exchange first: drain the write-through stores, arrive; the saved state follows
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                arrive((unsigned)(s + 2));
+            }
+            PS_STAMP(stamps, 512 + 4 * s + 2, g == 0 && lane == 0);
+            if (valid) {
+                const size_t o = ((size_t)(t + 1) * B + row) * H + u;
+                if (uu == 0) *reinterpret_cast<float4*>(p.h + o) = h4;
+                p.c[o] = c_state;
+                if (p.gates) {
+                    float* go = p.gates + ((size_t)t * B + row) * N + u;
+                    go[0] = ig; go[H] = fg; go[2 * H] = gg; go[3 * H] = og;
+                }
+            }
+            if (s + 1 < n_steps && !land((unsigned)(s + 2))) return;
+            PS_STAMP(stamps, 512 + 4 * s + 3, g == 0 && lane == 0);
+        }
+#ifdef PS_PROF
+        if (p.prof && blockIdx.x == 0 && g == 0) for (int i = 512 + lane; i < PS_PROF; i += 64) p.prof[i] = stamps[i];
+#endif
+        return;
+    }
+
+    // =========================== multiplier wave ===========================
+    const int k0 = (nkb * wave) >> 3, k1 = (nkb * (wave + 1)) >> 3;
+    PsFrag wreg[NBW][3];
+    {
+        const float4* src = reinterpret_cast<const float4*>(p.w_packed) + (size_t)c * nkb * 128;
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            const int kb = min(k0 + j, nkb - 1);
+            const PsFrag3 f = ps_split8(src[(kb * 2 + 0) * 64 + lane], src[(kb * 2 + 1) * 64 + lane]);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) wreg[j][pl] = f.p[pl];
+        }
+    }
+    auto wait_seen = [&](int g, unsigned pub) -> bool {
+        unsigned spins = 0;
+        while (seen[g] < pub) {
+            __builtin_amdgcn_s_sleep(1);
+            if (*lerr != 0 || ++spins > (PS_SPIN_MAX << 2)) { *lerr = 1; return false; }
+        }
+        return true;
+    };
+    PsLoads<NBW> buf;
+    if (n_gs > 0) {
+        if (!wait_seen(0, 1u)) return;
+        ps_issue16<NBW>(buf, xregion(0, p.t0 & 1), k0, k1, lane);
+    }
+    const int i16 = lane & 15, q4 = lane >> 4;
+    for (int i = 0; i < n_gs; ++i) {
+        const int g = i % NG, in = i + 1, gn = in % NG, tn = p.t0 + in / NG;
+        const bool has_next = in < n_gs;
+        const unsigned pubn = (unsigned)(in / NG + 1);
+#if defined(PS_EXP) && PS_EXP == 2      // timing experiment: never refill between the MFMAs
+        const bool early = false;
+#else
+        const bool early = has_next && seen[gn] >= pubn;
+#endif
+        const __amdgpu_buffer_rsrc_t nxr = xregion(gn, tn & 1);
+        PS_STAMP(stamps, 2 * i, tid == 64 * 5);
+        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            PsFrag a[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) { a[pl].u[0] = buf.x[j][pl].x; a[pl].u[1] = buf.x[j][pl].y; a[pl].u[2] = buf.x[j][pl].z; a[pl].u[3] = buf.x[j][pl].w; }
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2].v, wreg[j][0].v, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0].v, wreg[j][2].v, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1].v, wreg[j][1].v, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1].v, wreg[j][0].v, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0].v, wreg[j][1].v, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0].v, wreg[j][0].v, acc1, 0, 0, 0);
+            if (early) ps_issue_block<NBW>(buf, j, nxr, k0, k1, lane);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float* rw = red + (g * 8 + wave) * 256;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rw[(4 * q4 + r) * 16 + i16] = acc0[r] + acc1[r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(const_cast<unsigned*>(done) + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        PS_STAMP(stamps, 2 * i + 1, tid == 64 * 5);
+        if (has_next && !early) {
+            if (!wait_seen(gn, pubn)) return;
+            ps_issue16<NBW>(buf, nxr, k0, k1, lane);
+        }
+    }
+#ifdef PS_PROF
+    if (p.prof && blockIdx.x == 0 && wave == 5) for (int i = lane; i < 512; i += 64) p.prof[i] = stamps[i];
+#endif
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// pdec: attention LSTM + location-sensitive attention of the teacher-forced schedule, all steps in one launch (B <= 64).
+// Per step two phases with one grid barrier after each (see the file header):
+//   phase 1  every workgroup in its COLUMN role (LSTM units [4c, 4c+4)): gates over K = Dm + H from the exchange buffer [ctx_t | h_t]
+//            (weights fp32 in LDS, exact 3-way bf16 split products), cell, h_{t+1} -> row-major (write-through) + exchange layout
+//   phase 2  workgroups (b, j), b < B, in their SAMPLE role: query slice q[32j .. 32j+32) = W_q h_{t+1}[b] (W_q slice streamed from L2
+//            into registers behind the barrier), location features on MFMA, partial energies over the 32 channels, 4-way exchange of the
+//            partial energies through tagged granules, softmax (every workgroup of the sample computes the same weights in the same
+//            order), cumulative alignment kept in LDS, context columns [j Dm/4, (j+1) Dm/4) -> row-major + exchange layout
+// ---------------------------------------------------------------------------------------------------------------------------
+struct PsDec {
+    int B, L, H, A, Dm, ksz, t0, t1;
+    const float* w_packed;      // mtts_lstm_pack_weights(fp32) of [W_ih[:, P:] | W_hh]
+    const float* bias_u;        // [4H] unit-major
+    const float* pre;           // [T][B][4H] unit-major hoisted prenet projection
+    float* h; float* c;         // [T+1][B][H]
+    float* gates;               // [T][B][4H] or NULL
+    const uint8_t* hmask; const uint8_t* cmask;
+    PsCellCfg cell;
+    const float* w_query;       // [A][H]
+    const float* memory;        // [B][L][Dm]
+    const float* Mt;            // [B][L][A]
+    const float* U;             // [A][ksz]
+    const float* att_bias; const float* v;      // [A]
+    const int* lengths;         // [B]
+    float* ctx;                 // [T+1][B][Dm]
+    float* cum;                 // [T+1][B][L]
+    float* align;               // [T][B][L]
+    float* q_all;               // [T][B][A] or NULL
+    float* xp;                  // [2][64 rows][Dm + H] exchange (XP layout)
+    unsigned long long* eg;     // [64][4][128] partial-energy granules {tag, value}
+    PsSync sync;
+};
+
+constexpr int PD_LMAX = 128;         // encoder positions (8 waves x 16 rows)
+constexpr int PD_NCM = 9;            // memory float4 per thread in the context phase
+
+template <int RT>
+__global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void pdec_kernel(PsDec p) {
+    extern __shared__ __attribute__((aligned(16))) char psm[];
+    const int tid = threadIdx.x, lane = tid & 63, c = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = p.H, B = p.B, L = p.L, A = p.A, Dm = p.Dm, K = Dm + H, nkb = K >> 5, N = 4 * H;
+    const int pad = (p.ksz - 1) >> 1;
+    // ---- LDS carve
+    float4* wl = reinterpret_cast<float4*>(psm);                                       // [nkb][2][64] float4
+    float* red = reinterpret_cast<float*>(psm + (size_t)nkb * 2048);                    // [8][64][16] (phase 1) / scratch (phase 2)
+    float* Mt_s = red + 8 * 64 * 16;                                                    // [PD_LMAX][32]
+    float* cumw = Mt_s + PD_LMAX * 32;                                                  // [PD_LMAX + 64] cumulative alignment with zero halo
+    uint4* Upl = reinterpret_cast<uint4*>(cumw + PD_LMAX + 64);                         // [2 col tiles][3 planes][64 lanes]
+    float* vb = reinterpret_cast<float*>(Upl + 2 * 3 * 64);                             // v[32], bias[32]
+    // phase-2 scratch inside `red`
+    float* hs = red;                                   // [H] query operand: the sample's h row
+    float* qs = hs + 1024;                             // [32]
+    float* es = qs + 32;                               // [4][PD_LMAX] partial energies of the four slices
+    float* wsm = es + 4 * PD_LMAX;                     // [PD_LMAX] alignment weights
+    float* ctxp = wsm + PD_LMAX;                       // [ng][Dq] context partial sums
+#ifdef PS_PROF
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(vb + 64);
+#endif
+#define PD_STAMP(k) PS_STAMP(stamps, 10 * (t - p.t0) + (k), tid == 0 && (t - p.t0) < 30)
+
+    // ---- roles
+    const int row = tid >> 2, uu = tid & 3, u = 4 * c + uu;          // column role: cell thread (row, unit), tid < 4 B
+    const bool cellthr = tid < 4 * B;
+    const int rowc = cellthr ? row : 0;
+    const int sb = c >> 2, sj = c & 3;                                 // sample role: sample sb, slice sj
+    const bool has_sample = sb < B;
+    const int sbc = has_sample ? sb : 0;
+    const int Dq = Dm >> 2, d0 = sj * Dq, nc4 = Dq >> 2, ng = PS_THREADS / nc4;
+    const int len = min(p.lengths[sbc], L);
+    const unsigned xp_bytes = (unsigned)(64 * K * 4);
+    auto xregion = [&](int par) { return ps_rsrc(p.xp + (size_t)par * 64 * K, xp_bytes); };
+
+    // ---- stationary data -> LDS
+    {
+        const float4* src = reinterpret_cast<const float4*>(p.w_packed) + (size_t)c * nkb * 128;
+        for (int i = tid; i < nkb * 128; i += PS_THREADS) wl[i] = src[i];
+        for (int i = tid; i < L * 32; i += PS_THREADS) { const int l = i >> 5, a = i & 31; Mt_s[i] = p.Mt[((size_t)sbc * L + l) * A + 32 * sj + a]; }
+        for (int i = tid; i < PD_LMAX + 64; i += PS_THREADS) {
+            const int l = i - pad;
+            cumw[i] = (has_sample && l >= 0 && l < L) ? p.cum[((size_t)p.t0 * B + sb) * L + l] : 0.f;
+        }
+        if (tid < 2 * 64) {      // location filter bank slice as MFMA B fragments: lane (i16 = channel, q4) holds taps 8 q4 .. 8 q4 + 7
+            const int ct = tid >> 6, l2 = tid & 63, a = 32 * sj + 16 * ct + (l2 & 15), q4 = l2 >> 4;
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const int k = 8 * q4 + e; f[e] = k < p.ksz ? p.U[(size_t)a * p.ksz + k] : 0.f; }
+            const PsFrag3 fr = ps_split8(make_float4(f[0], f[1], f[2], f[3]), make_float4(f[4], f[5], f[6], f[7]));
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) Upl[(ct * 3 + pl) * 64 + l2] = make_uint4(fr.p[pl].u[0], fr.p[pl].u[1], fr.p[pl].u[2], fr.p[pl].u[3]);
+        }
+        if (tid < 32) { vb[tid] = p.v[32 * sj + tid]; vb[32 + tid] = p.att_bias[32 * sj + tid]; }
+    }
+    float c_state = 0.f, h_state = 0.f;
+    const float4 bias4 = *reinterpret_cast<const float4*>(p.bias_u + 4 * u);
+    if (cellthr) {
+        c_state = p.c[((size_t)p.t0 * B + row) * H + u];
+        h_state = p.h[((size_t)p.t0 * B + row) * H + u];
+    }
+    {   // exchange buffer of step t0: [ctx[t0] | h[t0]]
+        const float4 h4 = ps_quad_gather(h_state);
+        if (cellthr && uu == 0) ps_st16_sc1(xregion(p.t0 & 1), ps_xp_off(row, Dm + 4 * c, nkb), h4);
+        if (has_sample && tid < nc4) {
+            const float4 c4v = *reinterpret_cast<const float4*>(p.ctx + ((size_t)p.t0 * B + sb) * Dm + d0 + 4 * tid);
+            ps_st16_sc1(xregion(p.t0 & 1), ps_xp_off(sb, d0 + 4 * tid, nkb), c4v);
+        }
+    }
+    unsigned epoch = 0;
+    if (!ps_barrier(p.sync, ++epoch)) return;
+
+    for (int t = p.t0; t < p.t1; ++t) {
+        // ================= phase 1: attention LSTM (column role) =================
+        const float4 pre4 = *reinterpret_cast<const float4*>(p.pre + ((size_t)t * B + rowc) * N + 4 * u);
+        const size_t mo = ((size_t)t * B + rowc) * H + u;
+        const unsigned hm = p.hmask ? (unsigned)p.hmask[mo] : 1u, cm = p.cmask ? (unsigned)p.cmask[mo] : 1u;
+        PD_STAMP(0);
+        ps_gates<7, RT, 3>(xregion(t & 1), nkb, wl, red);
+        PD_STAMP(1);
+        __syncthreads();
+        float4 ga;
+        if (cellthr) ps_cell(red, row, uu, bias4, pre4, c_state, h_state, (int)hm, (int)cm, p.hmask != nullptr, p.cell, ga);
+        {
+            const float4 h4 = ps_quad_gather(h_state);
+            if (cellthr && uu == 0) {
+                ps_st16_sc1(xregion((t + 1) & 1), ps_xp_off(row, Dm + 4 * c, nkb), h4);
+                // row-major copy (write-through): the sample role reads rows of it after the barrier
+                ps_st16_sc1(ps_rsrc(p.h + (size_t)(t + 1) * B * H, (unsigned)(B * H * 4)), (unsigned)((row * H + u) * 4), h4);
+            }
+        }
+        PD_STAMP(2);
+        ps_bar_arrive(p.sync, ++epoch);
+        // operands of phase 2 that do not depend on h_{t+1}: requested behind the arrive, landing while the barrier completes.
+        // query weights (streamed from L2 every step: neither LDS nor the register file has 128 KiB to spare beside phase 1):
+        // lane (a = tid >> 4, l16 = tid & 15) takes k = 64 i + 4 l16 .. + 4, i.e. 256 contiguous bytes per channel and load
+        float4 wq4[16];
+        {
+            const float* wq = p.w_query + (size_t)(32 * sj + (tid >> 4)) * H + 4 * (tid & 15);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) wq4[i] = *reinterpret_cast<const float4*>(wq + 64 * i);
+        }
+        float4 mem4[PD_NCM];
+        {
+            const int c4 = tid % nc4, lg = tid / nc4;
+            const float* mem = p.memory + (size_t)sbc * L * Dm + d0 + 4 * c4;
+#pragma unroll
+            for (int i = 0; i < PD_NCM; ++i) {
+                const int l = min(lg + i * ng, L - 1);
+                mem4[i] = *reinterpret_cast<const float4*>(mem + (size_t)l * Dm);
+            }
+        }
+        if (cellthr) {
+            const size_t o = ((size_t)(t + 1) * B + row) * H + u;
+            p.c[o] = c_state;
+            if (p.gates) {
+                float* go = p.gates + ((size_t)t * B + row) * N + u;
+                go[0] = ga.x; go[H] = ga.y; go[2 * H] = ga.z; go[3 * H] = ga.w;
+            }
+        }
+        if (!ps_bar_wait(p.sync, epoch)) return;
+        PD_STAMP(3);
+
+        // ================= phase 2: attention (sample role) =================
+        if (has_sample) {
+            // ---- h_{t+1}[sb] -> LDS (16 chunks of 64 with 4 floats of padding: conflict-free reads below)
+            {
+                const __amdgpu_buffer_rsrc_t hr = ps_rsrc(p.h + ((size_t)(t + 1) * B + sb) * H, (unsigned)(H * 4));
+                if (tid < (H >> 2)) *reinterpret_cast<float4*>(hs + 4 * tid) = ps_ld16_sc1(hr, tid * 16);
+            }
+            __syncthreads();
+            // ---- query slice: thread (a = tid >> 4, chunk = tid & 15)
+            {
+                const float* hc = hs + 4 * (tid & 15);
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float4 h4 = *reinterpret_cast<const float4*>(hc + 64 * i);
+                    acc += wq4[i].x * h4.x + wq4[i].y * h4.y + wq4[i].z * h4.z + wq4[i].w * h4.w;
+                }
+                acc = row16_sum(acc);
+                if ((tid & 15) == 0) {
+                    qs[tid >> 4] = acc;
+                    if (p.q_all) p.q_all[((size_t)t * B + sb) * A + 32 * sj + (tid >> 4)] = acc;
+                }
+            }
+            __syncthreads();
+            PD_STAMP(4);
+            // ---- location features (MFMA, exact split) + partial energies: wave w <-> positions [16 w, 16 w + 16)
+            {
+                const int i16 = lane & 15, q4 = lane >> 4, l0 = 16 * wave;
+                float f[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = cumw[l0 + i16 + 8 * q4 + e];
+                const PsFrag3 af = ps_split8(make_float4(f[0], f[1], f[2], f[3]), make_float4(f[4], f[5], f[6], f[7]));
+                float e4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    PsFrag3 bf;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        const uint4 w = Upl[(ct * 3 + pl) * 64 + lane];
+                        bf.p[pl].u[0] = w.x; bf.p[pl].u[1] = w.y; bf.p[pl].u[2] = w.z; bf.p[pl].u[3] = w.w;
+                    }
+                    const f32x4 loc = ps_mma6(af, bf, (f32x4){0.f, 0.f, 0.f, 0.f});
+                    const int a = 16 * ct + i16;
+                    const float qa = qs[a] + vb[32 + a], va = vb[a];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int l = min(l0 + 4 * q4 + r, PD_LMAX - 1);
+                        e4[r] += va * tanhf_(qa + Mt_s[l * 32 + a] + loc[r]);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = row16_sum(e4[r]);
+                    const int l = l0 + 4 * q4 + r;
+                    if (i16 == 0 && l < L) {
+                        es[sj * PD_LMAX + l] = e;
+                        __hip_atomic_store(p.eg + ((size_t)(sb * 4 + sj)) * PD_LMAX + l, ((unsigned long long)epoch << 32) | __float_as_uint(e), PS_RLX, PS_AGENT);
+                    }
+                }
+            }
+            PD_STAMP(5);
+            // ---- the other three slices' partial energies (tagged granules: the data is the flag)
+            if (tid < 3 * PD_LMAX) {
+                const int o = tid / PD_LMAX, l = tid - o * PD_LMAX, j2 = o + (o >= sj ? 1 : 0);
+                if (l < L) {
+                    unsigned long long* gp = p.eg + ((size_t)(sb * 4 + j2)) * PD_LMAX + l;
+                    unsigned long long x = __hip_atomic_load(gp, PS_RLX, PS_AGENT);
+                    unsigned spins = 0;
+                    while ((unsigned)(x >> 32) != epoch) {
+                        __builtin_amdgcn_s_sleep(1);
+                        x = __hip_atomic_load(gp, PS_RLX, PS_AGENT);
+                        if (++spins > PS_SPIN_MAX) { __hip_atomic_store(p.sync.err, 2u, PS_RLX, PS_AGENT); break; }
+                    }
+                    es[j2 * PD_LMAX + l] = __uint_as_float((unsigned)x);
+                }
+            }
+            __syncthreads();
+            PD_STAMP(6);
+            // ---- masked softmax over the positions (wave 0), cumulative alignment
+            if (wave == 0) {
+                float e0[2], mx = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int l = lane + 64 * k;
+                    e0[k] = (l < L) ? ((es[l] + es[PD_LMAX + l]) + (es[2 * PD_LMAX + l] + es[3 * PD_LMAX + l])) : 0.f;
+                    if (l < len) mx = fmaxf(mx, e0[k]);
+                }
+                mx = wave_max(mx);
+                float sum = 0.f;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) { const int l = lane + 64 * k; e0[k] = (l < len) ? __expf(e0[k] - mx) : 0.f; sum += e0[k]; }
+                sum = wave_sum(sum);
+                const float inv = 1.f / sum;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int l = lane + 64 * k;
+                    if (l < L) {
+                        const float wl_ = e0[k] * inv, cn = cumw[pad + l] + wl_;
+                        wsm[l] = wl_; cumw[pad + l] = cn;
+                        if (sj == 0) { p.align[((size_t)t * B + sb) * L + l] = wl_; p.cum[((size_t)(t + 1) * B + sb) * L + l] = cn; }
+                    }
+                }
+            }
+            __syncthreads();
+            PD_STAMP(7);
+            // ---- context columns of this slice
+            {
+                const int c4 = tid % nc4, lg = tid / nc4;
+                float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < PD_NCM; ++i) {
+                    const int l = lg + i * ng;
+                    const float wl_ = (lg < ng && l < L) ? wsm[l] : 0.f;
+                    s4.x += wl_ * mem4[i].x; s4.y += wl_ * mem4[i].y; s4.z += wl_ * mem4[i].z; s4.w += wl_ * mem4[i].w;
+                }
+                if (lg < ng) *reinterpret_cast<float4*>(ctxp + (lg * nc4 + c4) * 4) = s4;
+            }
+            __syncthreads();
+            if (tid < nc4) {
+                float4 tt = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int k = 0; k < ng; ++k) { const float4 v4 = *reinterpret_cast<const float4*>(ctxp + (k * nc4 + tid) * 4); tt.x += v4.x; tt.y += v4.y; tt.z += v4.z; tt.w += v4.w; }
+                *reinterpret_cast<float4*>(p.ctx + ((size_t)(t + 1) * B + sb) * Dm + d0 + 4 * tid) = tt;
+                ps_st16_sc1(xregion((t + 1) & 1), ps_xp_off(sb, d0 + 4 * tid, nkb), tt);
+            }
+        }
+        PD_STAMP(8);
+        if (!ps_barrier(p.sync, ++epoch)) return;
+        PD_STAMP(9);
+    }
+#ifdef PS_PROF
+    if (g_ps_prof_dev && blockIdx.x == 0) for (int i = tid; i < 300; i += PS_THREADS) g_ps_prof_dev[i] = stamps[i];
+#endif
+#undef PD_STAMP
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -609,14 +1154,15 @@ bool persist_enabled() {
     return on && ps_device_ok();
 }
 
+// workspace layout (DecoderArgs.persist_ws): [counters 8 KiB][error word ...16 KiB][generator exchange][attention exchange][granules]
+static long ps_ws_gen_off() { return PS_XP_OFF; }
+static long ps_ws_att_off(int H) { return ps_ws_gen_off() + 8L * (H / 32) * 3072; }
+static long ps_ws_eg_off(int H, int Dm) { return ps_ws_att_off(H) + 2L * 64 * (Dm + H) * 4; }
+
 // bytes of the exchange / synchronisation workspace a decoder call hands to the persistent kernels (DecoderArgs.persist_ws)
 MTTS_API long mtts_decoder_persist_ws_bytes(int B, int L, int H, int Dm, int A) {
-    (void)B; (void)A;
-    const long sync = PS_XP_OFF;                                   // barrier counters + error word
-    const long xp_gen = 4L * 2 * (H / 32) * 3072;                  // generator LSTM exchange: 4 row groups x 2 parities, bf16 planes
-    const long xp_att = 2L * 64 * (Dm + H) * 4;                    // attention LSTM exchange [ctx | h]
-    const long eg = 64L * 4 * ((L + 127) / 128 * 128) * 8;         // partial-energy granules
-    return sync + xp_gen + xp_att + eg + 1024;
+    (void)B; (void)A; (void)L;
+    return ps_ws_eg_off(H, Dm) + 64L * 4 * PD_LMAX * 8 + 1024;
 }
 
 bool pgen_supported(const DecoderArgs& a) {
@@ -642,11 +1188,22 @@ int pgen_launch(const DecoderArgs& a, int t0, int t1, hipStream_t s) {
     }
     char* ws = (char*)a.persist_ws;
     p.sync.cnt = (unsigned*)ws; p.sync.err = (unsigned*)(ws + PS_ERR_OFF);
-    p.xp = (float*)(ws + PS_XP_OFF);
+    p.xp = (float*)(ws + ps_ws_gen_off());
     p.prof = g_ps_prof;
     MTTS_CHECK_HIP(hipMemsetAsync(ws, 0, PS_ERR_OFF, s));           // counters (the error word is sticky until the host reads it)
     const int RT = (a.B + 15) / 16;
     static const int variant = [] { const char* e = getenv("MTTS_PGEN"); return e ? atoi(e) : 2; }();
+    if (variant == 4 || variant == 2) {      // dataflow pipeline: 8 multiplier waves + one service wave per 16-row group
+        size_t lds4 = (size_t)RT * 8 * 256 * 4 + 64;
+#ifdef PS_PROF
+        lds4 += PS_PROF * 8;
+#endif
+#define PGEN4_GO(G) hipLaunchKernelGGL((pgen4_kernel<G>), dim3(PS_WGS), dim3(PS4_THREADS), lds4, s, p);
+        if (RT == 1) PGEN4_GO(1) else if (RT == 2) PGEN4_GO(2) else if (RT == 3) PGEN4_GO(3) else PGEN4_GO(4)
+#undef PGEN4_GO
+        MTTS_CHECK_LAUNCH("pgen4_kernel");
+        return 0;
+    }
     if (variant != 1) {      // round-robin pipeline over the 16-row groups
         size_t lds3 = (size_t)(a.H / 32) * 3072 + (size_t)RT * 8 * 256 * 4 + 64;
 #ifdef PS_PROF
@@ -671,6 +1228,56 @@ int pgen_launch(const DecoderArgs& a, int t0, int t1, hipStream_t s) {
     if (RT == 1) PGEN_GO(1) else if (RT == 2) PGEN_GO(2) else if (RT == 3) PGEN_GO(3) else PGEN_GO(4)
 #undef PGEN_GO
     MTTS_CHECK_LAUNCH("pgen_kernel");
+    return 0;
+}
+
+bool pdec_supported(const DecoderArgs& a) {
+    if (!(persist_enabled() && a.fast && a.precision == 0 && a.H == 4 * PS_WGS && a.A == 128 && a.B >= 1 && a.B <= 64 && a.L >= 1 && a.L <= PD_LMAX &&
+          a.persist_ws && a.att_w2p && a.att_bias_u && a.att_w_pre_u && a.pre_att && (a.Dm & 31) == 0 && (a.Dm + a.H) / 32 <= 56 &&
+          (a.ksz & 1) == 1 && a.ksz <= 32 && a.persist_ws_bytes >= mtts_decoder_persist_ws_bytes(a.B, a.L, a.H, a.Dm, a.A)))
+        return false;
+    static const bool off = [] { const char* e = getenv("MTTS_PDEC"); return e && e[0] == '0'; }();
+    if (off) return false;
+    const int nc4 = a.Dm / 16, ng = PS_THREADS / nc4;
+    return nc4 >= 1 && ng >= 1 && (a.L + ng - 1) / ng <= PD_NCM;
+}
+
+// attention LSTM + attention, steps [t0, t1) in one launch; needs U, Mt, pre_att and the packed weights of mtts_decoder_fwd's set-up
+int pdec_launch(const DecoderArgs& a, int t0, int t1, hipStream_t s) {
+    MTTS_REQUIRE(pdec_supported(a), "pdec_launch: unsupported shape");
+    if (t1 <= t0) return 0;
+    PsDec p; memset(&p, 0, sizeof(p));
+    p.B = a.B; p.L = a.L; p.H = a.H; p.A = a.A; p.Dm = a.Dm; p.ksz = a.ksz; p.t0 = t0; p.t1 = t1;
+    p.w_packed = (const float*)a.att_w2p; p.bias_u = a.att_bias_u; p.pre = a.pre_att;
+    p.h = a.h_att; p.c = a.c_att; p.gates = a.gates_att;
+    if (a.zone) {
+        if (a.training) { p.cell.zone = 1; p.hmask = a.att_hmask; p.cmask = a.att_cmask; }
+        else { p.cell.zone = 2; p.cell.zh = a.p_hidden; p.cell.zc = a.p_cell; }
+    } else if (a.training && a.att_hmask && a.p_hidden > 0.f) {
+        p.hmask = a.att_hmask; p.cell.hscale = 1.f / (1.f - a.p_hidden);
+    }
+    p.w_query = a.w_query; p.memory = a.memory; p.Mt = a.Mt; p.U = a.U; p.att_bias = a.att_bias; p.v = a.w_energy; p.lengths = a.lengths;
+    p.ctx = a.ctx; p.cum = a.cum; p.align = a.align; p.q_all = a.q_all;
+    char* ws = (char*)a.persist_ws;
+    p.sync.cnt = (unsigned*)ws; p.sync.err = (unsigned*)(ws + PS_ERR_OFF);
+    p.xp = (float*)(ws + ps_ws_att_off(a.H));
+    p.eg = (unsigned long long*)(ws + ps_ws_eg_off(a.H, a.Dm));
+    MTTS_CHECK_HIP(hipMemsetAsync(ws, 0, PS_ERR_OFF, s));
+    MTTS_CHECK_HIP(hipMemsetAsync(p.eg, 0, (size_t)64 * 4 * PD_LMAX * 8, s));
+    size_t lds = (size_t)((a.Dm + a.H) / 32) * 2048 + 8 * 64 * 16 * 4 + PD_LMAX * 32 * 4 + (PD_LMAX + 64) * 4 + 2 * 3 * 64 * 16 + 64 * 4;
+#ifdef PS_PROF
+    lds += 300 * 8;
+    MTTS_CHECK_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_ps_prof_dev), &g_ps_prof, sizeof(g_ps_prof), 0, hipMemcpyHostToDevice, s));
+#endif
+    const int RT = (a.B + 15) / 16;
+#define PDEC_GO(R)                                                                                                          \
+    {                                                                                                                       \
+        MTTS_CHECK_HIP(hipFuncSetAttribute((const void*)pdec_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(pdec_kernel<R>, dim3(PS_WGS), dim3(PS_THREADS), lds, s, p);                                      \
+    }
+    if (RT == 1) PDEC_GO(1) else if (RT == 2) PDEC_GO(2) else if (RT == 3) PDEC_GO(3) else PDEC_GO(4)
+#undef PDEC_GO
+    MTTS_CHECK_LAUNCH("pdec_kernel");
     return 0;
 }
 

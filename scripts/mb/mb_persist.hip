@@ -91,10 +91,47 @@ int main(int argc, char** argv) {
         printf("pgen  B=%d T=%d: %.3f ms = %.2f us per step (status %d)\n", B, T, ms, ms * 1e3 / T, mtts_decoder_persist_status(a.persist_ws, 0));
     }
 #ifdef PS_PROF
-    std::vector<unsigned long long> hp(PS_PROF); (void)hipMemcpy(hp.data(), prof, PS_PROF * 8, hipMemcpyDeviceToHost);
-    printf("workgroup 0 / wave 5, shader cycles per group-step (early issue | MFMA | late wait+issue, barrier | total):\n");
+    std::vector<unsigned long long> hp_gen(PS_PROF); (void)hipMemcpy(hp_gen.data(), prof, PS_PROF * 8, hipMemcpyDeviceToHost);
+#endif
+    // ---- pdec timing (random operands; parity is covered by the pytest suite)
+    {
+        const int P = 256, K = Dm + H;
+        a.T = T; a.P = P; a.ksz = 31; a.C = 32;
+        a.att_w2p = to_dev(host_rand((size_t)4 * H * K, 0.08f)); a.att_bias_u = to_dev(host_rand(4 * H, 0.2f)); a.att_w_pre_u = a.att_bias_u;
+        a.pre_att = to_dev(host_rand((size_t)T * B * 4 * H, 2.f));
+        a.h_att = dev_zero((size_t)(T + 1) * B * H); a.c_att = dev_zero((size_t)(T + 1) * B * H); a.gates_att = dev_zero((size_t)T * B * 4 * H);
+        a.w_query = to_dev(host_rand((size_t)A * H, 0.1f)); a.memory = to_dev(host_rand((size_t)B * L * Dm, 1.f)); a.Mt = to_dev(host_rand((size_t)B * L * A, 1.f));
+        a.U = to_dev(host_rand((size_t)A * 31, 0.3f)); a.att_bias = to_dev(host_rand(A, 0.1f)); a.w_energy = to_dev(host_rand(A, 0.5f));
+        std::vector<int> lens(B, L); int* dl; (void)hipMalloc(&dl, B * 4); (void)hipMemcpy(dl, lens.data(), B * 4, hipMemcpyHostToDevice); a.lengths = dl;
+        a.ctx = dev_zero((size_t)(T + 1) * B * Dm); a.cum = dev_zero((size_t)(T + 1) * B * L); a.align = dev_zero((size_t)T * B * L); a.q_all = dev_zero((size_t)T * B * A);
+        for (int rep = 0; rep < 3; ++rep) {
+            (void)hipEventRecord(e0, 0);
+            if (pdec_launch(a, 0, T, 0)) { printf("pdec_launch failed: %s\n", g_mtts_err); return 1; }
+            (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+            float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+            printf("pdec  B=%d T=%d: %.3f ms = %.2f us per step (status %d)\n", B, T, ms, ms * 1e3 / T, mtts_decoder_persist_status(a.persist_ws, 0));
+        }
+#ifdef PS_PROF
+        std::vector<unsigned long long> hq(PS_PROF); (void)hipMemcpy(hq.data(), prof, PS_PROF * 8, hipMemcpyDeviceToHost);
+        printf("pdec workgroup 0 / thread 0 (cycles): gates | cell+publish | barrier | h,q | energies | exchange | softmax | context | barrier || step\n");
+        for (int st = 20; st < 28; ++st) {
+            const unsigned long long* q = &hq[10 * st];
+            printf("  step %3d:", st);
+            for (int k = 0; k < 9; ++k) printf(" %6llu", q[k + 1] - q[k]);
+            printf(" || %6llu\n", q[10] - q[0]);
+        }
+#endif
+    }
+#ifdef PS_PROF
+    std::vector<unsigned long long>& hp = hp_gen;
+    printf("workgroup 0 / wave 5, shader cycles per group-step (MFMA + partial sums | wait + issue | total):\n");
     for (int i = 40; i < 52; ++i)
-        printf("  gs %3d: %6llu | %6llu | %6llu | %6llu\n", i, hp[4 * i + 1] - hp[4 * i], hp[4 * i + 2] - hp[4 * i + 1], hp[4 * i + 3] - hp[4 * i + 2], hp[4 * i + 4] - hp[4 * i]);
+        printf("  gs %3d: %6llu | %6llu | %6llu\n", i, hp[2 * i + 1] - hp[2 * i], hp[2 * i + 2] - hp[2 * i + 1], hp[2 * i + 2] - hp[2 * i]);
+    printf("service wave of group 0 (workgroup 0): wait for partial sums | cell + publish | drain + arrive | state stores + land | step\n");
+    for (int st = 20; st < 28; ++st) {
+        const unsigned long long* q = &hp[512 + 4 * st];
+        printf("  step %3d: %6llu | %6llu | %6llu | %6llu | %6llu\n", st, q[0] - q[-1], q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[0]);
+    }
 #endif
     return 0;
 }
