@@ -92,7 +92,19 @@ class FusedAdam(torch.optim.Adam):
         self._tables = {}
 
     def load_state_dict(self, state_dict):
-        super().load_state_dict(state_dict)
+        """torch.optim.Adam's state_dict, including one saved by the REFERENCE's two-group optimizer (train.py:261-270): its first
+        group lists the prenet / attention tensors twice (once through `_decoder`, once directly), so the packed `params` lists
+        repeat indices.  train.make_optimizer registers every tensor once, in the same first-occurrence order; dropping the repeated
+        indices makes the two layouts identical."""
+        groups = []
+        for g in state_dict['param_groups']:
+            seen, uniq = set(), []
+            for i in g['params']:
+                if i not in seen:
+                    seen.add(i)
+                    uniq.append(i)
+            groups.append(dict(g, params=uniq))
+        super().load_state_dict(dict(state_dict, param_groups=groups))
         self._tables = {}               # the moment buffers were replaced: the cached device tables point at freed memory
 
     def _table(self, name, plist):

@@ -594,3 +594,32 @@ def test_skinny_gemm_matches_torch_on_random_shapes(seed):
     ref = sum(x.double() @ w.double().t() for x, w in zip(xs, ws))
     got = out.double().sum(0) if ks > 1 else out[0].double() - bias.double()
     assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()), (B, N, [x.shape[1] for x in xs], ks)
+
+
+def test_fused_adam_two_groups_mixed_steps_match_torch():
+    """hp.encoder_optimizer layout (reference train.py:261-270): two parameter groups with their own learning rates, one global
+    clip coefficient over ALL parameters, and a parameter that receives no gradient in the first step (its bias-correction step
+    lags by one: the update then runs as one launch per (group, step value) table).  Against torch.optim.Adam + clip_grad_norm_."""
+    from multilingual_text_to_speech_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    shapes = [(300, 70), (5,), (70000,), (64, 33), (17,)]
+    base = [torch.randn(*s).cuda() for s in shapes]
+    p1 = [torch.nn.Parameter(p.clone()) for p in base]
+    p2 = [torch.nn.Parameter(p.clone()) for p in base]
+    groups = lambda ps: [{'params': ps[:3]}, {'params': ps[3:], 'lr': 3e-4}]
+    o1 = FusedAdam(groups(p1), lr=1e-3, weight_decay=1e-6)
+    o2 = torch.optim.Adam(groups(p2), lr=1e-3, weight_decay=1e-6)
+    for it in range(4):
+        gs = [torch.randn_like(p) * (3.0 if it % 2 == 0 else 0.01) for p in base]
+        for k, (a, b, gg) in enumerate(zip(p1, p2, gs)):
+            skip = it == 0 and k in (1, 4)                      # late starters in BOTH groups
+            a.grad, b.grad = (None, None) if skip else (gg.clone(), gg.clone())
+        norm = o1.step(max_norm=0.25)
+        ref_norm = torch.nn.utils.clip_grad_norm_([p for p in p2 if p.grad is not None], 0.25)
+        o2.step()
+        assert abs(norm[0].item() - ref_norm.item()) <= 1e-4 * ref_norm.item()
+        for k, (a, b) in enumerate(zip(p1, p2)):
+            assert (a - b).abs().max().item() <= 2e-6, (it, k)
+    for a, b in zip(p1, p2):
+        assert float(o1.state[a]['step']) == float(o2.state[b]['step'])
+        assert (o1.state[a]['exp_avg_sq'] - o2.state[b]['exp_avg_sq']).abs().max().item() <= 1e-7

@@ -83,3 +83,30 @@ def test_install_aliases_exposes_reference_import_names():
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+def test_fused_adam_loads_the_reference_two_group_state_dict():
+    """The reference builds its encoder_optimizer variant with the prenet / attention tensors listed twice in group 0
+    (train.py:261-270); its saved optimizer state must load into our de-duplicated FusedAdam (train.make_optimizer)."""
+    import warnings
+    import torch
+    from multilingual_text_to_speech_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    shared = [torch.nn.Parameter(torch.randn(3, 2)), torch.nn.Parameter(torch.randn(4))]
+    other = [torch.nn.Parameter(torch.randn(5)), torch.nn.Parameter(torch.randn(2, 2))]
+    enc = [torch.nn.Parameter(torch.randn(6))]
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        ref = torch.optim.Adam([{'params': shared + other + shared}, {'params': enc, 'lr': 3e-4}], lr=1e-3, weight_decay=1e-6)
+    for p in shared + other + enc:
+        p.grad = torch.randn_like(p)
+    ref.step()
+    sd = ref.state_dict()
+    assert len(sd['param_groups'][0]['params']) == 6          # duplicated indices as the reference saves them
+    mine = FusedAdam([{'params': shared + other}, {'params': enc, 'lr': 3e-4}], lr=1e-3, weight_decay=1e-6)
+    mine.load_state_dict(sd)
+    assert [len(g['params']) for g in mine.param_groups] == [4, 1]
+    assert mine.param_groups[1]['lr'] == 3e-4
+    for p in shared + other + enc:
+        assert torch.equal(mine.state[p]['exp_avg'], ref.state[p]['exp_avg'])
+        assert float(mine.state[p]['step']) == float(ref.state[p]['step'])      # (torch steps a twice-listed tensor twice)
