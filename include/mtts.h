@@ -698,8 +698,22 @@ float mtts_prof_empty_ms(void);
 
 const char* mtts_last_error(void);
 int mtts_version(void);
+/* Bitmask of timing-experiment compile switches baked into this library (1 = MTTS_DBG_SKIP_GEN_STEPS, 2 = MTTS_DBG_SKIP_WGRAD; such a
+ * build computes WRONG results on purpose).  0 for every production build. */
+int mtts_build_flags(void);
 /* sizeof() of the structs above in declaration order (0 = GemmArgs ... 6 = BiLstmArgs, 7 = AttnBwdArgs, 8 = DecoderGradArgs, 9 = BiLstmGradArgs, 10 = TacoLossArgs, 11 = AdamArgs, 12 = LstmPackArgs, 13 = LstmStepArgs, 14 = GenParamsArgs); -1 when out of range */
 int mtts_sizeof_struct(int which);
+
+
+/* ---- buffer-size queries -----------------------------------------------------------------------------------------------------
+ * ELEMENTS the caller must allocate for a caller-provided buffer of the argument blocks, by FIELD NAME (the struct member's
+ * name; per-layer arrays: "prenet_act", "prenet_mask", "prenet_wp0", "prenet_wp1", "prenet_w_T0" (first layer) / "prenet_w_T").
+ * Fill the shape fields first (DecoderArgs: B, L, T, M, P, H, A, Dm, ksz, C, n_prenet, kq, fast, precision; DecoderGradArgs: ksb,
+ * ksb_ctx, nch; BiLstmArgs: B, L, Cin, H).  Element = float, except att_w2p / gen_w2p / att_w_rec_T2p / persist_ws (bytes) and the
+ * keep-flag masks (uint8).  -1 = unknown field.  Replaces the size formulas a binding would otherwise copy from the comments. */
+long mtts_decoder_buffer_elems(const DecoderArgs* args, const char* field);
+long mtts_decoder_grad_buffer_elems(const DecoderArgs* fwd, const DecoderGradArgs* grad, const char* field);
+long mtts_bilstm_buffer_elems(const BiLstmArgs* args, int ksb, const char* field);
 
 #ifdef __cplusplus
 }

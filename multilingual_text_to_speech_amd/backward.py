@@ -46,60 +46,66 @@ def decoder_bwd(ctx, dspec, dstop, dalign):
     import os
     ksb = int(os.environ.get('MTTS_KSB', cfg.get('ksb', 4)))                 # tuning knobs (scripts/sweep_bwd.sh)
     nch = int(os.environ.get('MTTS_NCH_BWD', cfg.get('nch_bwd', 4)))
+    # K-split of the ctx-column input gradient: as many slabs as keep the launch within ONE wave of workgroups (256 CUs)
+    ksc = int(os.environ.get('MTTS_KSC', cfg.get('ksb_ctx', max(1, min(8, 256 // ((Dm + 15) // 16))))))
+    g.ksb, g.nch, g.ksb_ctx = ksb, nch, ksc
+    # every workspace size comes from the library (mtts_decoder_grad_buffer_elems)
+    lib().mtts_decoder_grad_buffer_elems.restype = ctypes.c_long
+
+    def n_of(field):
+        v = int(lib().mtts_decoder_grad_buffer_elems(ctypes.byref(a), ctypes.byref(g), field.encode()))
+        if v < 0:
+            raise _C.MttsError(f'mtts_decoder_grad_buffer_elems: unknown field {field}')
+        return v
+    E = lambda field, *shape: torch.empty(n_of(field), dtype=torch.float32, device=dev).view(*shape) if shape else \
+        torch.empty(n_of(field), dtype=torch.float32, device=dev)
+    Z = lambda field, *shape: torch.zeros(n_of(field), dtype=torch.float32, device=dev).view(*shape) if shape else \
+        torch.zeros(n_of(field), dtype=torch.float32, device=dev)
     buf('dout', dout)
     if dal is not None:
         buf('dalign', dal)
-    buf('att_w_rec_T', _e(Dm + H, 4 * H, device=dev))
-    buf('gen_w_hh_T', _e(H, 4 * H, device=dev))
-    buf('w_query_T', _e(H, A, device=dev))
-    buf('dG_att', _e(T, B, 4 * H, device=dev))
-    buf('dG_gen', _e(T, B, 4 * H, device=dev))
+    buf('att_w_rec_T', E('att_w_rec_T'))
+    buf('gen_w_hh_T', E('gen_w_hh_T'))
+    buf('w_query_T', E('w_query_T'))
+    buf('dG_att', E('dG_att'))
+    buf('dG_gen', E('dG_gen'))
     if H % 16 == 0 and st.h_att_p is not None:      # MFMA-tile-order copies for the per-step input-gradient GEMMs
         Bp = (B + 15) & ~15
-        zp = _z if Bp != B else _e                                 # padded batch rows of the packed copies stay zero
-        buf('dG_att_p', zp(T, Bp * 4 * H, device=dev))
-        buf('dG_gen_p', zp(T, Bp * 4 * H, device=dev))
-        buf('att_w_rec_Tp', _e(((Dm + H + 15) & ~15) * 4 * H, device=dev))
-        buf('gen_w_hh_Tp', _e(H * 4 * H, device=dev))
+        zp = Z if Bp != B else E                                   # padded batch rows of the packed copies stay zero
+        buf('dG_att_p', zp('dG_att_p'))
+        buf('dG_gen_p', zp('dG_gen_p'))
+        buf('att_w_rec_Tp', E('att_w_rec_Tp'))
+        buf('gen_w_hh_Tp', E('gen_w_hh_Tp'))
     if st.fast and H % 32 == 0 and Dm % 4 == 0 and B <= 64 and os.environ.get('MTTS_GBWD', '0') == '1':
         # experiment (off by default, see csrc/decoder_bwd.hip): K-split input-gradient product of chain A
-        buf('att_w_rec_T2p', torch.empty(int(lib().mtts_ksplit_packed_weight_bytes(Dm + H, 4 * H, 0)), dtype=torch.uint8, device=dev))
-        buf('part_rec', _e(24 * B * (Dm + H), device=dev))
-        buf('dh_rec_sum', _e(B, H, device=dev))
+        buf('att_w_rec_T2p', torch.empty(n_of('att_w_rec_T2p'), dtype=torch.uint8, device=dev))
+        buf('part_rec', E('part_rec'))
+        buf('dh_rec_sum', E('dh_rec_sum'))
     if not st.fast:      # general schedule (teacher forcing < 1): per-step chain with transposed full weights
-        buf('att_w_ih_T', _e(P + Dm + H, 4 * H, device=dev))
-        buf('gen_w_ih_T', _e(2 * H + Dm, 4 * H, device=dev))
-        buf('w_out_T', _e(H + Dm, Mo, device=dev))
-        pwt = [_e(M if i == 0 else P, P, device=dev) for i in range(n)]
+        buf('att_w_ih_T', E('att_w_ih_T'))
+        buf('gen_w_ih_T', E('gen_w_ih_T'))
+        buf('w_out_T', E('w_out_T'))
+        pwt = [E('prenet_w_T0' if i == 0 else 'prenet_w_T') for i in range(n)]
         keep.extend(pwt)
         for i in range(n):
             g.prenet_w_T[i] = pwt[i].data_ptr()
-        buf('step_ws', _z(B * ((P + Dm + H) + (2 * H + Dm) + (H + Dm) + M), device=dev))
-        buf('frames_fed', _e(T, B, M, device=dev))
-    buf('dHG', _e(T, B, H, device=dev))
-    buf('dHA', _e(T, B, H, device=dev))
+        buf('step_ws', Z('step_ws'))
+        buf('frames_fed', E('frames_fed'))
+    buf('dHG', E('dHG'))
+    buf('dHA', E('dHA'))
     # written slot by slot before they are read; only the boundary slots need clearing
-    buf('dctx_all', _e(T + 1, B, Dm, device=dev))[0].zero_()
-    buf('dctx_tot', _e(T + 1, B, Dm, device=dev))[0].zero_()
-    buf('dcum_all', _z(T + 1, B, L, device=dev))                   # accumulated with atomics by the chunk workgroups
-    buf('dq_all', _z(T, B, A, device=dev))
-    buf('part_gen', _z(ksb, B, H, device=dev))
-    # K-split of the ctx-column input gradient: as many slabs as keep the launch within ONE wave of workgroups (256 CUs)
-    ksc = int(os.environ.get('MTTS_KSC', cfg.get('ksb_ctx', max(1, min(8, 256 // ((Dm + 15) // 16))))))
-    buf('part_att', _z(ksc * B * Dm + ksb * B * H, device=dev))
-    g.ksb, g.nch, g.ksb_ctx = ksb, nch, ksc
-    buf('dc_att', _z(2, B, H, device=dev))
-    buf('dc_gen', _z(2, B, H, device=dev))
-    buf('dh_carry_att', _z(2, B, H, device=dev))
-    buf('dh_carry_gen', _z(2, B, H, device=dev))
-    buf('dMt', _z(B, L, A, device=dev))
-    buf('dU_slab', _z(B * nch, A * ksz, device=dev))
-    buf('dv_slab', _z(B * nch, A, device=dev))
-    buf('dbias_slab', _z(B * nch, A, device=dev))
-    buf('dU', _e(A, ksz, device=dev))
-    buf('dpren', _e(n, T, B, P, device=dev))
-    buf('colsum_ws', _e(int(lib().mtts_colsum_workspace_floats(max(4 * H, A * ksz, P, M + 1))), device=dev))
-    dmemory = buf('dmemory', _e(B, L, Dm, device=dev))
+    buf('dctx_all', E('dctx_all', T + 1, B, Dm))[0].zero_()
+    buf('dctx_tot', E('dctx_tot', T + 1, B, Dm))[0].zero_()
+    buf('dcum_all', Z('dcum_all'))                   # accumulated with atomics by the chunk workgroups
+    buf('dq_all', Z('dq_all'))
+    buf('part_gen', Z('part_gen'))
+    buf('part_att', Z('part_att'))
+    for name in ('dc_att', 'dc_gen', 'dh_carry_att', 'dh_carry_gen', 'dMt', 'dU_slab', 'dv_slab', 'dbias_slab'):
+        buf(name, Z(name))
+    buf('dU', E('dU'))
+    buf('dpren', E('dpren'))
+    buf('colsum_ws', E('colsum_ws'))
+    dmemory = buf('dmemory', E('dmemory', B, L, Dm))
     dpw = [_e(*w['prenet_w'][i].shape, device=dev) for i in range(n)]
     dpb = [_e(*w['prenet_b'][i].shape, device=dev) for i in range(n)]
     for i in range(n):
@@ -131,11 +137,13 @@ def bilstm_bwd(ctx, dy):
     hs, cs, gs = [h0, h1], [c0, c1], [g0, g1]
     g = _C.BiLstmGradArgs()
     ksb = 4
-    whT = [_e(H, 4 * H, device=dev) for _ in range(2)]
-    dxp = [_e(L, B, 4 * H, device=dev) for _ in range(2)]
-    part, dc, dhc = _z(2, ksb, B, H, device=dev), _z(2, 2, B, H, device=dev), _z(2, 2, B, H, device=dev)
-    cws = _e(int(lib().mtts_colsum_workspace_floats(4 * H)), device=dev)
-    dx = _e(L, B, Cin, device=dev)
+    lib().mtts_bilstm_buffer_elems.restype = ctypes.c_long
+    n = lambda field: int(lib().mtts_bilstm_buffer_elems(ctypes.byref(a), ksb, field.encode()))          # sizes come from the library
+    whT = [_e(n('w_hh_T'), device=dev) for _ in range(2)]
+    dxp = [_e(n('dxproj'), device=dev).view(L, B, 4 * H) for _ in range(2)]
+    part, dc, dhc = _z(n('part'), device=dev), _z(n('dc'), device=dev), _z(n('dh_carry'), device=dev)
+    cws = _e(n('colsum_ws'), device=dev)
+    dx = _e(n('dx'), device=dev).view(L, B, Cin)
     dw = [[_e(*t.shape, device=dev) for t in ws[d]] for d in range(2)]
     for d in range(2):
         a.w_ih[d], a.w_hh[d], a.b_ih[d], a.b_hh[d] = (t.data_ptr() for t in ws[d])

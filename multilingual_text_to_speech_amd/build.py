@@ -32,12 +32,26 @@ def _compile(src, obj):
     return obj
 
 
+def _flags_stamp(bdir):
+    """The object cache is only valid for the flags it was built with: a change of FLAGS / MTTS_EXTRA_FLAGS (A/B builds with
+    -DMTTS_DBG_* switches!) rebuilds everything instead of silently linking stale objects."""
+    import hashlib
+    want = hashlib.sha256(" ".join(FLAGS + os.environ.get("MTTS_EXTRA_FLAGS", "").split()).encode()).hexdigest()
+    path = os.path.join(bdir, "flags.sha256")
+    have = open(path).read().strip() if os.path.exists(path) else None
+    return want, have, path
+
+
 def build(force=False, verbose=True):
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
-    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    # everything a translation unit may include: headers AND generated instruction streams (gemm_pipe_body.inc)
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
     newest_hdr = max([os.path.getmtime(h) for h in hdrs] + [0.0])
     bdir = os.path.join(CSRC, "build")
     os.makedirs(bdir, exist_ok=True)
+    want, have, stamp = _flags_stamp(bdir)
+    if want != have:
+        force = True
     jobs, objs = [], []
     for s in srcs:
         o = os.path.join(bdir, os.path.basename(s) + ".o")
@@ -49,6 +63,8 @@ def build(force=False, verbose=True):
             print(f"[mtts build] compiling {len(jobs)} file(s) for gfx950", file=sys.stderr)
         with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(lambda so: _compile(*so), jobs))
+    with open(stamp, "w") as f:
+        f.write(want)
     if jobs or not os.path.exists(OUT):
         cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", OUT]
         r = subprocess.run(cmd, capture_output=True, text=True)

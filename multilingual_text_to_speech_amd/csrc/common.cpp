@@ -16,6 +16,20 @@ int mtts_fail(const char* fmt, ...) {
 MTTS_API const char* mtts_last_error(void) { return g_mtts_err; }
 MTTS_API int mtts_version(void) { return 100; }
 
+// Bitmask of the timing-experiment switches this library was compiled with (each of them produces WRONG results by design):
+//   1 = MTTS_DBG_SKIP_GEN_STEPS, 2 = MTTS_DBG_SKIP_WGRAD.  0 for every production build; bindings must refuse anything else
+// (multilingual_text_to_speech_amd._C.lib() does unless MTTS_ALLOW_DEBUG_LIB=1).
+MTTS_API int mtts_build_flags(void) {
+    int f = 0;
+#ifdef MTTS_DBG_SKIP_GEN_STEPS
+    f |= 1;
+#endif
+#ifdef MTTS_DBG_SKIP_WGRAD
+    f |= 2;
+#endif
+    return f;
+}
+
 // sizeof() of the ABI structs, in header order, so that bindings can verify their mirrors.
 MTTS_API int mtts_sizeof_struct(int which) {
     switch (which) {

@@ -21,65 +21,71 @@ class DecoderState:
     def __init__(self, B, L, T, dims, device, n_prenet, save_gates=True, fast=False, kq=8, precision=0):
         M, P, H, A, Dm, ksz, C = dims
         self.B, self.L, self.T, self.dims, self.n_prenet, self.kq, self.fast = B, L, T, dims, n_prenet, kq, fast
-        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
-        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)
         self.Mo = _round4(M + 1)
-        self.prenet_act = [e(T, B, P) for _ in range(n_prenet)]
-        self.U, self.Mt, self.PL = e(A, ksz), e(B, L, A), e(2, B, L, A)
-        # K-split step kernels (csrc/lstm_step.hip): query partials come in H/16 slabs
         self.precision = int(precision)
+        # every buffer size comes from the library (mtts_decoder_buffer_elems): shape-only argument block first
+        sh = _C.DecoderArgs()
+        sh.B, sh.L, sh.T, sh.M, sh.P, sh.H, sh.A, sh.Dm, sh.ksz, sh.C = B, L, T, M, P, H, A, Dm, ksz, C
+        sh.n_prenet, sh.kq, sh.fast, sh.precision = n_prenet, kq, int(bool(fast)), self.precision
+        lib().mtts_decoder_buffer_elems.restype = ctypes.c_long
+
+        def n(field):
+            v = int(lib().mtts_decoder_buffer_elems(ctypes.byref(sh), field.encode()))
+            if v < 0:
+                raise _C.MttsError(f'mtts_decoder_buffer_elems: unknown field {field}')
+            return v
+        e = lambda field: torch.empty(n(field), dtype=torch.float32, device=device)
+        z = lambda field: torch.zeros(n(field), dtype=torch.float32, device=device)
+        raw = lambda field: torch.empty(n(field), dtype=torch.uint8, device=device)
+
+        def z0(field, *shape):              # only slot 0 (the initial state) is read before it is written: no need to clear ~1 GB per decode
+            t = e(field).view(*shape)
+            t[0].zero_()
+            return t
+        self.prenet_act = [e('prenet_act').view(T, B, P) for _ in range(n_prenet)]
+        self.U, self.Mt, self.PL = e('U').view(A, ksz), e('Mt').view(B, L, A), e('PL').view(2, B, L, A)
+        # K-split step kernels (csrc/lstm_step.hip): query partials come in H/16 slabs
         off = os.environ.get('MTTS_NO_LSTEP', '0')
         ok = H % 32 == 0 and Dm % 32 == 0 and A % 16 == 0 and A <= 256
         self.use_lstep = bool(fast and off != '1' and ok)                       # teacher-forced schedule: hoisted projections
         use_lgen = bool(not fast and off != '1' and ok and P % 32 == 0)          # general schedule: un-hoisted 3-segment operands
-        self.qpart = e(max(kq, H // 16) if (self.use_lstep or use_lgen) else kq, B, A)
+        self.qpart = e('qpart').view(-1, B, A) if (self.use_lstep or use_lgen) else torch.empty(kq, B, A, dtype=torch.float32, device=device)
         self.att_w2p = self.att_bias_u = self.att_w_pre_u = self.gate_part = None
         self.gen_w2p = self.gen_bias_u = self.gen_w_ih_u = self.gate_part_gen = None
-        packed = lambda K: torch.empty(int(lib().mtts_lstm_packed_weight_bytes(H, K, self.precision)), dtype=torch.uint8, device=device)
-        part = lambda K: e(int(lib().mtts_lstm_step_partial_floats(B, H, K)))
         if fast and off not in ('1', 'gen') and H % 32 == 0:
-            self.gen_w2p, self.gen_bias_u, self.gen_w_ih_u, self.gate_part_gen = packed(H), e(4 * H), e(4 * H, H + Dm), part(H)
+            self.gen_w2p, self.gen_bias_u, self.gen_w_ih_u, self.gate_part_gen = raw('gen_w2p'), e('gen_bias_u'), e('gen_w_ih_u'), e('gate_part_gen')
         if self.use_lstep:
-            self.att_w2p, self.att_bias_u, self.att_w_pre_u, self.gate_part = packed(Dm + H), e(4 * H), e(4 * H, P), part(Dm + H)
+            self.att_w2p, self.att_bias_u, self.att_w_pre_u, self.gate_part = raw('att_w2p'), e('att_bias_u'), e('att_w_pre_u'), e('gate_part')
         self.prenet_wp = None
         if not fast and n_prenet == 2 and M % 16 == 0 and P % 16 == 0:        # free-running steps: fused two-layer prenet kernel
-            self.prenet_wp = [e(P * M), e(P * P)]
+            self.prenet_wp = [e('prenet_wp0'), e('prenet_wp1')]
         if use_lgen:
-            self.att_w2p, self.att_bias_u, self.gate_part = packed(P + Dm + H), e(4 * H), part(P + Dm + H)
-            self.gen_w2p, self.gen_bias_u, self.gate_part_gen = packed(2 * H + Dm), e(4 * H), part(2 * H + Dm)
-        def z0(*s):
-            t = e(*s)
-            t[0].zero_()
-            return t
-        # only slot 0 (the initial state) is read before it is written: no need to clear ~1 GB per decode
-        self.h_att, self.c_att = z0(T + 1, B, H), z0(T + 1, B, H)
-        self.h_gen, self.c_gen = z0(T + 1, B, H), z0(T + 1, B, H)
-        self.ctx, self.cum = z0(T + 1, B, Dm), z0(T + 1, B, L)
-        self.align = e(T, B, L)
-        self.gates_att = e(T, B, 4 * H) if save_gates else None
-        self.gates_gen = e(T, B, 4 * H) if save_gates else None
-        self.out = z(T + 1, B, self.Mo)
-        self.pre_att = e(T, B, 4 * H) if fast else None
-        self.pre_gen = e(T, B, 4 * H) if fast else None
-        self.q_all = e(T, B, A) if save_gates else None
+            self.att_w2p, self.att_bias_u, self.gate_part = raw('att_w2p'), e('att_bias_u'), e('gate_part')
+            self.gen_w2p, self.gen_bias_u, self.gate_part_gen = raw('gen_w2p'), e('gen_bias_u'), e('gate_part_gen')
+        self.h_att, self.c_att = z0('h_att', T + 1, B, H), z0('c_att', T + 1, B, H)
+        self.h_gen, self.c_gen = z0('h_gen', T + 1, B, H), z0('c_gen', T + 1, B, H)
+        self.ctx, self.cum = z0('ctx', T + 1, B, Dm), z0('cum', T + 1, B, L)
+        self.align = e('align').view(T, B, L)
+        self.gates_att = e('gates_att').view(T, B, 4 * H) if save_gates else None
+        self.gates_gen = e('gates_gen').view(T, B, 4 * H) if save_gates else None
+        self.out = z('out').view(T + 1, B, self.Mo)
+        self.pre_att = e('pre_att').view(T, B, 4 * H) if fast else None
+        self.pre_gen = e('pre_gen').view(T, B, 4 * H) if fast else None
+        self.q_all = e('q_all').view(T, B, A) if save_gates else None
         # MFMA-tile-order copies of the recurrent operands (only when the widths are multiples of 16)
         Bp = (B + 15) & ~15
         use_pack = os.environ.get('MTTS_NO_PACK', '0') != '1'      # debugging / A-B switch: row-major operands only
         hp_ok, dp_ok = use_pack and H % 16 == 0, use_pack and Dm % 16 == 0
-        zp = z0 if Bp == B else z                                  # padded batch rows of the packed copies stay zero
-        self.h_att_p = zp(T + 1, Bp * H) if hp_ok else None
-        self.h_gen_p = zp(T + 1, Bp * H) if hp_ok else None
-        self.ctx_p = zp(T + 1, Bp * Dm) if dp_ok else None
-        self.att_w_ctx_p = e(4 * H * Dm) if (dp_ok and H % 4 == 0) else None
-        self.att_w_hh_p = e(4 * H * H) if hp_ok else None
-        self.gen_w_hh_p = e(4 * H * H) if hp_ok else None
-        self.w_query_p = e(((A + 15) & ~15) * H) if hp_ok else None
+        zp = (lambda f, *sh_: z0(f, *sh_)) if Bp == B else (lambda f, *sh_: z(f).view(*sh_))      # padded batch rows of the packed copies stay zero
+        self.h_att_p = zp('h_att_p', T + 1, Bp * H) if hp_ok else None
+        self.h_gen_p = zp('h_gen_p', T + 1, Bp * H) if hp_ok else None
+        self.ctx_p = zp('ctx_p', T + 1, Bp * Dm) if dp_ok else None
+        self.att_w_ctx_p = e('att_w_ctx_p') if (dp_ok and H % 4 == 0) else None
+        self.att_w_hh_p = e('att_w_hh_p') if hp_ok else None
+        self.gen_w_hh_p = e('gen_w_hh_p') if hp_ok else None
+        self.w_query_p = e('w_query_p') if hp_ok else None
         # exchange / barrier workspace of the persistent recurrence kernels (csrc/persist.hip), zero-filled once
-        self.persist_ws = None
-        if fast:
-            lib().mtts_decoder_persist_ws_bytes.restype = ctypes.c_long
-            nb = int(lib().mtts_decoder_persist_ws_bytes(B, L, H, Dm, A))
-            self.persist_ws = torch.zeros(nb, dtype=torch.uint8, device=device)
+        self.persist_ws = torch.zeros(n('persist_ws'), dtype=torch.uint8, device=device) if fast else None
         self._args = (B, L, dims, device, n_prenet, save_gates, fast, kq, precision)
 
     _PER_STEP = ('prenet_act', 'h_att', 'c_att', 'h_gen', 'c_gen', 'ctx', 'cum', 'align', 'gates_att', 'gates_gen', 'out', 'pre_att',

@@ -349,11 +349,13 @@ class BiLstmFn(torch.autograd.Function):
         a.x, a.lengths = ptr(x_tm), ptr(lengths32)
         ws = [(w_ih.contiguous(), w_hh.contiguous(), b_ih.contiguous(), b_hh.contiguous()),
               (w_ih_r.contiguous(), w_hh_r.contiguous(), b_ih_r.contiguous(), b_hh_r.contiguous())]
-        xproj = [_f32(L, B, 4 * H, device=dev) for _ in range(2)]
-        h = [torch.zeros(L + 1, B, H, device=dev) for _ in range(2)]
-        c = [torch.zeros(L + 1, B, H, device=dev) for _ in range(2)]
-        gates = [_f32(L, B, 4 * H, device=dev) for _ in range(2)]
-        y = _f32(B, L, 2 * H, device=dev)
+        lib().mtts_bilstm_buffer_elems.restype = ctypes.c_long
+        n = lambda field: int(lib().mtts_bilstm_buffer_elems(ctypes.byref(a), 0, field.encode()))      # sizes come from the library
+        xproj = [_f32(n('xproj'), device=dev).view(L, B, 4 * H) for _ in range(2)]
+        h = [torch.zeros(n('h'), device=dev).view(L + 1, B, H) for _ in range(2)]
+        c = [torch.zeros(n('c'), device=dev).view(L + 1, B, H) for _ in range(2)]
+        gates = [_f32(n('gates'), device=dev).view(L, B, 4 * H) for _ in range(2)]
+        y = _f32(n('y'), device=dev).view(B, L, 2 * H)
         for d in range(2):
             a.w_ih[d], a.w_hh[d], a.b_ih[d], a.b_hh[d] = (t.data_ptr() for t in ws[d])
             a.xproj[d], a.h[d], a.c[d], a.gates[d] = xproj[d].data_ptr(), h[d].data_ptr(), c[d].data_ptr(), gates[d].data_ptr()

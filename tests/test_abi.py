@@ -40,3 +40,42 @@ def test_no_cpu_fallback():
     from multilingual_text_to_speech_amd import kernels as K
     with pytest.raises(_C.MttsError):
         K.linear(torch.zeros(2, 4), torch.zeros(3, 4))
+
+
+def test_buffer_size_queries_cover_every_caller_allocated_buffer(library):
+    """mtts_decoder_buffer_elems / mtts_decoder_grad_buffer_elems / mtts_bilstm_buffer_elems: every pointer member of the argument
+    blocks that the CALLER allocates (inputs, weights and gradient outputs aside) has a size query, the values follow the layouts in
+    the header comments, unknown names return -1."""
+    for f in ('mtts_decoder_buffer_elems', 'mtts_decoder_grad_buffer_elems', 'mtts_bilstm_buffer_elems'):
+        getattr(library, f).restype = ctypes.c_long
+    a = _C.DecoderArgs()
+    a.B, a.L, a.T, a.M, a.P, a.H, a.A, a.Dm, a.ksz, a.C, a.n_prenet, a.kq, a.fast = 64, 120, 600, 80, 256, 1024, 128, 544, 31, 32, 2, 8, 1
+    q = lambda f: library.mtts_decoder_buffer_elems(ctypes.byref(a), f.encode())
+    assert q('h_att') == 601 * 64 * 1024 and q('ctx') == 601 * 64 * 544 and q('out') == 601 * 64 * 84 and q('align') == 600 * 64 * 120
+    assert q('att_w2p') == 4 * 1024 * (544 + 1024) * 4 and q('qpart') == 64 * 64 * 128
+    assert q('persist_ws') == library.mtts_decoder_persist_ws_bytes(64, 120, 1024, 544, 128) > 0
+    assert q('no_such_field') == -1
+    inputs = {'memory', 'lengths', 'frames_in', 'teacher', 'prenet_w', 'prenet_b', 'prenet_mask', 'att_hmask', 'att_cmask', 'gen_hmask', 'gen_cmask',
+              'prenet_wp', 'prenet_act'}
+    weights = {n for n, _ in _C.DecoderArgs._fields_ if n.startswith(('att_w_', 'att_b_', 'gen_w_', 'gen_b_', 'w_', 'b_')) and not n.endswith(('_p', '_u', '2p'))}
+    weights |= {'att_bias'}
+    for name, ctype in _C.DecoderArgs._fields_:
+        if ctype is ctypes.c_void_p and name not in inputs and name not in weights:
+            assert q(name) > 0, name
+    assert q('prenet_act') == 600 * 64 * 256 and q('prenet_wp0') == 256 * 80 and q('prenet_mask') == 600 * 64 * 256
+    g = _C.DecoderGradArgs()
+    g.ksb, g.ksb_ctx, g.nch = 4, 7, 4
+    qg = lambda f: library.mtts_decoder_grad_buffer_elems(ctypes.byref(a), ctypes.byref(g), f.encode())
+    assert qg('part_att') == 7 * 64 * 544 + 4 * 64 * 1024 and qg('dU_slab') == 64 * 4 * 128 * 31 and qg('dpren') == 2 * 600 * 64 * 256
+    for name, ctype in _C.DecoderGradArgs._fields_:
+        if ctype is ctypes.c_void_p and not name.startswith('d_'):
+            assert qg(name) > 0, name
+    assert qg('prenet_w_T0') == 80 * 256 and qg('bogus') == -1
+    b = _C.BiLstmArgs()
+    b.B, b.L, b.Cin, b.H = 64, 120, 512, 256
+    qb = lambda f: library.mtts_bilstm_buffer_elems(ctypes.byref(b), 4, f.encode())
+    assert qb('h') == 121 * 64 * 256 and qb('part') == 2 * 4 * 64 * 256 and qb('y') == 64 * 120 * 512 and qb('zzz') == -1
+
+
+def test_library_reports_no_debug_switches(library):
+    assert library.mtts_build_flags() == 0
