@@ -82,6 +82,10 @@ __device__ __forceinline__ PsFrag3 ps_split8(const float4& lo, const float4& hi)
     ps_split_pair(hi.z, hi.w, f.p[0].u[3], f.p[1].u[3], f.p[2].u[3]);
     return f;
 }
+__device__ __forceinline__ unsigned ps_bf16_rne(float x) {      // upper 16 bits of the RNE-rounded value
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
 // acc += A B^T with fp32 accuracy: six bf16 MFMA terms, small ones first
 __device__ __forceinline__ f32x4 ps_mma6(const PsFrag3& a, const PsFrag3& b, f32x4 acc) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p[2].v, b.p[0].v, acc, 0, 0, 0);
@@ -102,6 +106,24 @@ __device__ __forceinline__ f32x4 ps_mma6(const PsFrag3& a, const PsFrag3& b, f32
 __device__ __forceinline__ unsigned ps_xp_off(int row, int k, int nkb) {        // BYTE offset of the 16-byte quantum holding k .. k+3
     const int rt = row >> 4, i16 = row & 15, kb = k >> 5, j = k & 31, q4 = j >> 3, hf = (j >> 2) & 1;
     return (unsigned)((((((rt * nkb + kb) * 2 + hf) * 64) + (q4 * 16 + i16)) * 4) * 4);
+}
+
+// bf16 path (precision 1: operands of every contraction rounded to bf16, RNE): the exchange holds finished bf16 A-fragments ("XB"),
+//   byte offset = ((rt * nkb + kb) * 64 + q4 * 16 + i16) * 16 + (k & 4) * 2       for the four bf16 of k .. k+3 (k % 4 == 0)
+__device__ __forceinline__ unsigned ps_xb_off(int row, int k, int nkb) {
+    const int rt = row >> 4, i16 = row & 15, kb = k >> 5, j = k & 31, q4 = j >> 3;
+    return (unsigned)(((rt * nkb + kb) * 64 + q4 * 16 + i16) * 16 + (j & 4) * 2);
+}
+// publish four consecutive columns k .. k+3 of `row`: fp32 quantum (PREC 0) or four RNE-rounded bf16 (PREC 1), write-through
+template <int PREC>
+__device__ __forceinline__ void ps_publish4(__amdgpu_buffer_rsrc_t r, int row, int k, int nkb, float4 v) {
+    if (PREC) {
+        typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+        u32x2 w; w.x = ps_bf16_rne(v.x) | (ps_bf16_rne(v.y) << 16); w.y = ps_bf16_rne(v.z) | (ps_bf16_rne(v.w) << 16);
+        __builtin_amdgcn_raw_buffer_store_b64(w, r, ps_xb_off(row, k, nkb), 0, 16);
+    } else {
+        ps_st16_sc1(r, ps_xp_off(row, k, nkb), v);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -218,6 +240,40 @@ __device__ __forceinline__ void ps_gates(__amdgpu_buffer_rsrc_t xr, int nkb, con
         for (int r = 0; r < 4; ++r) out[(16 * rt + 4 * q4 + r) * 16 + i16] = acc[rt][r];
 }
 
+// bf16 form: the exchange holds bf16 fragments, the LDS weight slice is bf16 ([nkb][64 lanes] x 16 B), one MFMA per product
+template <int NBW, int RT>
+__device__ __forceinline__ void ps_gates_bf16(__amdgpu_buffer_rsrc_t xr, int nkb, const uint4* __restrict__ wlb, float* __restrict__ red) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int k0 = (nkb * wave) >> 3, k1 = (nkb * (wave + 1)) >> 3;
+    u32x4 xa[NBW][RT];
+#pragma unroll
+    for (int j = 0; j < NBW; ++j)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+            xa[j][rt] = __builtin_amdgcn_raw_buffer_load_b128(xr, (k0 + j < k1) ? (unsigned)(((rt * nkb + k0 + j) * 1024) + lane * 16) : 0xfffffff0u, 0, 16);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+        const uint4 w = wlb[min(k0 + j, nkb - 1) * 64 + lane];
+        PsFrag wb; wb.u[0] = w.x; wb.u[1] = w.y; wb.u[2] = w.z; wb.u[3] = w.w;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            PsFrag a; a.u[0] = xa[j][rt].x; a.u[1] = xa[j][rt].y; a.u[2] = xa[j][rt].z; a.u[3] = xa[j][rt].w;
+            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, wb.v, acc[rt], 0, 0, 0);
+        }
+    }
+    float* out = red + wave * (64 * 16);
+    const int i16 = lane & 15, q4 = lane >> 4;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(16 * rt + 4 * q4 + r) * 16 + i16] = acc[rt][r];
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // LSTM cell for (row, unit) = (tid >> 2, tid & 3), tid < 4 B: sums the 8 partials, adds the hoisted projection and the bias,
 // applies dropout / zoneout (reference modules/layers.py:26-47) and returns the h that recurs.  c / h of the previous step live
@@ -272,22 +328,24 @@ struct PsGen {
     unsigned long long* prof;   // NULL in production
 };
 
-template <int RT>
+template <int RT, int PREC>
 __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void pgen_kernel(PsGen p) {
     extern __shared__ __attribute__((aligned(16))) char psm[];
     const int tid = threadIdx.x, c = blockIdx.x;
     const int H = p.H, B = p.B, nkb = H >> 5, N = 4 * H;
-    float4* wl = reinterpret_cast<float4*>(psm);                       // [nkb][2][64] float4 = nkb * 2 KiB
-    float* red = reinterpret_cast<float*>(psm + (size_t)nkb * 2048);    // [8][64][16]
+    float4* wl = reinterpret_cast<float4*>(psm);                       // fp32: [nkb][2][64] float4 = nkb * 2 KiB; bf16: [nkb][64] x 16 B
+    float* red = reinterpret_cast<float*>(psm + (size_t)nkb * (PREC ? 1024 : 2048));    // [8][64][16]
     // ---- stationary weights -> LDS
     {
-        const float4* src = reinterpret_cast<const float4*>(p.w_packed) + (size_t)c * nkb * 128;
-        for (int i = tid; i < nkb * 128; i += PS_THREADS) wl[i] = src[i];
+        const int per = PREC ? 64 : 128;                                // 16-byte quanta per k-block
+        const float4* src = reinterpret_cast<const float4*>(p.w_packed) + (size_t)c * nkb * per;
+        for (int i = tid; i < nkb * per; i += PS_THREADS) wl[i] = src[i];
     }
     const int row = tid >> 2, uu = tid & 3, u = 4 * c + uu;
     const bool cellthr = tid < 4 * B;
     const int rowc = cellthr ? row : 0;
-    const unsigned xp_bytes = (unsigned)(64 * H * 4);
+    const unsigned xp_bytes = (unsigned)(64 * H * (PREC ? 2 : 4));
+    auto xregion = [&](int par) { return ps_rsrc(reinterpret_cast<char*>(p.xp) + (size_t)par * xp_bytes, xp_bytes); };
     float c_state = 0.f, h_state = 0.f;
     const float4 bias4 = *reinterpret_cast<const float4*>(p.bias_u + 4 * u);
     if (cellthr) {
@@ -296,7 +354,7 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     }
     {   // publish h[t0] in the exchange layout
         const float4 h4 = ps_quad_gather(h_state);
-        if (cellthr && uu == 0) ps_st16_sc1(ps_rsrc(p.xp + (size_t)(p.t0 & 1) * 64 * H, xp_bytes), ps_xp_off(row, 4 * c, nkb), h4);
+        if (cellthr && uu == 0) ps_publish4<PREC>(xregion(p.t0 & 1), row, 4 * c, nkb, h4);
     }
     unsigned epoch = 0;
     if (!ps_barrier(p.sync, ++epoch)) return;
@@ -305,7 +363,8 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const float4 pre4 = *reinterpret_cast<const float4*>(p.pre + ((size_t)t * B + rowc) * N + 4 * u);
         const int hm = (p.hmask && cellthr) ? (int)p.hmask[((size_t)t * B + row) * H + u] : 1;
         const int cm = (p.cmask && cellthr) ? (int)p.cmask[((size_t)t * B + row) * H + u] : 1;
-        ps_gates<4, RT, 4>(ps_rsrc(p.xp + (size_t)(t & 1) * 64 * H, xp_bytes), nkb, wl, red);
+        if (PREC) ps_gates_bf16<4, RT>(xregion(t & 1), nkb, reinterpret_cast<const uint4*>(wl), red);
+        else ps_gates<4, RT, 4>(xregion(t & 1), nkb, wl, red);
         __syncthreads();
         float4 ga;
         if (cellthr) ps_cell(red, row, uu, bias4, pre4, c_state, h_state, hm, cm, p.hmask != nullptr, p.cell, ga);
@@ -315,7 +374,7 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             p.c[o] = c_state;
             if (uu == 0) {
                 *reinterpret_cast<float4*>(p.h + o) = h4;
-                ps_st16_sc1(ps_rsrc(p.xp + (size_t)((t + 1) & 1) * 64 * H, xp_bytes), ps_xp_off(row, 4 * c, nkb), h4);
+                ps_publish4<PREC>(xregion((t + 1) & 1), row, 4 * c, nkb, h4);
             }
             if (p.gates) {
                 float* go = p.gates + ((size_t)t * B + row) * N + u;
@@ -328,17 +387,7 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// pgen3: the same recurrence, software-pipelined ROUND-ROBIN over the 16-row groups of the batch (the samples of a batch do not
-// interact in an LSTM, so a batch of 64 is four independent recurrences).  One "group-step" = the gate GEMM of one row group for one
-// time step.  While group g's h_{t+1} travels (write-through drain, counter atomic, poll), the workgroup runs the group-steps of the
-// other groups; the grid-barrier latency and the first-byte latency of the exchange reads leave the critical path:
-//   * group-step i: seven waves multiply (k-blocks dealt over the seven), having issued the loads of group-step i+1 FIRST (two
-//     register buffers, ping-pong); the eighth wave - wave g' of the previous group g' - runs that group's LSTM cell, publishes,
-//     drains its stores and arrives, all in the shadow of the others' MFMAs (the cell wave of a group never multiplies in the
-//     group-step right after its own);
-//   * barrier = 8 counters per group (blockIdx % 8), arrive = one non-returning atomic per workgroup and publish, wait = every wave
-//     samples the 8 counters (lanes 0-7) one group-step ahead of need;
-//   * weights stay in LDS as three bf16 planes in MFMA B-fragment order (split once per launch); ONE __syncthreads per group-step.
+// helpers of the pipelined (dataflow) generator kernel below
 // ---------------------------------------------------------------------------------------------------------------------------
 struct PsBar2 { unsigned* cnt; unsigned* err; };      // cnt[(g * 8 + x) * 32]: counter x of row group g
 
@@ -414,227 +463,6 @@ __device__ __forceinline__ void ps_issue16(PsLoads<NBW>& ld, __amdgpu_buffer_rsr
 #pragma unroll
     for (int j = 0; j < NBW; ++j) ps_issue_block<NBW>(ld, j, xr, k0, k1, lane);
 }
-
-// [16 rows x 16 columns] partial over the k-blocks [k0, k0 + NBW) held in `buf`; with PREFETCH the fragment registers of a block are
-// refilled with the NEXT group-step's block (k-range [nk0, nk1) of region nxr) as soon as its six MFMAs have been issued - one
-// register buffer serves both group-steps.  Two accumulators: consecutive MFMAs never depend on each other.
-template <int NBW, bool PREFETCH>
-__device__ __forceinline__ void ps_mma16(PsLoads<NBW>& buf, int nkb, int k0, const uint4* __restrict__ wpl, float* __restrict__ red_w, int lane,
-                                         __amdgpu_buffer_rsrc_t nxr, int nk0, int nk1) {
-    f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < NBW; ++j) {
-        const int kb = min(k0 + j, nkb - 1);
-        PsFrag wb[3], a[3];
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-            const uint4 w = wpl[(kb * 3 + pl) * 64 + lane];
-            wb[pl].u[0] = w.x; wb[pl].u[1] = w.y; wb[pl].u[2] = w.z; wb[pl].u[3] = w.w;
-            a[pl].u[0] = buf.x[j][pl].x; a[pl].u[1] = buf.x[j][pl].y; a[pl].u[2] = buf.x[j][pl].z; a[pl].u[3] = buf.x[j][pl].w;
-        }
-        // six terms, small ones first, alternating accumulators
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2].v, wb[0].v, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0].v, wb[2].v, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1].v, wb[1].v, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1].v, wb[0].v, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0].v, wb[1].v, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0].v, wb[0].v, acc1, 0, 0, 0);
-        if (PREFETCH) ps_issue_block<NBW>(buf, j, nxr, nk0, nk1, lane);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    const int i16 = lane & 15, q4 = lane >> 4;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) red_w[(4 * q4 + r) * 16 + i16] = acc0[r] + acc1[r];
-}
-
-template <int NG>
-__global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void pgen3_kernel(PsGen p) {
-    extern __shared__ __attribute__((aligned(16))) char psm[];
-    constexpr int NACT = NG >= 2 ? 7 : 8;                     // multiplying waves per group-step
-    constexpr int NBW = NG >= 2 ? 5 : 4;                      // k-blocks per multiplying wave (nkb = 32)
-    const int tid = threadIdx.x, lane = tid & 63, c = blockIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int H = p.H, B = p.B, nkb = H >> 5, N = 4 * H;
-    uint4* wpl = reinterpret_cast<uint4*>(psm);                                        // [nkb][3][64] x 16 B
-    float* red = reinterpret_cast<float*>(psm + (size_t)nkb * 3072);                   // [NG][8][16][16]
-#ifdef PS_PROF
-    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(red + NG * 8 * 256);
-#endif
-    const PsBar2 bar{p.sync.cnt, p.sync.err};
-    // ---- stationary weights: fp32 packed slice -> three bf16 planes in LDS; partial-sum slots start at zero
-    {
-        const float4* src = reinterpret_cast<const float4*>(p.w_packed) + (size_t)c * nkb * 128;
-        for (int i = tid; i < nkb * 64; i += PS_THREADS) {
-            const int kb = i >> 6, l = i & 63;
-            const PsFrag3 f = ps_split8(src[(kb * 2 + 0) * 64 + l], src[(kb * 2 + 1) * 64 + l]);
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) wpl[(kb * 3 + pl) * 64 + l] = make_uint4(f.p[pl].u[0], f.p[pl].u[1], f.p[pl].u[2], f.p[pl].u[3]);
-        }
-        for (int i = tid; i < NG * 8 * 256; i += PS_THREADS) red[i] = 0.f;
-    }
-    // ---- cell role: wave g (< NG) owns the 16 rows x 4 units of row group g; lane -> (local row, unit)
-    const bool cellwave = wave < NG;
-    const int rl = lane >> 2, uu = lane & 3, u = 4 * c + uu;
-    const int row = 16 * wave + rl;
-    const bool cellthr = cellwave && row < B;
-    const int rowc = cellthr ? row : 0;
-    const unsigned xg_bytes = (unsigned)(nkb * 3072);                               // one (group, parity) exchange region (XQ layout)
-    auto xregion = [&](int g, int par) { return ps_rsrc(reinterpret_cast<char*>(p.xp) + (size_t)(g * 2 + par) * xg_bytes, xg_bytes); };
-    float c_state = 0.f, h_state = 0.f;
-    const float4 bias4 = *reinterpret_cast<const float4*>(p.bias_u + 4 * u);
-    if (cellthr) {
-        c_state = p.c[((size_t)p.t0 * B + row) * H + u];
-        h_state = p.h[((size_t)p.t0 * B + row) * H + u];
-    }
-    if (cellwave) {   // publish h[t0] (rows local to the group), arrive
-        const float4 h4 = ps_quad_gather(h_state);
-        if (cellthr && uu == 0) ps_xq_store4(xregion(wave, p.t0 & 1), rl, 4 * c, h4);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) ps_arrive(bar, wave);
-    }
-    __syncthreads();
-    const unsigned per_pub = PS_WGS / 8;                      // arrivals per counter and publish
-    const int n_gs = (p.t1 - p.t0) * NG;
-    // k-range of `wave` in a group-step of group g: the cell wave of the PREVIOUS group (wave (g + NG - 1) % NG) does not multiply
-    auto krange = [&](int g, int& k0, int& k1) {
-        if (NG == 1) { k0 = (nkb * wave) >> 3; k1 = (nkb * (wave + 1)) >> 3; return; }
-        const int wp = (g + NG - 1) % NG;
-        if (wave == wp) { k0 = k1 = 0; return; }
-        const int r = wave - (wave > wp ? 1 : 0);
-        k0 = (nkb * r) / NACT; k1 = (nkb * (r + 1)) / NACT;
-    };
-    // operands of the cell this wave will run for time step tc (issued one group-step ahead)
-    float4 pre4 = make_float4(0.f, 0.f, 0.f, 0.f); unsigned hm = 1, cm = 1;
-    auto cell_prefetch = [&](int tc) {
-        pre4 = *reinterpret_cast<const float4*>(p.pre + ((size_t)tc * B + rowc) * N + 4 * u);
-        const size_t mo = ((size_t)tc * B + rowc) * H + u;
-        hm = p.hmask ? (unsigned)p.hmask[mo] : 1u;
-        cm = p.cmask ? (unsigned)p.cmask[mo] : 1u;
-    };
-    // LSTM cell of (group = this wave, time tc): partial sums -> gates -> state; publishes h[tc + 1]
-    auto cell = [&](int tc) {
-        const float* redg = red + wave * (8 * 256);
-        float4 g4 = bias4;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) {
-            const float4 v = *reinterpret_cast<const float4*>(redg + w * 256 + rl * 16 + 4 * uu);
-            g4.x += v.x; g4.y += v.y; g4.z += v.z; g4.w += v.w;
-        }
-        g4.x += pre4.x; g4.y += pre4.y; g4.z += pre4.z; g4.w += pre4.w;
-        const float ig = sigmoidf_(g4.x), fg = sigmoidf_(g4.y), gg = tanhf_(g4.z), og = sigmoidf_(g4.w);
-        const float cp = c_state, hp = h_state;
-        const float cn = fg * cp + ig * gg;
-        const float hn = og * tanhf_(cn);
-        float ho, co = cn;
-        if (p.cell.zone == 1) { ho = hm ? hn : hp; co = cm ? cn : cp; }
-        else if (p.cell.zone == 2) { ho = p.cell.zh * hp + (1.f - p.cell.zh) * hn; co = p.cell.zc * cp + (1.f - p.cell.zc) * cn; }
-        else ho = p.hmask ? (hm ? hn * p.cell.hscale : 0.f) : hn;
-        c_state = co; h_state = ho;
-        const float4 h4 = ps_quad_gather(h_state);
-        if (cellthr) {
-            const size_t o = ((size_t)(tc + 1) * B + row) * H + u;
-            if (uu == 0) {
-                ps_xq_store4(xregion(wave, (tc + 1) & 1), rl, 4 * c, h4);
-                *reinterpret_cast<float4*>(p.h + o) = h4;
-            }
-            p.c[o] = c_state;
-            if (p.gates) {
-                float* go = p.gates + ((size_t)tc * B + row) * N + u;
-                go[0] = ig; go[H] = fg; go[2 * H] = gg; go[3 * H] = og;
-            }
-        }
-    };
-    // Only wave 7 touches the global counters (2048 pollers on eight cache lines would serialise behind each other): it samples
-    // them in the middle of its MFMA loop for the publish the NEXT group-step's prefetch needs, posts `seen[g] = publish number`
-    // to LDS before the group-step's __syncthreads, and is the one that spins when a publish is late.
-    volatile unsigned* seen = reinterpret_cast<volatile unsigned*>(red + NG * 8 * 256 + PS_PROF_WORDS);      // [NG] + [1] error flag
-    if (tid < 8) seen[tid] = 0;
-    __syncthreads();
-    auto wait_pub = [&](int g, unsigned pub) -> bool {
-        if (seen[g] >= pub) return true;
-        if (wave == 7) {
-            if (!ps_wait(bar, g, pub * per_pub)) { if (lane == 0) seen[NG] = 1; return false; }
-            if (lane == 0) seen[g] = pub;
-            return true;
-        }
-        unsigned spins = 0;
-        while (seen[g] < pub) {
-            __builtin_amdgcn_s_sleep(1);
-            if (seen[NG] != 0 || ++spins > (PS_SPIN_MAX << 2)) return false;
-        }
-        return true;
-    };
-    PsLoads<NBW> buf;
-    // group-step i: group g = i % NG, time t = t0 + i / NG, inputs = publish (i / NG + 1) of group g
-    auto gstep = [&](int i) -> bool {
-        const int g = i % NG, t = p.t0 + i / NG;
-        const int in = i + 1, gn = in % NG, tn = p.t0 + in / NG;
-        const bool has_next = in < n_gs;
-        PS_STAMP(stamps, 4 * i + 0, tid == 64 * 5);
-        if (NG >= 2 && wave == (g + NG - 1) % NG) {
-            // ---- cell wave of the previous group-step: cell, publish, drain, arrive - beside the others' MFMAs
-            if (i > 0) {
-                cell(p.t0 + (i - 1) / NG);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) ps_arrive(bar, wave);
-            }
-            if (has_next) {      // this wave multiplies again in the next group-step
-                int k0, k1; krange(gn, k0, k1);
-                if (!wait_pub(gn, (unsigned)(in / NG + 1))) return false;
-                ps_issue16<NBW>(buf, xregion(gn, tn & 1), k0, k1, lane);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
-            // ---- multiplying wave: loads of the NEXT group-step first, then this group-step's MFMAs
-            const bool want = NG >= 2 && has_next && wave != g;      // (wave g runs group g's cell during the next group-step)
-            const unsigned pubn = (unsigned)(in / NG + 1);
-            int kn0 = 0, kn1 = 0;
-            if (want) krange(gn, kn0, kn1);
-            const bool early = want && seen[gn] >= pubn;              // the next group-step's inputs have already landed
-            if (wave == g && cellwave) cell_prefetch(t);
-            __builtin_amdgcn_sched_barrier(0);
-            PS_STAMP(stamps, 4 * i + 1, tid == 64 * 5);
-            int k0, k1; krange(g, k0, k1);
-            if (early) ps_mma16<NBW, true>(buf, nkb, k0, wpl, red + (g * 8 + wave) * 256, lane, xregion(gn, tn & 1), kn0, kn1);
-            else ps_mma16<NBW, false>(buf, nkb, k0, wpl, red + (g * 8 + wave) * 256, lane, xregion(gn, tn & 1), kn0, kn1);
-            PS_STAMP(stamps, 4 * i + 2, tid == 64 * 5);
-            if (want && !early) {      // the publish was late: wait for it now, behind this group-step's arithmetic
-                if (!wait_pub(gn, pubn)) return false;
-                ps_issue16<NBW>(buf, xregion(gn, tn & 1), kn0, kn1, lane);
-            }
-            if (NG >= 2 && wave == 7 && i + 2 < n_gs) {      // what the prefetch of the next group-step will need
-                const int g2 = (i + 2) % NG; const unsigned pub2 = (unsigned)((i + 2) / NG + 1);
-                if (__all(ps_sample(bar, g2) >= pub2 * per_pub) && lane == 0) seen[g2] = pub2;
-            }
-        }
-        __syncthreads();
-        PS_STAMP(stamps, 4 * i + 3, tid == 64 * 5);
-        if (NG == 1) {      // single group: nothing to overlap with - cell, drain, arrive, and the partial sums are free again
-            if (wave == 0) { cell(t); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) ps_arrive(bar, 0); }
-            __syncthreads();
-            if (has_next) {
-                int k0, k1; krange(0, k0, k1);
-                if (!wait_pub(0, (unsigned)(in + 1))) return false;
-                ps_issue16<NBW>(buf, xregion(0, tn & 1), k0, k1, lane);
-            }
-        }
-        return true;
-    };
-    // prologue: loads of group-step 0
-    if (n_gs > 0 && !(NG >= 2 && wave == NG - 1)) {
-        int k0, k1; krange(0, k0, k1);
-        if (!wait_pub(0, 1u)) return;
-        ps_issue16<NBW>(buf, xregion(0, p.t0 & 1), k0, k1, lane);
-    }
-    for (int i = 0; i < n_gs; ++i)
-        if (!gstep(i)) return;
-    if (NG >= 2 && n_gs > 0 && wave == (n_gs - 1) % NG) cell(p.t1 - 1);      // the last group-step's cell
-#ifdef PS_PROF
-    __syncthreads();
-    if (p.prof && blockIdx.x == 0) for (int i = tid; i < PS_PROF; i += PS_THREADS) p.prof[i] = stamps[i];
-#endif
-}
-
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // pgen4: dataflow form of the pipelined recurrence.  Workgroup = 8 MULTIPLIER waves + one SERVICE wave per 16-row group (12 waves):
@@ -874,7 +702,7 @@ struct PsDec {
 constexpr int PD_LMAX = 128;         // encoder positions (8 waves x 16 rows)
 constexpr int PD_NCM = 9;            // memory float4 per thread in the context phase
 
-template <int RT>
+template <int RT, int PREC>
 __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void pdec_kernel(PsDec p) {
     extern __shared__ __attribute__((aligned(16))) char psm[];
     const int tid = threadIdx.x, lane = tid & 63, c = blockIdx.x;
@@ -883,7 +711,7 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     const int pad = (p.ksz - 1) >> 1;
     // ---- LDS carve
     float4* wl = reinterpret_cast<float4*>(psm);                                       // [nkb][2][64] float4
-    float* red = reinterpret_cast<float*>(psm + (size_t)nkb * 2048);                    // [8][64][16] (phase 1) / scratch (phase 2)
+    float* red = reinterpret_cast<float*>(psm + (size_t)nkb * (PREC ? 1024 : 2048));      // [8][64][16] (phase 1) / scratch (phase 2)
     float* Mt_s = red + 8 * 64 * 16;                                                    // [PD_LMAX][32]
     float* cumw = Mt_s + PD_LMAX * 32;                                                  // [PD_LMAX + 64] cumulative alignment with zero halo
     uint4* Upl = reinterpret_cast<uint4*>(cumw + PD_LMAX + 64);                         // [2 col tiles][3 planes][64 lanes]
@@ -908,13 +736,14 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     const int sbc = has_sample ? sb : 0;
     const int Dq = Dm >> 2, d0 = sj * Dq, nc4 = Dq >> 2, ng = PS_THREADS / nc4;
     const int len = min(p.lengths[sbc], L);
-    const unsigned xp_bytes = (unsigned)(64 * K * 4);
-    auto xregion = [&](int par) { return ps_rsrc(p.xp + (size_t)par * 64 * K, xp_bytes); };
+    const unsigned xp_bytes = (unsigned)(64 * K * (PREC ? 2 : 4));
+    auto xregion = [&](int par) { return ps_rsrc(reinterpret_cast<char*>(p.xp) + (size_t)par * xp_bytes, xp_bytes); };
 
     // ---- stationary data -> LDS
     {
-        const float4* src = reinterpret_cast<const float4*>(p.w_packed) + (size_t)c * nkb * 128;
-        for (int i = tid; i < nkb * 128; i += PS_THREADS) wl[i] = src[i];
+        const int per = PREC ? 64 : 128;                                // 16-byte quanta per k-block (bf16-packed / fp32-packed weights)
+        const float4* src = reinterpret_cast<const float4*>(p.w_packed) + (size_t)c * nkb * per;
+        for (int i = tid; i < nkb * per; i += PS_THREADS) wl[i] = src[i];
         for (int i = tid; i < L * 32; i += PS_THREADS) { const int l = i >> 5, a = i & 31; Mt_s[i] = p.Mt[((size_t)sbc * L + l) * A + 32 * sj + a]; }
         for (int i = tid; i < PD_LMAX + 64; i += PS_THREADS) {
             const int l = i - pad;
@@ -939,10 +768,10 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     }
     {   // exchange buffer of step t0: [ctx[t0] | h[t0]]
         const float4 h4 = ps_quad_gather(h_state);
-        if (cellthr && uu == 0) ps_st16_sc1(xregion(p.t0 & 1), ps_xp_off(row, Dm + 4 * c, nkb), h4);
+        if (cellthr && uu == 0) ps_publish4<PREC>(xregion(p.t0 & 1), row, Dm + 4 * c, nkb, h4);
         if (has_sample && tid < nc4) {
             const float4 c4v = *reinterpret_cast<const float4*>(p.ctx + ((size_t)p.t0 * B + sb) * Dm + d0 + 4 * tid);
-            ps_st16_sc1(xregion(p.t0 & 1), ps_xp_off(sb, d0 + 4 * tid, nkb), c4v);
+            ps_publish4<PREC>(xregion(p.t0 & 1), sb, d0 + 4 * tid, nkb, c4v);
         }
     }
     unsigned epoch = 0;
@@ -954,7 +783,8 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const size_t mo = ((size_t)t * B + rowc) * H + u;
         const unsigned hm = p.hmask ? (unsigned)p.hmask[mo] : 1u, cm = p.cmask ? (unsigned)p.cmask[mo] : 1u;
         PD_STAMP(0);
-        ps_gates<7, RT, 3>(xregion(t & 1), nkb, wl, red);
+        if (PREC) ps_gates_bf16<7, RT>(xregion(t & 1), nkb, reinterpret_cast<const uint4*>(wl), red);
+        else ps_gates<7, RT, 3>(xregion(t & 1), nkb, wl, red);
         PD_STAMP(1);
         __syncthreads();
         float4 ga;
@@ -962,7 +792,7 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         {
             const float4 h4 = ps_quad_gather(h_state);
             if (cellthr && uu == 0) {
-                ps_st16_sc1(xregion((t + 1) & 1), ps_xp_off(row, Dm + 4 * c, nkb), h4);
+                ps_publish4<PREC>(xregion((t + 1) & 1), row, Dm + 4 * c, nkb, h4);
                 // row-major copy (write-through): the sample role reads rows of it after the barrier
                 ps_st16_sc1(ps_rsrc(p.h + (size_t)(t + 1) * B * H, (unsigned)(B * H * 4)), (unsigned)((row * H + u) * 4), h4);
             }
@@ -1121,7 +951,7 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 float4 tt = make_float4(0.f, 0.f, 0.f, 0.f);
                 for (int k = 0; k < ng; ++k) { const float4 v4 = *reinterpret_cast<const float4*>(ctxp + (k * nc4 + tid) * 4); tt.x += v4.x; tt.y += v4.y; tt.z += v4.z; tt.w += v4.w; }
                 *reinterpret_cast<float4*>(p.ctx + ((size_t)(t + 1) * B + sb) * Dm + d0 + 4 * tid) = tt;
-                ps_st16_sc1(xregion((t + 1) & 1), ps_xp_off(sb, d0 + 4 * tid, nkb), tt);
+                ps_publish4<PREC>(xregion((t + 1) & 1), sb, d0 + 4 * tid, nkb, tt);
             }
         }
         PD_STAMP(8);
@@ -1166,7 +996,7 @@ MTTS_API long mtts_decoder_persist_ws_bytes(int B, int L, int H, int Dm, int A) 
 }
 
 bool pgen_supported(const DecoderArgs& a) {
-    return persist_enabled() && a.fast && a.precision == 0 && a.H == 4 * PS_WGS && a.B >= 1 && a.B <= 64 && a.persist_ws &&
+    return persist_enabled() && a.fast && (a.precision == 0 || a.precision == 1) && a.H == 4 * PS_WGS && a.B >= 1 && a.B <= 64 && a.persist_ws &&
            a.gen_w2p && a.gen_bias_u && a.pre_gen && a.persist_ws_bytes >= mtts_decoder_persist_ws_bytes(a.B, a.L, a.H, a.Dm, a.A);
 }
 
@@ -1193,7 +1023,7 @@ int pgen_launch(const DecoderArgs& a, int t0, int t1, hipStream_t s) {
     MTTS_CHECK_HIP(hipMemsetAsync(ws, 0, PS_ERR_OFF, s));           // counters (the error word is sticky until the host reads it)
     const int RT = (a.B + 15) / 16;
     static const int variant = [] { const char* e = getenv("MTTS_PGEN"); return e ? atoi(e) : 2; }();
-    if (variant == 4 || variant == 2) {      // dataflow pipeline: 8 multiplier waves + one service wave per 16-row group
+    if (variant != 1 && a.precision == 0) {      // dataflow pipeline: 8 multiplier waves + one service wave per 16-row group
         size_t lds4 = (size_t)RT * 8 * 256 * 4 + 64;
 #ifdef PS_PROF
         lds4 += PS_PROF * 8;
@@ -1204,35 +1034,21 @@ int pgen_launch(const DecoderArgs& a, int t0, int t1, hipStream_t s) {
         MTTS_CHECK_LAUNCH("pgen4_kernel");
         return 0;
     }
-    if (variant != 1) {      // round-robin pipeline over the 16-row groups
-        size_t lds3 = (size_t)(a.H / 32) * 3072 + (size_t)RT * 8 * 256 * 4 + 64;
-#ifdef PS_PROF
-        lds3 += PS_PROF * 8;
-#endif
-#define PGEN3_GO(G)                                                                                                          \
-    {                                                                                                                        \
-        MTTS_CHECK_HIP(hipFuncSetAttribute((const void*)pgen3_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); \
-        hipLaunchKernelGGL((pgen3_kernel<G>), dim3(PS_WGS), dim3(PS_THREADS), lds3, s, p);                                   \
-    }
-        if (RT == 1) PGEN3_GO(1) else if (RT == 2) PGEN3_GO(2) else if (RT == 3) PGEN3_GO(3) else PGEN3_GO(4)
-#undef PGEN3_GO
-        MTTS_CHECK_LAUNCH("pgen3_kernel");
-        return 0;
-    }
-    const size_t lds = (size_t)(a.H / 32) * 2048 + 8 * 64 * 16 * 4;
-#define PGEN_GO(R)                                                                                                          \
+    const size_t lds = (size_t)(a.H / 32) * (a.precision ? 1024 : 2048) + 8 * 64 * 16 * 4;
+#define PGEN_GO(R, PR)                                                                                                      \
     {                                                                                                                       \
-        MTTS_CHECK_HIP(hipFuncSetAttribute((const void*)pgen_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(pgen_kernel<R>, dim3(PS_WGS), dim3(PS_THREADS), lds, s, p);                                      \
+        MTTS_CHECK_HIP(hipFuncSetAttribute((const void*)pgen_kernel<R, PR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((pgen_kernel<R, PR>), dim3(PS_WGS), dim3(PS_THREADS), lds, s, p);                                \
     }
-    if (RT == 1) PGEN_GO(1) else if (RT == 2) PGEN_GO(2) else if (RT == 3) PGEN_GO(3) else PGEN_GO(4)
+    if (a.precision) { if (RT == 1) PGEN_GO(1, 1) else if (RT == 2) PGEN_GO(2, 1) else if (RT == 3) PGEN_GO(3, 1) else PGEN_GO(4, 1) }
+    else { if (RT == 1) PGEN_GO(1, 0) else if (RT == 2) PGEN_GO(2, 0) else if (RT == 3) PGEN_GO(3, 0) else PGEN_GO(4, 0) }
 #undef PGEN_GO
     MTTS_CHECK_LAUNCH("pgen_kernel");
     return 0;
 }
 
 bool pdec_supported(const DecoderArgs& a) {
-    if (!(persist_enabled() && a.fast && a.precision == 0 && a.H == 4 * PS_WGS && a.A == 128 && a.B >= 1 && a.B <= 64 && a.L >= 1 && a.L <= PD_LMAX &&
+    if (!(persist_enabled() && a.fast && (a.precision == 0 || a.precision == 1) && a.H == 4 * PS_WGS && a.A == 128 && a.B >= 1 && a.B <= 64 && a.L >= 1 && a.L <= PD_LMAX &&
           a.persist_ws && a.att_w2p && a.att_bias_u && a.att_w_pre_u && a.pre_att && (a.Dm & 31) == 0 && (a.Dm + a.H) / 32 <= 56 &&
           (a.ksz & 1) == 1 && a.ksz <= 32 && a.persist_ws_bytes >= mtts_decoder_persist_ws_bytes(a.B, a.L, a.H, a.Dm, a.A)))
         return false;
@@ -1264,18 +1080,19 @@ int pdec_launch(const DecoderArgs& a, int t0, int t1, hipStream_t s) {
     p.eg = (unsigned long long*)(ws + ps_ws_eg_off(a.H, a.Dm));
     MTTS_CHECK_HIP(hipMemsetAsync(ws, 0, PS_ERR_OFF, s));
     MTTS_CHECK_HIP(hipMemsetAsync(p.eg, 0, (size_t)64 * 4 * PD_LMAX * 8, s));
-    size_t lds = (size_t)((a.Dm + a.H) / 32) * 2048 + 8 * 64 * 16 * 4 + PD_LMAX * 32 * 4 + (PD_LMAX + 64) * 4 + 2 * 3 * 64 * 16 + 64 * 4;
+    size_t lds = (size_t)((a.Dm + a.H) / 32) * (a.precision ? 1024 : 2048) + 8 * 64 * 16 * 4 + PD_LMAX * 32 * 4 + (PD_LMAX + 64) * 4 + 2 * 3 * 64 * 16 + 64 * 4;
 #ifdef PS_PROF
     lds += 300 * 8;
     MTTS_CHECK_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_ps_prof_dev), &g_ps_prof, sizeof(g_ps_prof), 0, hipMemcpyHostToDevice, s));
 #endif
     const int RT = (a.B + 15) / 16;
-#define PDEC_GO(R)                                                                                                          \
+#define PDEC_GO(R, PR)                                                                                                      \
     {                                                                                                                       \
-        MTTS_CHECK_HIP(hipFuncSetAttribute((const void*)pdec_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(pdec_kernel<R>, dim3(PS_WGS), dim3(PS_THREADS), lds, s, p);                                      \
+        MTTS_CHECK_HIP(hipFuncSetAttribute((const void*)pdec_kernel<R, PR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((pdec_kernel<R, PR>), dim3(PS_WGS), dim3(PS_THREADS), lds, s, p);                                \
     }
-    if (RT == 1) PDEC_GO(1) else if (RT == 2) PDEC_GO(2) else if (RT == 3) PDEC_GO(3) else PDEC_GO(4)
+    if (a.precision) { if (RT == 1) PDEC_GO(1, 1) else if (RT == 2) PDEC_GO(2, 1) else if (RT == 3) PDEC_GO(3, 1) else PDEC_GO(4, 1) }
+    else { if (RT == 1) PDEC_GO(1, 0) else if (RT == 2) PDEC_GO(2, 0) else if (RT == 3) PDEC_GO(3, 0) else PDEC_GO(4, 0) }
 #undef PDEC_GO
     MTTS_CHECK_LAUNCH("pdec_kernel");
     return 0;

@@ -29,6 +29,28 @@ import torch.nn.functional as F
 # helpers
 # --------------------------------------------------------------------------------------------------
 
+# bf16-operand mode (tests of the product's bf16 path only; the reference itself is fp32): the product rounds the OPERANDS of its
+# GEMM-class contractions to bf16 (RNE) and keeps everything else in fp32.  `BF16_SITES` names the contraction sites
+# that round; `_lin` / `_conv` apply the same rounding here, so that an oracle run differs from the product only by summation order.
+# Sites: 'conv' (conv blocks incl. post-net), 'bilstm_in' (BiLSTM input projection), 'lstm' (decoder LSTM gates, both operands),
+# 'memory' (memory projection), 'loc' (the location filter bank U = W_loc W_conv is formed from rounded factors), 'prenet',
+# 'proj' (frame / stop projection), 'linear' (classifier / generator bottlenecks).  Never rounded (fp32 in the product): BiLSTM
+# recurrent product, query projection, U applied to the cumulative alignment, energies, softmax, context.
+BF16_SITES = frozenset()
+
+
+def _r(x, site):
+    return x.to(torch.bfloat16).to(torch.float32) if site in BF16_SITES else x
+
+
+def _lin(site, x, w, b=None):
+    return F.linear(_r(x, site), _r(w, site), b)
+
+
+def _conv(site, x, w, *args):
+    return F.conv1d(_r(x, site), _r(w, site), *args)
+
+
 def _mask(masks, name, x):
     m = None if masks is None else masks.get(name)
     return x if m is None else x * m
@@ -82,7 +104,7 @@ def conv_block(sd, prefix, x, kernel, activation, masks, mask_name, training, di
     """ConvBlock: pad -> Conv1d(bias=False) -> BatchNorm1d(eps 1e-5, momentum .1) -> act -> dropout.
     reference modules/layers.py:66-86; Sequential indices: 0 pad, 1 conv, 2 bn."""
     x = _same_pad(x, kernel, dilation)
-    x = F.conv1d(x, sd[prefix + '._block.1.weight'], None, 1, 0, dilation, groups)
+    x = _conv('conv', x, sd[prefix + '._block.1.weight'], None, 1, 0, dilation, groups)
     x = batch_norm(x, sd[prefix + '._block.2.weight'], sd[prefix + '._block.2.bias'],
                    sd[prefix + '._block.2.running_mean'], sd[prefix + '._block.2.running_var'],
                    training, 0.1, 1e-5, stats_out, prefix + '._block.2')
@@ -130,9 +152,9 @@ def generated_conv_block(sd, prefix, e, x, in_ch, out_ch, kernel, activation, ma
 # LSTM pieces
 # --------------------------------------------------------------------------------------------------
 
-def lstm_cell(x, h, c, w_ih, w_hh, b_ih, b_hh):
+def lstm_cell(x, h, c, w_ih, w_hh, b_ih, b_hh, site_x='lstm', site_h='lstm'):
     """torch.nn.LSTMCell arithmetic (gate order i, f, g, o) - reference modules/layers.py:18,37."""
-    gates = F.linear(x, w_ih, b_ih) + F.linear(h, w_hh, b_hh)
+    gates = _lin(site_x, x, w_ih, b_ih) + _lin(site_h, h, w_hh, b_hh)
     i, f, g, o = gates.chunk(4, 1)
     c_new = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
     h_new = torch.sigmoid(o) * torch.tanh(c_new)
@@ -154,7 +176,7 @@ def bilstm_packed(sd, prefix, x, lengths):
         outs = [None] * L
         for t in steps:
             valid = (lengths > t).to(x.dtype)[:, None]
-            h_new, c_new = lstm_cell(x[:, t], h, c, w_ih, w_hh, b_ih, b_hh)
+            h_new, c_new = lstm_cell(x[:, t], h, c, w_ih, w_hh, b_ih, b_hh, 'bilstm_in', 'bilstm_rec')
             h = valid * h_new + (1 - valid) * h
             c = valid * c_new + (1 - valid) * c
             outs[t] = h * valid
@@ -249,7 +271,7 @@ def prenet(sd, x, masks, name):
     """Prenet.forward: Linear -> ReLU -> dropout(always on), reference modules/tacotron2.py:37-46."""
     i = 0
     while f'_prenet._layers.{i}.weight' in sd:
-        x = torch.relu(F.linear(x, sd[f'_prenet._layers.{i}.weight'], sd[f'_prenet._layers.{i}.bias']))
+        x = torch.relu(_lin('prenet', x, sd[f'_prenet._layers.{i}.weight'], sd[f'_prenet._layers.{i}.bias']))
         x = _mask(masks, f'{name}.{i}', x)
         i += 1
     return x
@@ -261,8 +283,14 @@ def lsa_step(sd, query, memory, memory_transform, cum_weights, mask):
     p = '_attention'
     q = F.linear(query, sd[p + '._query.weight']).unsqueeze(1)                          # [B,1,A]
     ksz = sd[p + '._loc_features.weight'].shape[2]
-    loc = F.conv1d(cum_weights.unsqueeze(1), sd[p + '._loc_features.weight'], None, 1, (ksz - 1) // 2)
-    loc = F.linear(loc.transpose(1, 2), sd[p + '._location.weight'])                    # [B,L,A]
+    if 'loc' in BF16_SITES:
+        # product: the two location layers are folded into ONE filter bank U = W_loc W_conv by a (rounded-operand) GEMM, then U is
+        # applied to the cumulative alignment in fp32
+        U = _r(sd[p + '._location.weight'], 'loc') @ _r(sd[p + '._loc_features.weight'].squeeze(1), 'loc')       # [A, ksz]
+        loc = F.conv1d(cum_weights.unsqueeze(1), U.unsqueeze(1), None, 1, (ksz - 1) // 2).transpose(1, 2)
+    else:
+        loc = F.conv1d(cum_weights.unsqueeze(1), sd[p + '._loc_features.weight'], None, 1, (ksz - 1) // 2)
+        loc = F.linear(loc.transpose(1, 2), sd[p + '._location.weight'])                    # [B,L,A]
     energy = torch.tanh(q + memory_transform + loc + sd[p + '._bias'])
     energy = F.linear(energy, sd[p + '._energy.weight']).squeeze(-1)                    # [B,L]
     energy = energy.masked_fill(~mask, float('-inf'))
@@ -302,7 +330,7 @@ def decode(sd, cfg, encoded, mask, target, teacher, speaker, language, masks, tr
         encoded = torch.cat((encoded, F.embedding(speaker, sd['_decoder._speaker_embedding.weight'])), -1)
     if cfg['multi_language'] and '_decoder._language_embedding.weight' in sd:
         encoded = torch.cat((encoded, F.embedding(language, sd['_decoder._language_embedding.weight'])), -1)
-    memory_transform = F.linear(encoded, sd['_attention._memory.weight'])
+    memory_transform = _lin('memory', encoded, sd['_attention._memory.weight'])
     cum = encoded.new_zeros(B, L)
     context = encoded.new_zeros(B, encoded.shape[2])
     h_att = encoded.new_zeros(B, H); c_att = encoded.new_zeros(B, H)
@@ -328,8 +356,8 @@ def decode(sd, cfg, encoded, mask, target, teacher, speaker, language, masks, tr
         h_gen, c_gen = decoder_cell(sd, '_generator_lstm', cfg, torch.cat((h_att, context), 1), h_gen, c_gen, sm,
                                     'gen_lstm', training)
         proto = torch.cat((h_gen, context), 1)
-        frame = F.linear(proto, sd['_decoder._frame_prediction.weight'], sd['_decoder._frame_prediction.bias'])
-        stop = F.linear(proto, sd['_decoder._stop_prediction.weight'], sd['_decoder._stop_prediction.bias'])
+        frame = _lin('proj', proto, sd['_decoder._frame_prediction.weight'], sd['_decoder._frame_prediction.bias'])
+        stop = _lin('proj', proto, sd['_decoder._stop_prediction.weight'], sd['_decoder._stop_prediction.bias'])
         frames.append(frame); stops.append(stop); aligns.append(weights)
         if inference and stop_rule and bool(torch.sigmoid(stop).ge(0.5).all()):          # :201-207 (batch 1)
             if stop_frames == -1:
@@ -353,8 +381,8 @@ def postnet(sd, cfg, x, masks, training, stats_out=None):
 
 def reversal_classifier(sd, x):
     """ReversalClassifier.forward (forward = identity, two Linears), reference modules/classifier.py:57-60."""
-    x = F.linear(x, sd['_reversal_classifier._classifier.0.weight'], sd['_reversal_classifier._classifier.0.bias'])
-    return F.linear(x, sd['_reversal_classifier._classifier.1.weight'], sd['_reversal_classifier._classifier.1.bias'])
+    x = _lin('linear', x, sd['_reversal_classifier._classifier.0.weight'], sd['_reversal_classifier._classifier.0.bias'])
+    return _lin('linear', x, sd['_reversal_classifier._classifier.1.weight'], sd['_reversal_classifier._classifier.1.bias'])
 
 
 class _GradReverse(torch.autograd.Function):

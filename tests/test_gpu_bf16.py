@@ -94,3 +94,13 @@ def test_bf16_decoder_at_real_widths_tracks_the_fp32_path(bf16_mode):
         a, b = outs['bf16'][i], outs['fp32'][i]
         err = ((a - b).double().norm() / b.double().norm()).item()
         assert 0 < err <= 5e-2, f'{name}: relative L2 error {err:.3e}'
+
+
+@pytest.mark.parametrize('B,T', [(16, 49), (40, 30)])
+def test_bf16_path_matches_the_oracle_with_bf16_rounded_operands(B, T):
+    """shared_training at the real widths (persistent bf16 decoder kernels: B <= 64), forward in train mode with injected dropout
+    draws, against the CPU oracle run with the SAME operand rounding (oracle.BF16_SITES): relative L2 <= 2e-3 on encoder output,
+    decoder mels and alignments (2e-2 behind the post-net) - tight enough to catch a wrong-but-plausible kernel, which the 5e-2 bound
+    against the fp32 fixtures is not."""
+    from tests.test_gpu_more import run_train_step_case
+    run_train_step_case('shared_training', B, 30, T, {}, check_grads=False, bf16=True)
