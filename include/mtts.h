@@ -394,6 +394,8 @@ typedef struct DecoderArgs {
        once, mtts_decoder_persist_ws_bytes(B, L, H, Dm, A) bytes; NULL -> per-step launches everywhere */
     void* persist_ws;
     long persist_ws_bytes;
+    int* persist_err;      /* optional long-lived device error word of the persistent kernels (0 = ok, 2 = a grid barrier gave up);
+                              NULL -> the word inside persist_ws (mtts_decoder_persist_status) */
 } DecoderArgs;
 
 int mtts_decoder_fwd(const DecoderArgs* args, void* stream);
@@ -403,6 +405,16 @@ int mtts_decoder_fwd(const DecoderArgs* args, void* stream);
  * stream.  *replayed (nullable) = 1 when a graph ran.  Replaces the per-step Python / kernel-launch loop of
  * Decoder.inference (modules/tacotron2.py:216-219,178-207) for BASELINE configs[4]. */
 int mtts_decoder_fwd_graphed(const DecoderArgs* args, void* stream, int* replayed);
+/* Destroys the graphs captured for `stream` (call when the fixed-address buffers they were captured over are retired). */
+int mtts_decoder_graphs_clear(void* stream);
+/* Stop rule of batched free-running synthesis evaluated ON THE DEVICE (reference Decoder._decode, modules/tacotron2.py:201-207, per
+ * sample): walks the stop logits of frames [t0, t1) in `out` ([T+1][B][Mo], column M of slot t+1 = frame t) and updates
+ * state[0..B) = armed counters (-1 = not armed), state[B..2B) = frame count at which the utterance ended (-1 = running);
+ * *running (device int, one word per in-flight chunk) = utterances still running after this chunk.  The caller fills `state` with
+ * -1 before the first chunk and reads ONE int per chunk instead of copying every stop logit to the host.
+ * stop_threshold = probability (>= 1: never stop). */
+int mtts_stop_rule_update(const float* out, int t0, int t1, int B, int Mo, int M, float stop_threshold, int stop_frames, int* state,
+                          int* running, void* stream);
 /* Persistent (weights-stationary, one launch for all steps) recurrences of the teacher-forced schedule (csrc/persist.hip; replace the
  * per-step LSTMCell / attention launches of Decoder._decode, modules/tacotron2.py:180-193).  mtts_decoder_fwd uses them when
  * DecoderArgs.persist_ws is set, the shape fits (H = 1024, B <= 64, fp32) and MTTS_PERSIST != 0.

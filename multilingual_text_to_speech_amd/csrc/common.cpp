@@ -184,6 +184,17 @@ MTTS_API int mtts_set_stream_workspace(void* stream, void* ptr, size_t bytes) {
 // with ONE hipGraphLaunch afterwards.  The caller keeps the buffers alive and at the same addresses between calls
 // (decoder_ops.GraphedDecode does); `stream` must not be the legacy default stream.  The first call with a new argument block
 // runs eagerly, the second one captures, later ones replay.  Returns 0 on success; *replayed (nullable) says which path ran.
+// Destroy every captured graph of `stream` (a caller that retires a set of fixed-address buffers calls this: the graphs keyed by
+// those addresses can never be replayed again).  Returns the number of graphs destroyed.
+MTTS_API int mtts_decoder_graphs_clear(void* stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    StreamCtx* c = ctx_locked((hipStream_t)stream);
+    const int n = (int)c->graphs.size();
+    for (GraphEntry* g : c->graphs) { if (g->exec) (void)hipGraphExecDestroy(g->exec); if (g->graph) (void)hipGraphDestroy(g->graph); delete g; }
+    c->graphs.clear();
+    return n;
+}
+
 MTTS_API int mtts_decoder_fwd_graphed(const DecoderArgs* args, void* stream, int* replayed) {
     hipStream_t s = (hipStream_t)stream;
     if (replayed) *replayed = 0;
@@ -210,7 +221,12 @@ MTTS_API int mtts_decoder_fwd_graphed(const DecoderArgs* args, void* stream, int
         if (replayed) *replayed = 1;
         return 0;
     }
-    if (e->seen++ == 0) return mtts_decoder_fwd(args, stream);
+    bool first;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        first = e->seen++ == 0;
+    }
+    if (first) return mtts_decoder_fwd(args, stream);
     MTTS_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     const int rc = mtts_decoder_fwd(args, stream);
     hipGraph_t graph = nullptr;

@@ -305,3 +305,52 @@ int sum_slabs(const float* part, int n, long stride, int ldp, const float* bias,
     MTTS_CHECK_LAUNCH("sum_slabs_kernel");
     return 0;
 }
+
+// ---- stop rule of batched free-running synthesis, on the device ---------------------------------------------------------------------
+// Reference Decoder._decode, modules/tacotron2.py:201-207 (batch 1): a frame whose stop probability reaches the threshold arms a
+// counter (stop_frames) the first time and decrements it afterwards; the utterance ends at the frame where the counter reaches 0.
+// Per sample b over the frames [t0, t1) of `out` ([T+1][B][Mo], stop logit in column M, slot t+1 = frame t):
+//   state[b] = armed (-1 = not armed), state[B + b] = done (-1 = running, else the frame count); *running = samples still running.
+// One thread per sample walks its frames in order (the rule is sequential in t); the host reads ONE int per chunk.
+__global__ void stop_rule_kernel(const float* __restrict__ out, int t0, int t1, int B, int Mo, int M, float logit_threshold, int stop_frames,
+                                 int* __restrict__ state, int* __restrict__ running_out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    int running = 0;
+    if (b < B) {
+        int armed = state[b], done = state[B + b];
+        for (int t = t0; t < t1 && done < 0; ++t) {
+            const bool f = out[((long)(t + 1) * B + b) * Mo + M] >= logit_threshold;      // sigmoid(x) >= p  <=>  x >= logit(p)
+            if (f) {
+                if (armed == -1) armed = stop_frames;
+                else if (--armed == 0) done = t + 1;
+            }
+        }
+        state[b] = armed; state[B + b] = done;
+        running = done < 0;
+    }
+    // running count (block-level, then one atomic per block into a zeroed word)
+    __shared__ int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    if (running) atomicAdd(&cnt, 1);
+    __syncthreads();
+    if (threadIdx.x == 0 && cnt) atomicAdd(running_out, cnt);
+}
+
+// state: int[2B] device array, filled with -1 before the FIRST chunk; *running (device int, cleared here on the stream) receives the
+// number of utterances still running after this chunk - give every in-flight chunk its own word.  stop_threshold in (0, 1) is the
+// probability threshold (>= 1 disables the rule).
+MTTS_API int mtts_stop_rule_update(const float* out, int t0, int t1, int B, int Mo, int M, float stop_threshold, int stop_frames, int* state,
+                                   int* running, void* stream) {
+    MTTS_REQUIRE(B > 0 && t1 >= t0 && M < Mo && stop_frames >= 1, "mtts_stop_rule_update: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    MTTS_REQUIRE(state && running, "mtts_stop_rule_update: state / running are required");
+    MTTS_CHECK_HIP(hipMemsetAsync(running, 0, sizeof(int), s));
+    float thr;
+    if (stop_threshold >= 1.f) thr = INFINITY;
+    else if (stop_threshold <= 0.f) thr = -INFINITY;
+    else thr = logf(stop_threshold / (1.f - stop_threshold));
+    hipLaunchKernelGGL(stop_rule_kernel, dim3((B + 127) / 128), dim3(128), 0, s, out, t0, t1, B, Mo, M, thr, stop_frames, state, running);
+    MTTS_CHECK_LAUNCH("stop_rule_kernel");
+    return 0;
+}

@@ -1017,7 +1017,7 @@ int pgen_launch(const DecoderArgs& a, int t0, int t1, hipStream_t s) {
         p.hmask = a.gen_hmask; p.cell.hscale = 1.f / (1.f - a.p_hidden);
     }
     char* ws = (char*)a.persist_ws;
-    p.sync.cnt = (unsigned*)ws; p.sync.err = (unsigned*)(ws + PS_ERR_OFF);
+    p.sync.cnt = (unsigned*)ws; p.sync.err = a.persist_err ? (unsigned*)a.persist_err : (unsigned*)(ws + PS_ERR_OFF);
     p.xp = (float*)(ws + ps_ws_gen_off());
     p.prof = g_ps_prof;
     MTTS_CHECK_HIP(hipMemsetAsync(ws, 0, PS_ERR_OFF, s));           // counters (the error word is sticky until the host reads it)
@@ -1075,7 +1075,7 @@ int pdec_launch(const DecoderArgs& a, int t0, int t1, hipStream_t s) {
     p.w_query = a.w_query; p.memory = a.memory; p.Mt = a.Mt; p.U = a.U; p.att_bias = a.att_bias; p.v = a.w_energy; p.lengths = a.lengths;
     p.ctx = a.ctx; p.cum = a.cum; p.align = a.align; p.q_all = a.q_all;
     char* ws = (char*)a.persist_ws;
-    p.sync.cnt = (unsigned*)ws; p.sync.err = (unsigned*)(ws + PS_ERR_OFF);
+    p.sync.cnt = (unsigned*)ws; p.sync.err = a.persist_err ? (unsigned*)a.persist_err : (unsigned*)(ws + PS_ERR_OFF);
     p.xp = (float*)(ws + ps_ws_att_off(a.H));
     p.eg = (unsigned long long*)(ws + ps_ws_eg_off(a.H, a.Dm));
     MTTS_CHECK_HIP(hipMemsetAsync(ws, 0, PS_ERR_OFF, s));

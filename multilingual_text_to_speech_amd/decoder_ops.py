@@ -139,6 +139,9 @@ def fill_decoder_args(a, st, w, memory, lengths32, frames_in, teacher_host, mask
     a.kq, a.fast, a.precision = st.kq, int(st.fast), st.precision
     ws = getattr(st, 'persist_ws', None)
     a.persist_ws, a.persist_ws_bytes = ptr(ws), (ws.numel() if ws is not None else 0)
+    if ws is not None:
+        from .kernels import _err_flag
+        a.persist_err = ctypes.c_void_p(_err_flag(ws.device).data_ptr() + 4)      # kernels.check_device_errors() reads it
     return a
 
 
@@ -232,13 +235,26 @@ class GraphedDecode:
     frame+stop projection.  One session per (device, B, L, dims, frames, precision); the library keys its graphs by the exact
     argument block, runs a new block eagerly once, captures it the second time and replays it afterwards."""
     _cache = {}
+    MAX_SESSIONS = 4          # a session pins ~frames x 0.7 MB per utterance of device memory: least-recently-used sessions are retired
+    L_BUCKET = 32             # memories are zero-padded to a multiple of this many positions (lengths mask the padding), so that
+                              # utterances of similar length share one session and its graphs instead of capturing per length
+
+    @classmethod
+    def bucket(cls, L):
+        return ((L + cls.L_BUCKET - 1) // cls.L_BUCKET) * cls.L_BUCKET
 
     @classmethod
     def get(cls, B, L, frames, dims, dev, n_prenet, kq, precision):
         key = (torch.device(dev).index or 0, B, L, frames, tuple(dims), n_prenet, kq, precision)
-        if key not in cls._cache:
-            cls._cache[key] = cls(B, L, frames, dims, dev, n_prenet, kq, precision)
-        return cls._cache[key]
+        sess = cls._cache.pop(key, None)
+        if sess is None:
+            while len(cls._cache) >= cls.MAX_SESSIONS:          # retire the least recently used session and its graphs
+                old = cls._cache.pop(next(iter(cls._cache)))
+                with torch.cuda.device(old.memory.device):
+                    lib().mtts_decoder_graphs_clear(ctypes.c_void_p(old.stream.cuda_stream))
+            sess = cls(B, L, frames, dims, dev, n_prenet, kq, precision)
+        cls._cache[key] = sess                                   # (re)insert as most recently used
+        return sess
 
     def __init__(self, B, L, frames, dims, dev, n_prenet, kq, precision):
         M, P, H, A, Dm, ksz, C = dims
@@ -306,7 +322,10 @@ def decode_free(memory, lengths, w, cfg, masks, max_frames, stop_frames, chunk=3
     mask_fn = masks if callable(masks) else None
     session = None
     if graph and max_frames <= 2048:          # hipGraph replay: fixed buffers for the whole range (mtts_decoder_fwd_graphed)
-        session = GraphedDecode.get(B, L, max_frames, (M, P, H, A, Dm, ksz, C), dev, len(w['prenet_w']), cfg.get('kq', 8),
+        Lb = GraphedDecode.bucket(L)
+        if Lb != L:                            # pad the memory to the bucket length; the per-sample lengths mask the padding
+            memory = torch.cat((memory, memory.new_zeros(B, Lb - L, Dm)), 1)
+        session = GraphedDecode.get(B, Lb, max_frames, (M, P, H, A, Dm, ksz, C), dev, len(w['prenet_w']), cfg.get('kq', 8),
                                     cfg.get('precision', _C.get_precision()))
         caller = torch.cuda.current_stream(dev)
         session.stream.wait_stream(caller)
@@ -314,6 +333,8 @@ def decode_free(memory, lengths, w, cfg, masks, max_frames, stop_frames, chunk=3
             out = _decode_free_loop(memory, lengths, w, cfg, mask_fn(max_frames) if mask_fn is not None else masks, max_frames, stop_frames,
                                     chunk, stop_threshold, session, dev, M)
         caller.wait_stream(session.stream)
+        if Lb != L:
+            out = (out[0], out[1], out[2][:, :, :L].contiguous(), out[3])
         for t in out[:3]:
             t.record_stream(caller)
         return out
@@ -334,17 +355,18 @@ def _decode_free_loop(memory, lengths, w, cfg, masks, max_frames, stop_frames, c
         if mask_fn is not None:
             masks = mask_fn(cap)
         st = DecoderState(B, L, cap, (M, P, H, A, Dm, ksz, C), dev, len(w['prenet_w']), save_gates=False, fast=False,
-                          kq=cfg.get('kq', 8))
+                          kq=cfg.get('kq', 8), precision=cfg.get('precision', _C.get_precision()))
     lengths32 = lengths.to(device=dev, dtype=torch.int32).contiguous()
-    # The stop rule is evaluated on the host per chunk while the device already runs the NEXT chunk (speculatively): the
-    # stop logits of chunk k leave through a copy stream once an event after chunk k has fired.
-    import numpy as np
-    armed = np.full(B, -1, dtype=np.int64)
-    done = np.full(B, -1, dtype=np.int64)
+    # The stop rule runs ON THE DEVICE (mtts_stop_rule_update: per-sample armed / done counters in a device int array); after
+    # each chunk ONE int - how many utterances are still running - travels to the host through a copy stream, while the device
+    # already runs the NEXT chunk (speculatively).
+    state = torch.full((2 * B,), -1, dtype=torch.int32, device=dev)
+    ring = torch.zeros(8, dtype=torch.int32, device=dev)          # running counts of the chunks in flight (two at a time)
+    n_sub = 0
     copy_stream = _copy_stream(dev)
 
     def submit(t):
-        nonlocal st, masks, cap
+        nonlocal st, masks, cap, n_sub
         t1 = min(max_frames, t + chunk)
         if t1 > cap:                                 # outgrown: double the per-step buffers, keep what has been decoded
             cap = min(max_frames, max(2 * cap, t1))
@@ -354,34 +376,31 @@ def _decode_free_loop(memory, lengths, w, cfg, masks, max_frames, stop_frames, c
             session.run(w, cfg, t, t1)
         else:
             run_decoder(st, w, memory, lengths32, None, None, masks, cfg, t, t1)
-        flags = (torch.sigmoid(st.out[t + 1:t1 + 1, :, M]) >= stop_threshold)
+        slot = ring[n_sub % 8:n_sub % 8 + 1]
+        n_sub += 1
+        check(lib().mtts_stop_rule_update(ptr(st.out), t, t1, B, st.Mo, M, ctypes.c_float(stop_threshold), int(stop_frames), ptr(state),
+                                          ptr(slot), stream_ptr()), 'mtts_stop_rule_update')
+        running = torch.empty(1, dtype=torch.int32, pin_memory=True)
         ev = torch.cuda.Event()
         ev.record()
-        return t, t1, flags, ev
-
-    def evaluate(t, t1, flags, ev):
         with torch.cuda.stream(copy_stream):
             copy_stream.wait_event(ev)
-            flags.record_stream(copy_stream)
-            host = flags.to('cpu', non_blocking=False).numpy()
-        for i in range(t1 - t):
-            f = host[i] & (done < 0)
-            first = f & (armed == -1)
-            again = f & (armed != -1)
-            armed[first] = stop_frames
-            armed[again] -= 1
-            done[again & (armed == 0)] = t + i + 1
+            running.copy_(slot, non_blocking=True)
+            done_ev = torch.cuda.Event()
+            done_ev.record()
+        return t1, running, done_ev
 
     pending = submit(0) if max_frames > 0 else None
     while pending is not None:
-        nxt = submit(pending[1]) if pending[1] < max_frames else None
-        evaluate(*pending)
-        if (done >= 0).all():
+        nxt = submit(pending[0]) if pending[0] < max_frames else None
+        pending[2].synchronize()
+        if int(pending[1][0]) == 0:
             break
         pending = nxt
     torch.cuda.current_stream(dev).synchronize()
-    done = [int(d) if d >= 0 else None for d in done]
-    n = [d if d is not None else max_frames for d in done]
+    done = state[B:].tolist()
+    # (a speculative chunk may have run past the point where the last utterance ended: `done` is final once set)
+    n = [d if d >= 0 else max_frames for d in done]
     Tn = max(n)
     frames = st.out[1:Tn + 1, :, :M].transpose(0, 1).contiguous()
     stop = st.out[1:Tn + 1, :, M].transpose(0, 1).contiguous()

@@ -117,19 +117,26 @@ _ERR_FLAGS = {}
 
 
 def _err_flag(device):
-    """One device int per GPU, raised by kernels that met invalid input (an embedding id outside its table)."""
+    """Two device ints per GPU: [0] raised by kernels that met invalid input (an embedding id outside its table), [1] by a persistent
+    decoder kernel whose grid barrier gave up (DecoderArgs.persist_err)."""
     key = torch.device(device).index or 0
     if key not in _ERR_FLAGS:
-        _ERR_FLAGS[key] = torch.zeros(1, dtype=torch.int32, device=device)
+        _ERR_FLAGS[key] = torch.zeros(2, dtype=torch.int32, device=device)
     return _ERR_FLAGS[key]
 
 
 def check_device_errors(device=None):
-    """Raise if a kernel flagged invalid input since the last check (synchronises; call once per step / synthesis call)."""
+    """Raise if a kernel flagged invalid input since the last check, or if a persistent decoder kernel gave up on a grid barrier
+    (synchronises; call once per step / synthesis call)."""
     for key, flag in list(_ERR_FLAGS.items()):
         if device is not None and (torch.device(device).index or 0) != key:
             continue
-        if int(flag.item()) != 0:
+        v = flag.tolist()
+        if v[1] != 0:
+            flag.zero_()
+            raise _C.MttsError(f'a persistent decoder kernel reported error {v[1]} (2 = a grid barrier timed out: the decode of that call '
+                               'is invalid); set MTTS_PERSIST=0 to run the per-step launch schedule')
+        if v[0] != 0:
             flag.zero_()
             raise _C.MttsError('an embedding id was outside its table (symbol id >= symbols_count()+3, speaker id >= '
                                'hp.speaker_number or language id >= hp.language_number); the row was read as zeros')

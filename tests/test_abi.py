@@ -56,7 +56,7 @@ def test_buffer_size_queries_cover_every_caller_allocated_buffer(library):
     assert q('persist_ws') == library.mtts_decoder_persist_ws_bytes(64, 120, 1024, 544, 128) > 0
     assert q('no_such_field') == -1
     inputs = {'memory', 'lengths', 'frames_in', 'teacher', 'prenet_w', 'prenet_b', 'prenet_mask', 'att_hmask', 'att_cmask', 'gen_hmask', 'gen_cmask',
-              'prenet_wp', 'prenet_act'}
+              'prenet_wp', 'prenet_act', 'persist_err'}
     weights = {n for n, _ in _C.DecoderArgs._fields_ if n.startswith(('att_w_', 'att_b_', 'gen_w_', 'gen_b_', 'w_', 'b_')) and not n.endswith(('_p', '_u', '2p'))}
     weights |= {'att_bias'}
     for name, ctype in _C.DecoderArgs._fields_:
