@@ -189,11 +189,13 @@ __device__ __forceinline__ bool ps_barrier(const PsSync& s, unsigned epoch) {
 //   from the exchange buffer (sc1 loads, DEPTH blocks in flight), takes its weight fragments from LDS and leaves its
 //   [16 RT rows x 16 columns] partial sums in red[w][row][col].
 // ---------------------------------------------------------------------------------------------------------------------------
+// acc += this wave's share of the k-blocks [kb_lo, kb_hi) (the eight waves split the range; at most NBW blocks per wave)
 template <int NBW, int RT, int DEPTH>
-__device__ __forceinline__ void ps_gates(__amdgpu_buffer_rsrc_t xr, int nkb, const float4* __restrict__ wl, float* __restrict__ red) {
+__device__ __forceinline__ void ps_gates_acc(__amdgpu_buffer_rsrc_t xr, int nkb, int kb_lo, int kb_hi, const float4* __restrict__ wl, f32x4 (&acc)[RT]) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int k0 = (nkb * wave) >> 3, k1 = (nkb * (wave + 1)) >> 3;
+    const int nrange = kb_hi - kb_lo;
+    const int k0 = kb_lo + ((nrange * wave) >> 3), k1 = kb_lo + ((nrange * (wave + 1)) >> 3);
     float4 xa[DEPTH][RT][2];
     // fragment (rt, kb): byte offset ((rt * nkb + kb) * 2 + hf) * 1024 + lane * 16; blocks past k1 read out of range (= 0)
     auto issue = [&](int j, int slot) {
@@ -210,9 +212,6 @@ __device__ __forceinline__ void ps_gates(__amdgpu_buffer_rsrc_t xr, int nkb, con
 #pragma unroll
     for (int j = 0; j < DEPTH && j < NBW; ++j) issue(j, j);
     __builtin_amdgcn_sched_barrier(0);          // keep the whole burst ahead of the first use (hipcc would sink loads next to their uses)
-    f32x4 acc[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // (MFMA and split VALU of one SIMD do not overlap on gfx950 with 16x16x32 tiles - measured with software-pipelined and with
     //  hand-interleaved streams: their times add, 8.2k + 5.4k cycles per phase at K = 1568, B = 64 - so the loop stays simple.)
 #pragma unroll
@@ -231,7 +230,13 @@ __device__ __forceinline__ void ps_gates(__amdgpu_buffer_rsrc_t xr, int nkb, con
         }
         if (j + DEPTH < NBW) { issue(j + DEPTH, j % DEPTH); __builtin_amdgcn_sched_barrier(0); }
     }
-    // D layout: column = lane & 15, row = 4 (lane >> 4) + r
+}
+
+// this wave's partial sums -> red[wave][row][col]   (D layout: column = lane & 15, row = 4 (lane >> 4) + r)
+template <int RT>
+__device__ __forceinline__ void ps_gates_store(const f32x4 (&acc)[RT], float* __restrict__ red) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* out = red + wave * (64 * 16);
     const int i16 = lane & 15, q4 = lane >> 4;
 #pragma unroll
@@ -240,12 +245,25 @@ __device__ __forceinline__ void ps_gates(__amdgpu_buffer_rsrc_t xr, int nkb, con
         for (int r = 0; r < 4; ++r) out[(16 * rt + 4 * q4 + r) * 16 + i16] = acc[rt][r];
 }
 
+template <int NBW, int RT, int DEPTH>
+__device__ __forceinline__ void ps_gates(__amdgpu_buffer_rsrc_t xr, int nkb, const float4* __restrict__ wl, float* __restrict__ red) {
+    f32x4 acc[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    ps_gates_acc<NBW, RT, DEPTH>(xr, nkb, 0, nkb, wl, acc);
+    ps_gates_store<RT>(acc, red);
+}
+
+template <int NBW, int RT>
+__device__ __forceinline__ void ps_gates_bf16(__amdgpu_buffer_rsrc_t xr, int nkb, const uint4* __restrict__ wlb, float* __restrict__ red);
+
 // bf16 form: the exchange holds bf16 fragments, the LDS weight slice is bf16 ([nkb][64 lanes] x 16 B), one MFMA per product
 template <int NBW, int RT>
-__device__ __forceinline__ void ps_gates_bf16(__amdgpu_buffer_rsrc_t xr, int nkb, const uint4* __restrict__ wlb, float* __restrict__ red) {
+__device__ __forceinline__ void ps_gates_bf16_acc(__amdgpu_buffer_rsrc_t xr, int nkb, int kb_lo, int kb_hi, const uint4* __restrict__ wlb, f32x4 (&acc)[RT]) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int k0 = (nkb * wave) >> 3, k1 = (nkb * (wave + 1)) >> 3;
+    const int nrange = kb_hi - kb_lo;
+    const int k0 = kb_lo + ((nrange * wave) >> 3), k1 = kb_lo + ((nrange * (wave + 1)) >> 3);
     u32x4 xa[NBW][RT];
 #pragma unroll
     for (int j = 0; j < NBW; ++j)
@@ -253,9 +271,6 @@ __device__ __forceinline__ void ps_gates_bf16(__amdgpu_buffer_rsrc_t xr, int nkb
         for (int rt = 0; rt < RT; ++rt)
             xa[j][rt] = __builtin_amdgcn_raw_buffer_load_b128(xr, (k0 + j < k1) ? (unsigned)(((rt * nkb + k0 + j) * 1024) + lane * 16) : 0xfffffff0u, 0, 16);
     __builtin_amdgcn_sched_barrier(0);
-    f32x4 acc[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < NBW; ++j) {
         const uint4 w = wlb[min(k0 + j, nkb - 1) * 64 + lane];
@@ -266,12 +281,15 @@ __device__ __forceinline__ void ps_gates_bf16(__amdgpu_buffer_rsrc_t xr, int nkb
             acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, wb.v, acc[rt], 0, 0, 0);
         }
     }
-    float* out = red + wave * (64 * 16);
-    const int i16 = lane & 15, q4 = lane >> 4;
+}
+
+template <int NBW, int RT>
+__device__ __forceinline__ void ps_gates_bf16(__amdgpu_buffer_rsrc_t xr, int nkb, const uint4* __restrict__ wlb, float* __restrict__ red) {
+    f32x4 acc[RT];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) out[(16 * rt + 4 * q4 + r) * 16 + i16] = acc[rt][r];
+    for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    ps_gates_bf16_acc<NBW, RT>(xr, nkb, 0, nkb, wlb, acc);
+    ps_gates_store<RT>(acc, red);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -776,6 +794,18 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     }
     unsigned epoch = 0;
     if (!ps_barrier(p.sync, ++epoch)) return;
+    // The gate GEMM of a step is split by operand: the h-part (k-blocks [Dm/32, nkb): h_t is known one barrier earlier than ctx_t)
+    // runs in the shadow of the barrier that publishes ctx_t; only the ctx-part sits between that barrier and the cell.
+    const int kb_ctx = Dm >> 5;
+    f32x4 acc[RT];
+    auto gates_part = [&](int tt, int lo, int hi, auto nbw_tag) {
+        constexpr int NBWP = decltype(nbw_tag)::value;
+        if (PREC) ps_gates_bf16_acc<NBWP, RT>(xregion(tt & 1), nkb, lo, hi, reinterpret_cast<const uint4*>(wl), acc);
+        else ps_gates_acc<NBWP, RT, (NBWP < 3 ? NBWP : 3)>(xregion(tt & 1), nkb, lo, hi, wl, acc);
+    };
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    gates_part(p.t0, kb_ctx, nkb, std::integral_constant<int, 4>{});
 
     for (int t = p.t0; t < p.t1; ++t) {
         // ================= phase 1: attention LSTM (column role) =================
@@ -783,8 +813,8 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const size_t mo = ((size_t)t * B + rowc) * H + u;
         const unsigned hm = p.hmask ? (unsigned)p.hmask[mo] : 1u, cm = p.cmask ? (unsigned)p.cmask[mo] : 1u;
         PD_STAMP(0);
-        if (PREC) ps_gates_bf16<7, RT>(xregion(t & 1), nkb, reinterpret_cast<const uint4*>(wl), red);
-        else ps_gates<7, RT, 3>(xregion(t & 1), nkb, wl, red);
+        gates_part(t, 0, kb_ctx, std::integral_constant<int, 3>{});
+        ps_gates_store<RT>(acc, red);
         PD_STAMP(1);
         __syncthreads();
         float4 ga;
@@ -955,7 +985,11 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             }
         }
         PD_STAMP(8);
-        if (!ps_barrier(p.sync, ++epoch)) return;
+        ps_bar_arrive(p.sync, ++epoch);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (t + 1 < p.t1) gates_part(t + 1, kb_ctx, nkb, std::integral_constant<int, 4>{});      // h_{t+1} landed one barrier ago
+        if (!ps_bar_wait(p.sync, epoch)) return;
         PD_STAMP(9);
     }
 #ifdef PS_PROF
@@ -1049,7 +1083,7 @@ int pgen_launch(const DecoderArgs& a, int t0, int t1, hipStream_t s) {
 
 bool pdec_supported(const DecoderArgs& a) {
     if (!(persist_enabled() && a.fast && (a.precision == 0 || a.precision == 1) && a.H == 4 * PS_WGS && a.A == 128 && a.B >= 1 && a.B <= 64 && a.L >= 1 && a.L <= PD_LMAX &&
-          a.persist_ws && a.att_w2p && a.att_bias_u && a.att_w_pre_u && a.pre_att && (a.Dm & 31) == 0 && (a.Dm + a.H) / 32 <= 56 &&
+          a.persist_ws && a.att_w2p && a.att_bias_u && a.att_w_pre_u && a.pre_att && (a.Dm & 31) == 0 && a.Dm / 32 <= 24 &&
           (a.ksz & 1) == 1 && a.ksz <= 32 && a.persist_ws_bytes >= mtts_decoder_persist_ws_bytes(a.B, a.L, a.H, a.Dm, a.A)))
         return false;
     static const bool off = [] { const char* e = getenv("MTTS_PDEC"); return e && e[0] == '0'; }();
