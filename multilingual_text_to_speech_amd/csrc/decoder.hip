@@ -224,7 +224,11 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
     if (a.fast && !fuse2 && !pg && !sb) return mtts_fail("decoder: cannot create the side stream");
     // persistent attention LSTM + attention (persist.hip): chain A of the fast schedule as ONE launch
     const bool pd = pg && use_ls && pdec_supported(a);
-    if (pd) MTTS_TRY(pdec_launch(a, a.t0, a.t1, s));
+    if (pd) {      // (bench.py samples the whole launch with HIP events: mtts_prof_begin / mtts_prof_end)
+        const bool sampled = prof_sample(0, s, 0);
+        MTTS_TRY(pdec_launch(a, a.t0, a.t1, s));
+        if (sampled) prof_sample(0, s, 1);
+    }
     for (int t = a.t0; t < a.t1 && !pd; ++t) {
         if (fuse2 && t > a.t0 && ((t - a.t0) % CH) == 0) MTTS_TRY(gen_pre(a, t - CH, t, 0, s));      // input gates of the chunk chain B enters now
         const bool teach = a.frames_in && a.teacher && a.teacher[t];

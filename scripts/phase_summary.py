@@ -32,7 +32,7 @@ def main():
         wall = (step[i1][1] - step[i0][0]) / 1e6
         acc = collections.defaultdict(float)
         for s, e, name, q in seg:
-            acc[name.split('(')[0][:40]] += (e - s) / 1e6
+            acc[name.replace('(anonymous namespace)::', '').split('(')[0][:40]] += (e - s) / 1e6
         top = sorted(acc.items(), key=lambda kv: -kv[1])[:5]
         print('%-26s -> %-26s %7.2f ms wall, %5d kernels, kernel time %7.2f ms | %s' % (n0, n1, wall, len(seg), sum(acc.values()),
               '; '.join('%s %.2f' % (a[:28], b) for a, b in top)))

@@ -10,7 +10,7 @@ def load(path, counter):
         for r in csv.DictReader(f):
             if r['Counter_Name'] != counter:
                 continue
-            acc[(r['Kernel_Name'][:36], int(r['Grid_Size']), int(r['Queue_Id']))].append(float(r['Counter_Value']))
+            acc[(r['Kernel_Name'].replace('(anonymous namespace)::', '')[:36], int(r['Grid_Size']), int(r['Queue_Id']))].append(float(r['Counter_Value']))
     return acc
 
 

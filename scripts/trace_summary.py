@@ -23,7 +23,7 @@ def main():
         rows = rows[marks[args.region - 1] + 1:marks[args.region]]
     acc = collections.defaultdict(list)
     for _, name, q, s, e, gx, gy, gz in rows:
-        acc[(name.split('(')[0][:44], gx, gy, gz, q)].append((e - s) / 1e3)
+        acc[(name.replace('(anonymous namespace)::', '').split('(')[0][:44], gx, gy, gz, q)].append((e - s) / 1e3)
     table = sorted(acc.items(), key=lambda kv: -sum(kv[1]))
     tot = sum(sum(v) for v in acc.values())
     print('%-46s %-18s %2s %6s %9s %9s %9s %9s %6s' % ('kernel', 'workgroups', 'q', 'n', 'avg_us', 'med_us', 'min_us', 'total_ms', '%'))

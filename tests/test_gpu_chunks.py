@@ -36,6 +36,12 @@ def test_mixed_teacher_forcing_train_step_at_real_widths(preset, B):
     run_train_step_case(preset, B, 20, T, {}, teacher=teacher)
 
 
+def test_zoneout_train_step_at_real_widths():
+    """decoder_regularization = 'zoneout' (reference ZoneoutLSTMCell, modules/layers.py:26-34) through the persistent decoder
+    kernels (real widths, batch <= 64): forward, loss and every gradient against the oracle with injected zoneout draws."""
+    run_train_step_case('shared_training', 16, 30, 20, {'decoder_regularization': 'zoneout'})
+
+
 def test_generated_training_train_step_at_real_widths():
     """BASELINE configs[2] (params/generated_training.json: G = 10 languages, generator_dim 20, bottleneck 8, language embedding
     32): full train step (forward, loss, every parameter gradient) at the real widths, two samples per language group,

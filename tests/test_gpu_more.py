@@ -167,6 +167,11 @@ def run_train_step_case(preset, B, L, T, over, check_grads=True, ragged=None, te
     H, P = hp.decoder_dimension, hp.prenet_dimension
     teacher = [True] * T if teacher is None else [bool(x) for x in teacher]
     inj = {'teacher': teacher, 'dec.att_lstm': keep(T, B, H, p=hp.dropout_hidden), 'dec.gen_lstm': keep(T, B, H, p=hp.dropout_hidden)}
+    zone = hp.decoder_regularization == 'zoneout'
+    if zone:
+        for cell in ('att_lstm', 'gen_lstm'):
+            inj[f'dec.{cell}.h'] = keep(T, B, H, p=hp.zoneout_hidden)
+            inj[f'dec.{cell}.c'] = keep(T, B, H, p=hp.zoneout_cell)
     inj.update({f'dec.prenet.{i}': keep(T, B, P, p=hp.dropout) for i in range(2)})
     G = hp.language_number if hp.encoder_type == 'generated' else 1
     if hp.encoder_type == 'generated':
@@ -186,6 +191,10 @@ def run_train_step_case(preset, B, L, T, over, check_grads=True, ragged=None, te
     cfg = O.cfg_from_params(hp)
     mult = lambda m, p: m.float() / (1 - p)
     om = {'att_lstm': mult(inj['dec.att_lstm'], hp.dropout_hidden), 'gen_lstm': mult(inj['dec.gen_lstm'], hp.dropout_hidden)}
+    if zone:
+        for cell in ('att_lstm', 'gen_lstm'):
+            om[f'{cell}.h'] = mult(inj[f'dec.{cell}.h'], hp.zoneout_hidden)
+            om[f'{cell}.c'] = mult(inj[f'dec.{cell}.c'], hp.zoneout_cell)
     for i in range(2):
         om[f'prenet.{i}'] = torch.cat((mult(inj[f'dec.prenet.{i}'], hp.dropout).transpose(0, 1), torch.ones(B, 1, P)), 1)
         om[f'prenet_step.{i}'] = mult(inj[f'dec.prenet.{i}'], hp.dropout)          # free-running steps draw per step ([T,B,P])
