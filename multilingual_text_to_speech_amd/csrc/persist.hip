@@ -829,16 +829,19 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         }
         PD_STAMP(2);
         ps_bar_arrive(p.sync, ++epoch);
+#if !(defined(PS_EXP) && PS_EXP == 5)
+#define PD_PREFETCH_EARLY 1
+#endif
+        float4 wq4[16]; float4 mem4[PD_NCM];
+        auto pd_prefetch = [&]() {
         // operands of phase 2 that do not depend on h_{t+1}: requested behind the arrive, landing while the barrier completes.
         // query weights (streamed from L2 every step: neither LDS nor the register file has 128 KiB to spare beside phase 1):
         // lane (a = tid >> 4, l16 = tid & 15) takes k = 64 i + 4 l16 .. + 4, i.e. 256 contiguous bytes per channel and load
-        float4 wq4[16];
         {
             const float* wq = p.w_query + (size_t)(32 * sj + (tid >> 4)) * H + 4 * (tid & 15);
 #pragma unroll
             for (int i = 0; i < 16; ++i) wq4[i] = *reinterpret_cast<const float4*>(wq + 64 * i);
         }
-        float4 mem4[PD_NCM];
         {
             const int c4 = tid % nc4, lg = tid / nc4;
             const float* mem = p.memory + (size_t)sbc * L * Dm + d0 + 4 * c4;
@@ -848,6 +851,10 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 mem4[i] = *reinterpret_cast<const float4*>(mem + (size_t)l * Dm);
             }
         }
+        };
+#ifdef PD_PREFETCH_EARLY
+        pd_prefetch();
+#endif
         if (cellthr) {
             const size_t o = ((size_t)(t + 1) * B + row) * H + u;
             p.c[o] = c_state;
@@ -857,6 +864,9 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             }
         }
         if (!ps_bar_wait(p.sync, epoch)) return;
+#ifndef PD_PREFETCH_EARLY
+        pd_prefetch();
+#endif
         PD_STAMP(3);
 
         // ================= phase 2: attention (sample role) =================

@@ -144,3 +144,17 @@ def broadcast_parameters(module, src=0):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src)
+
+
+def global_mean_scale(n_local, device):
+    """Factor that turns a rank's LOCAL mean over `n_local` items into its share of the GLOBAL mean after the gradient all-reduce
+    (which averages over ranks): mean_global = (1 / world) * sum_r [ local_mean_r * n_local_r * world / n_global ].
+    Used for the adversarial classifier loss, a mean over the VALID characters of the batch (reference
+    modules/classifier.py:62-69 on the gathered global batch): shards with different text lengths hold different numbers of them.
+    Returns a 1-element tensor on `device` (no host synchronisation); 1.0 when not running data parallel."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return torch.ones(1, dtype=torch.float32, device=device)
+    world = dist.get_world_size()
+    total = torch.tensor([float(n_local)], dtype=torch.float32, device=device)
+    dist.all_reduce(total, op=dist.ReduceOp.SUM)
+    return (float(n_local) * world) / total.clamp_min(1.0)

@@ -329,7 +329,9 @@ class TacotronLoss(Module):
         if hp.guided_attention_loss:
             losses['guided_att'] = v[3] if ga_on else 0
         if hp.reversal_classifier:
-            losses['lang_class'] = ReversalClassifier.loss(source_length, speaker, speaker_prediction) * \
+            from ..dist import global_mean_scale      # data parallel: the reference's CE is a mean over the GLOBAL batch's valid characters
+            share = global_mean_scale(int(source_length.sum()), speaker_prediction.device)
+            losses['lang_class'] = ReversalClassifier.loss(source_length, speaker, speaker_prediction) * share[0] * \
                 (hp.reversal_classifier_w / (hp.num_mels + 2))
             total = total + losses['lang_class']
         return total, losses

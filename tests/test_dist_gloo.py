@@ -152,3 +152,33 @@ def test_sharded_evaluation_equals_single_process(tmp_path):
         assert set(got) == set(single)
         for k in single:
             assert abs(got[k] - single[k]) <= 1e-6 * max(1.0, abs(single[k])), (k, got[k], single[k])
+
+
+# ---- classifier loss under data parallelism: local mean -> share of the global mean ---------------------------------------------
+def _worker_scale(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from multilingual_text_to_speech_amd import dist as D
+    D.init(backend='gloo')
+    n_local = [10, 30][rank]
+    vals = torch.arange(n_local, dtype=torch.float32) + 100.0 * rank          # per-item losses of this rank's valid characters
+    share = D.global_mean_scale(n_local, torch.device('cpu'))
+    contrib = vals.mean() * share[0]                                           # what the rank adds to its loss
+    t = contrib.clone()
+    dist.all_reduce(t)
+    torch.save(dict(share=share, mean_of_ranks=t / world), f'{out}/s{rank}.pt')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_local_mean_is_rescaled_to_the_global_mean(tmp_path):
+    from multilingual_text_to_speech_amd import dist as D
+    assert float(D.global_mean_scale(17, torch.device('cpu'))) == 1.0         # not data parallel: no change
+    port = _free_port()
+    mp.spawn(_worker_scale, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    everything = torch.cat((torch.arange(10, dtype=torch.float32), torch.arange(30, dtype=torch.float32) + 100.0))
+    for r in range(2):
+        got = torch.load(f'{tmp_path}/s{r}.pt')
+        assert abs(float(got['share']) - [0.5, 1.5][r]) < 1e-6
+        assert abs(float(got['mean_of_ranks']) - float(everything.mean())) < 1e-4
