@@ -1103,7 +1103,10 @@ MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
     static const bool reserve_cu = [] { const char* e = getenv("MTTS_GEMM_RESERVE_CU"); return !(e && e[0] == '0'); }();
     const size_t lds = (p.nosplit && reserve_cu) ? (size_t)96 * 1024 : lds_base;
     hipStream_t s = (hipStream_t)stream;
-    static bool attr_done = false;
+    // the attribute is per DEVICE (one process may drive several): one flag per device ordinal
+    static bool attr_done_dev[64] = {false};
+    int dev_ = 0; (void)hipGetDevice(&dev_);
+    bool& attr_done = attr_done_dev[dev_ & 63];
     if (!attr_done) {   // > 64 KiB of dynamic LDS needs the opt-in attribute
         const void* kernels[19] = {(const void*)gemm_pipe_persist_kernel<false, false>, (const void*)gemm_pipe_persist_kernel<false, true>,
                                    (const void*)gemm_pipe_persist_kernel<true, false>, (const void*)gemm_pipe_persist_kernel<true, true>,

@@ -582,7 +582,10 @@ static int ls_marshal(const LstmStepArgs& a, LsGates& g, LsCell& c) {
 }
 
 static int ls_set_attrs() {
-    static bool attr_done = false;
+    // the attribute is per DEVICE (one process may drive several): one flag per device ordinal
+    static bool attr_done_dev[64] = {false};
+    int dev_ = 0; (void)hipGetDevice(&dev_);
+    bool& attr_done = attr_done_dev[dev_ & 63];
     if (!attr_done) {
         MTTS_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_gates_kernel<0, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 7 * LS_PLANE_B));
         MTTS_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_gates_kernel<0, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 10 * LS_PLANE_B));
