@@ -7,6 +7,7 @@
 // Per step only skinny GEMMs against TRANSPOSED recurrent weights, the fused LSTM-cell backward epilogue and the
 // attention backward kernel run; every weight gradient is one large MFMA GEMM over the saved gate gradients.
 #include "common.h"
+#include <chrono>
 #include <stdlib.h>
 #include <algorithm>
 #include <vector>
@@ -270,6 +271,8 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
     // ---- weight gradients ride a third, least-priority stream: every chunk's dG^T x product is queued as soon as its chain
     //      has produced the chunk's dG, and accumulates (beta = 1) into the gradient; one workgroup per CU (nosplit) so that
     //      the step kernels of both chains always find room.  The frame-projection gradient needs no chain at all.
+    //      Round-3 A/B (same box, ms per train step): beside the chains 84.0, deferred to the end of the chains on the caller's
+    //      stream 88.3-89.1, helper stream confined to 64 / 128 / 192 CUs by hipExtStreamCreateWithCUMask 106-108 (not kept).
     hipStream_t sw = wgrad_stream(s);
     if (!sw) return mtts_fail("decoder backward: cannot create the weight-gradient stream");
     auto wgrad = [&](const float* dY, int ldy, int Mw, const float* X, int ldx, int Nw, float* dW, int ldw, int rows, float beta) -> int {
@@ -288,6 +291,18 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
         MTTS_TRY(wgrad(dout1, Mo, M + 1, a.h_gen + BH, H, H, g.d_w_out, H + Dm, TB, 0.f));
         MTTS_TRY(wgrad(dout1, Mo, M + 1, a.ctx + BD, Dm, Dm, g.d_w_out + H, H + Dm, TB, 0.f));
     }
+    static const bool host_timing = [] { const char* e = getenv("MTTS_HOST_TIMING"); return e && e[0] == '1'; }();
+    const auto host_t0 = std::chrono::steady_clock::now();
+    // MTTS_HOST_TIMING=1 (diagnosis): host submission time and a per-chunk GPU timeline of the three streams from timing events
+    std::vector<hipEvent_t> tev;
+    std::vector<const char*> tev_name;
+    std::vector<int> tev_chunk;
+    auto tmark = [&](hipStream_t st, const char* name, int c) {
+        if (!host_timing) return;
+        hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return;
+        (void)hipEventRecord(e, st); tev.push_back(e); tev_name.push_back(name); tev_chunk.push_back(c);
+    };
+    tmark(s, "start", -1);
     const float* pren = a.prenet_act[a.n_prenet - 1];
     auto submit_B = [&](int c) -> int {
         const int c0 = c * CH, c1 = std::min(T, c0 + CH), n = c1 - c0;
@@ -327,12 +342,14 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
         MTTS_TRY(mtts_gemm_ex(&q, sb));
         chunk_ev[c] = pool_event(s);
         MTTS_CHECK_HIP(hipEventRecord(chunk_ev[c], sb));
+        tmark(sb, "B end", c);
         // generator-LSTM weight gradients of this chunk
         MTTS_CHECK_HIP(hipStreamWaitEvent(sw, chunk_ev[c], 0));
         const float beta = c == nchunks - 1 ? 0.f : 1.f;
         MTTS_TRY(wgrad(g.dG_gen + c0 * B4H, 4 * H, 4 * H, a.h_att + (c0 + 1) * BH, H, H, g.d_gen_w_ih, H + Dm, n * B, beta));
         MTTS_TRY(wgrad(g.dG_gen + c0 * B4H, 4 * H, 4 * H, a.ctx + (c0 + 1) * BD, Dm, Dm, g.d_gen_w_ih + H, H + Dm, n * B, beta));
         MTTS_TRY(wgrad(g.dG_gen + c0 * B4H, 4 * H, 4 * H, a.h_gen + c0 * BH, H, H, g.d_gen_w_hh, H, n * B, beta));
+        tmark(sw, "Wgen end", c);
         return 0;
     };
     // Chain A per step t:  { attention backward(t)  ||  dG_att(t+1) W_hh^T }  ->  dq W_q + cell backward(t)  ->  dG_att(t) W_ih[:, P:]^T
@@ -351,6 +368,7 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
     auto submit_A = [&](int c) -> int {
         const int c0 = c * CH, c1 = std::min(T, c0 + CH);
         MTTS_CHECK_HIP(hipStreamWaitEvent(s, chunk_ev[c], 0));
+        tmark(s, "A start", c);
         for (int t = c1 - 1; t >= c0; --t) {
             {
                 AttnBwdArgs q; memset(&q, 0, sizeof(q));
@@ -403,6 +421,7 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
                 MTTS_TRY(skinny_launch(q, s));
             }
         }
+        tmark(s, "A end", c);
         {   // attention-LSTM and query weight gradients of this chunk
             hipEvent_t ev = pool_event(s);
             MTTS_CHECK_HIP(hipEventRecord(ev, s));
@@ -414,6 +433,7 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
             MTTS_TRY(wgrad(dG, 4 * H, 4 * H, a.ctx + c0 * BD, Dm, Dm, g.d_att_w_ih + P, P + Dm, n * B, beta));
             MTTS_TRY(wgrad(dG, 4 * H, 4 * H, a.h_att + c0 * BH, H, H, g.d_att_w_hh, H, n * B, beta));
             MTTS_TRY(wgrad(g.dq_all + c0 * BA, A, A, a.h_att + (c0 + 1) * BH, H, H, g.d_w_query, H, n * B, beta));
+            tmark(sw, "Watt end", c);
         }
         return 0;
     };
@@ -422,6 +442,17 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
     for (int c = nchunks - 1; c >= 0; --c) {
         if (c > 0) MTTS_TRY(submit_B(c - 1));
         MTTS_TRY(submit_A(c));
+    }
+    if (host_timing)
+        fprintf(stderr, "[mtts] decoder_bwd: chains submitted in %.3f ms of host time (T=%d)\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count(), T);
+    if (host_timing && !tev.empty()) {
+        (void)hipStreamSynchronize(sb); (void)hipStreamSynchronize(sw); (void)hipStreamSynchronize(s);
+        for (size_t i = 1; i < tev.size(); ++i) {
+            float ms = 0.f; (void)hipEventElapsedTime(&ms, tev[0], tev[i]);
+            fprintf(stderr, "[mtts]   %-9s chunk %2d  %8.3f ms\n", tev_name[i], tev_chunk[i], ms);
+        }
+        for (hipEvent_t e : tev) (void)hipEventDestroy(e);
     }
     hipEvent_t ev_b_done = pool_event(s), ev_w_done = pool_event(s);
     MTTS_CHECK_HIP(hipEventRecord(ev_b_done, sb));

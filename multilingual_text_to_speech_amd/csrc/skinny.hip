@@ -36,6 +36,14 @@ int skinny_launch(const SkinnyArgs& p, hipStream_t s) {
     // Default for more than 32 rows: the <= 128-VGPR variant.  The 4-deep one (153 VGPRs) is ~10 % faster alone, but cannot share a CU
     // with two GEMM workgroups of the helper streams and then WAITS for them: 92.0-92.3 vs 94.4-94.8 ms per train step.
     static const bool force_lo = [] { const char* e = getenv("MTTS_SKINNY_DEEP"); return !(e && e[0] == '1'); }();
+    // LSTM cell backward (K <= the query width): the launch is all epilogue operands (16 loads per (row, unit)); one 16-row tile per
+    // workgroup gives four times the workgroups to fetch them (bit-identical: same K chunks per wave, same reduction order).
+    static const bool cell_rows16 = [] { const char* e = getenv("MTTS_CELL_ROWS16"); return !(e && e[0] == '0'); }();
+    if (cell_rows16 && p.lstm == 2 && p.B > 16 && p.B <= 64 && q.seg[0].K <= 256 && q.nseg == 1 && ks == 1) {
+        hipLaunchKernelGGL(skinny_kernel<1>, dim3(cbs, cdiv(p.B, 16), 1), dim3(NT), 0, s, q);
+        MTTS_CHECK_LAUNCH("skinny_kernel");
+        return 0;
+    }
     if (p.B <= 16) hipLaunchKernelGGL(skinny_kernel<1>, dim3(cbs, cdiv(p.B, 16), ks), dim3(NT), 0, s, q);
     else if (p.B <= 32) hipLaunchKernelGGL(skinny_kernel<2>, dim3(cbs, cdiv(p.B, 32), ks), dim3(NT), 0, s, q);
     else if (force_lo || (long)cbs * cdiv(p.B, 64) * ks > 320) hipLaunchKernelGGL(skinny_kernel_lo<4>, dim3(cbs, cdiv(p.B, 64), ks), dim3(NT), 0, s, q);
