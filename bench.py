@@ -15,13 +15,19 @@ Extra objects on the line (N = 1):
                  (HIP events on the launch stream around the whole 600-step decoder forward); peak 8 TB/s.
                  `traffic` = HBM bytes per step from live rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate passes,
                  difference of a long and a short decode so that everything not proportional to the frame count cancels).
-                 `kernels` keeps the per-launch figures of the dominant kernel (attention-LSTM step) as a sub-field.
+                 `kernels` keeps the per-launch figures of the dominant kernel as a sub-field, sampled inside the timed train steps:
+                 `persistent_attention_decoder` (pdec_kernel: ONE launch = all 600 steps of attention LSTM + attention, reported
+                 per step) or, when the per-step launch schedule runs (batch > 64), `attention_lstm_step`.
   roofline_b240 / roofline_b240_bf16 / roofline_b40_bf16 - the same quantity for params/generated_switching at batch 240 (the valid
                  batch next to the north star's 256) in fp32 and bf16, and at batch 40 (one rank's shard of configs[3]) in bf16.
   inference    - BASELINE configs[4]: batched synthesis, 128 utterances x 201 tokens -> 600 frames, with its own step roofline.
   cpu_baseline - the CPU oracle (oracle/tacotron_oracle.py, a torch-CPU port of the reference's arithmetic, kind "port") timed
-                 on this host's cores on a bounded sample of the same workload, plus `reference_recorded`: the reference
-                 itself (kind "reference") as recorded in the build container by scripts/cpu_reference_baseline.py.
+                 on this host's cores on the SAME configuration (batch 64 x 600 frames; 2 train steps, <= 150 s), plus
+                 `reference_recorded`: the reference itself (kind "reference") as recorded in the build container by
+                 scripts/cpu_reference_baseline.py, and the ratios gpu_over_port / gpu_over_reference_recorded.
+
+`python bench.py --gpus N` (N > 1) outside a torch.distributed launcher re-executes itself under torch.distributed.run
+(127.0.0.1, free port); under the driver's own launcher it is a plain worker.
 """
 import argparse
 import ctypes
