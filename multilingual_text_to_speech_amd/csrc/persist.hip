@@ -715,8 +715,10 @@ struct PsDec {
     float* xp;                  // [2][64 rows][Dm + H] exchange (XP layout)
     unsigned long long* eg;     // [64][4][128] partial-energy granules {tag, value}
     PsSync sync;
+    int poll_h;                 // 1: the sample role polls its h row (pre-filled with PS_SENTINEL by the host) instead of waiting for the barrier
 };
 
+constexpr unsigned PS_SENTINEL = 0xffffffffu;      // a NaN pattern no arithmetic produces
 constexpr int PD_LMAX = 128;         // encoder positions (8 waves x 16 rows)
 constexpr int PD_NCM = 9;            // memory float4 per thread in the context phase
 
@@ -863,7 +865,12 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 go[0] = ga.x; go[H] = ga.y; go[2 * H] = ga.z; go[3 * H] = ga.w;
             }
         }
-        if (!ps_bar_wait(p.sync, epoch)) return;
+        // h_{t+1} has to be complete for the h-part of the next gates (every row) and for the query (the own sample's row only).
+        // poll_h: the query does not wait for the grid barrier - the h rows of steps (t0, t1] were pre-filled with a sentinel by the
+        // host, every 16-byte quantum of a row is written by ONE store of its owner, and the four waves that fetch the row simply
+        // re-read it until no sentinel is left (the payload is the flag: one store -> load hop instead of drain -> two-level arrive ->
+        // poll -> fetch).  The barrier itself is then waited for after the attention step, where it has long completed.
+        if (!p.poll_h && !ps_bar_wait(p.sync, epoch)) return;
 #ifndef PD_PREFETCH_EARLY
         pd_prefetch();
 #endif
@@ -874,7 +881,19 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             // ---- h_{t+1}[sb] -> LDS (16 chunks of 64 with 4 floats of padding: conflict-free reads below)
             {
                 const __amdgpu_buffer_rsrc_t hr = ps_rsrc(p.h + ((size_t)(t + 1) * B + sb) * H, (unsigned)(H * 4));
-                if (tid < (H >> 2)) *reinterpret_cast<float4*>(hs + 4 * tid) = ps_ld16_sc1(hr, tid * 16);
+                if (tid < (H >> 2)) {
+                    float4 v = ps_ld16_sc1(hr, tid * 16);
+                    if (p.poll_h) {
+                        unsigned spins = 0;
+                        while (__builtin_amdgcn_ballot_w64(__float_as_uint(v.x) == PS_SENTINEL || __float_as_uint(v.y) == PS_SENTINEL ||
+                                                           __float_as_uint(v.z) == PS_SENTINEL || __float_as_uint(v.w) == PS_SENTINEL) != 0ull) {
+                            __builtin_amdgcn_s_sleep(1);
+                            v = ps_ld16_sc1(hr, tid * 16);
+                            if (++spins > PS_SPIN_MAX) { __hip_atomic_store(p.sync.err, 2u, PS_RLX, PS_AGENT); break; }
+                        }
+                    }
+                    *reinterpret_cast<float4*>(hs + 4 * tid) = v;
+                }
             }
             __syncthreads();
             // ---- query slice: thread (a = tid >> 4, chunk = tid & 15)
@@ -995,6 +1014,7 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             }
         }
         PD_STAMP(8);
+        if (p.poll_h && !ps_bar_wait(p.sync, epoch)) return;       // the h barrier of this step (complete long ago)
         ps_bar_arrive(p.sync, ++epoch);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1045,6 +1065,7 @@ bool pgen_supported(const DecoderArgs& a) {
 }
 
 unsigned long long* g_ps_prof = nullptr;      // timeline buffer of the micro-benchmark harness (NULL in the library)
+bool g_pdec_poll_off = false;                 // harness switch: barrier-only hand-off of h (bit-equality check of the two forms)
 
 // generator LSTM steps [t0, t1) in one launch (h_gen[t0] / c_gen[t0] are the initial state)
 int pgen_launch(const DecoderArgs& a, int t0, int t1, hipStream_t s) {
@@ -1124,6 +1145,10 @@ int pdec_launch(const DecoderArgs& a, int t0, int t1, hipStream_t s) {
     p.eg = (unsigned long long*)(ws + ps_ws_eg_off(a.H, a.Dm));
     MTTS_CHECK_HIP(hipMemsetAsync(ws, 0, PS_ERR_OFF, s));
     MTTS_CHECK_HIP(hipMemsetAsync(p.eg, 0, (size_t)64 * 4 * PD_LMAX * 8, s));
+    static const bool poll_on = [] { const char* e = getenv("MTTS_PDEC_POLL"); return !(e && e[0] == '0'); }();
+    p.poll_h = (poll_on && !g_pdec_poll_off) ? 1 : 0;
+    if (p.poll_h)       // h rows of the steps this launch produces: sentinel until their owner's store lands
+        MTTS_CHECK_HIP(hipMemsetAsync(a.h_att + (size_t)(t0 + 1) * a.B * a.H, 0xff, (size_t)(t1 - t0) * a.B * a.H * sizeof(float), s));
     size_t lds = (size_t)((a.Dm + a.H) / 32) * (a.precision ? 1024 : 2048) + 8 * 64 * 16 * 4 + PD_LMAX * 32 * 4 + (PD_LMAX + 64) * 4 + 2 * 3 * 64 * 16 + 64 * 4;
 #ifdef PS_PROF
     lds += 300 * 8;
