@@ -683,6 +683,201 @@ __global__ __launch_bounds__(PS4_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
 }
 
 
+
+template <int NG>
+__global__ __launch_bounds__(PS4_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void pgen7_kernel(PsGen p) {
+    extern __shared__ __attribute__((aligned(16))) char psm[];
+    constexpr int NBW = 4;                                    // k-blocks per multiplier wave (nkb = 32)
+    const int tid = threadIdx.x, lane = tid & 63, c = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = p.H, B = p.B, nkb = H >> 5, N = 4 * H;
+    float* red = reinterpret_cast<float*>(psm);                                        // [NG][8][16][16]
+    volatile unsigned* done = reinterpret_cast<volatile unsigned*>(red + NG * 8 * 256);   // [4]  multiplier waves finished, per group (monotonic)
+    volatile unsigned* seen = done + 4;                                                // [4]  publish number that has landed, per group
+    volatile unsigned* lerr = done + 8;
+#ifdef PS_PROF
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(const_cast<unsigned*>(done) + 16);
+#endif
+    const PsBar2 bar{p.sync.cnt, p.sync.err};
+    if (tid < 12) done[tid] = 0;
+    __syncthreads();
+    const unsigned per_pub = PS_WGS / 8;
+    const int n_steps = p.t1 - p.t0, n_gs = n_steps * NG;
+    const unsigned xg_bytes = (unsigned)(nkb * 2048);      // fp32 A-fragment image of 16 rows (XP layout, rt = 0)
+    auto xregion = [&](int g, int par) { return ps_rsrc(reinterpret_cast<char*>(p.xp) + (size_t)(g * 2 + par) * xg_bytes, xg_bytes); };
+
+    if (wave >= 8) {
+        // =========================== service wave of row group g ===========================
+        const int g = wave - 8;
+        if (g >= NG) return;
+        const int rl = lane >> 2, uu = lane & 3, u = 4 * c + uu, row = 16 * g + rl;
+        const bool valid = row < B;
+        const int rowc = valid ? row : 0;
+        const float4 bias4 = *reinterpret_cast<const float4*>(p.bias_u + 4 * u);
+        float c_state = valid ? p.c[((size_t)p.t0 * B + row) * H + u] : 0.f;
+        float h_state = valid ? p.h[((size_t)p.t0 * B + row) * H + u] : 0.f;
+        // Two-level arrive (as ps_barrier): the counters that take 32 atomics per publish are polled by nobody; the polled word
+        // (top counter of the group) takes 8.  sub[g][x] = cnt[(g * 9 + 1 + x) * 32], top[g] = cnt[g * 9 * 32].
+        unsigned* top = bar.cnt + (g * 9) * 32;
+        unsigned* sub = bar.cnt + (g * 9 + 1 + (blockIdx.x & 7)) * 32;
+        auto arrive = [&](unsigned pub) {
+            if (lane == 0) {
+                const unsigned prev = __hip_atomic_fetch_add(sub, 1u, PS_RLX, PS_AGENT);
+                if (prev + 1 == pub * per_pub) __hip_atomic_fetch_add(top, 1u, PS_RLX, PS_AGENT);
+            }
+        };
+        auto land = [&](unsigned pub) -> bool {      // wait until publish `pub` of this group has arrived everywhere, then tell the multipliers
+            unsigned spins = 0;
+            while (__hip_atomic_load(top, PS_RLX, PS_AGENT) < pub * 8u) {
+                __builtin_amdgcn_s_sleep(1);
+                if ((++spins & 1023u) == 0 && (spins > PS_SPIN_MAX || __hip_atomic_load(bar.err, PS_RLX, PS_AGENT) != 0)) {
+                    if (lane == 0) { __hip_atomic_store(bar.err, 2u, PS_RLX, PS_AGENT); *lerr = 1; }
+                    return false;
+                }
+            }
+            if (lane == 0) seen[g] = pub;
+            return true;
+        };
+        {
+            const float4 h4 = ps_quad_gather(h_state);
+            if (valid && uu == 0) ps_st16_sc1(xregion(g, p.t0 & 1), ps_xp_off(rl, 4 * c, nkb), h4);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            arrive(1u);
+            if (!land(1u)) return;
+        }
+        for (int s = 0; s < n_steps; ++s) {
+            const int t = p.t0 + s;
+            const float4 pre4 = *reinterpret_cast<const float4*>(p.pre + ((size_t)t * B + rowc) * N + 4 * u);
+            const size_t mo = ((size_t)t * B + rowc) * H + u;
+            const unsigned hm = p.hmask ? (unsigned)p.hmask[mo] : 1u, cm = p.cmask ? (unsigned)p.cmask[mo] : 1u;
+            {   // the eight partial sums of this group-step are in LDS
+                unsigned spins = 0;
+                while (done[g] < 8u * (unsigned)(s + 1)) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (*lerr != 0 || ++spins > (PS_SPIN_MAX << 2)) { if (lane == 0) { *lerr = 1; __hip_atomic_store(bar.err, 2u, PS_RLX, PS_AGENT); } return; }
+                }
+            }
+            PS_STAMP(stamps, 512 + 4 * s + 0, g == 0 && lane == 0);
+            const float* redg = red + g * (8 * 256);
+            float4 g4 = bias4;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const float4 v = *reinterpret_cast<const float4*>(redg + w * 256 + rl * 16 + 4 * uu);
+                g4.x += v.x; g4.y += v.y; g4.z += v.z; g4.w += v.w;
+            }
+            g4.x += pre4.x; g4.y += pre4.y; g4.z += pre4.z; g4.w += pre4.w;
+            const float ig = sigmoidf_(g4.x), fg = sigmoidf_(g4.y), gg = tanhf_(g4.z), og = sigmoidf_(g4.w);
+            const float cp = c_state, hp = h_state;
+            const float cn = fg * cp + ig * gg;
+            const float hn = og * tanhf_(cn);
+            float ho, co = cn;
+            if (p.cell.zone == 1) { ho = hm ? hn : hp; co = cm ? cn : cp; }
+            else if (p.cell.zone == 2) { ho = p.cell.zh * hp + (1.f - p.cell.zh) * hn; co = p.cell.zc * cp + (1.f - p.cell.zc) * cn; }
+            else ho = p.hmask ? (hm ? hn * p.cell.hscale : 0.f) : hn;
+            c_state = co; h_state = ho;
+            const float4 h4 = ps_quad_gather(h_state);
+            if (valid && uu == 0) ps_st16_sc1(xregion(g, (t + 1) & 1), ps_xp_off(rl, 4 * c, nkb), h4);      // ONE 16-byte fp32 quantum (the consumers split)
+            PS_STAMP(stamps, 512 + 4 * s + 1, g == 0 && lane == 0);
+            if (s + 1 < n_steps) {      // exchange first: drain the write-through stores, arrive; the saved state follows
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                arrive((unsigned)(s + 2));
+            }
+            PS_STAMP(stamps, 512 + 4 * s + 2, g == 0 && lane == 0);
+            if (valid) {
+                const size_t o = ((size_t)(t + 1) * B + row) * H + u;
+                if (uu == 0) *reinterpret_cast<float4*>(p.h + o) = h4;
+                p.c[o] = c_state;
+                if (p.gates) {
+                    float* go = p.gates + ((size_t)t * B + row) * N + u;
+                    go[0] = ig; go[H] = fg; go[2 * H] = gg; go[3 * H] = og;
+                }
+            }
+            if (s + 1 < n_steps && !land((unsigned)(s + 2))) return;
+            PS_STAMP(stamps, 512 + 4 * s + 3, g == 0 && lane == 0);
+        }
+#ifdef PS_PROF
+        if (p.prof && blockIdx.x == 0 && g == 0) for (int i = 512 + lane; i < PS_PROF; i += 64) p.prof[i] = stamps[i];
+#endif
+        return;
+    }
+
+    // =========================== multiplier wave ===========================
+    const int k0 = (nkb * wave) >> 3, k1 = (nkb * (wave + 1)) >> 3;
+    PsFrag wreg[NBW][3];
+    {
+        const float4* src = reinterpret_cast<const float4*>(p.w_packed) + (size_t)c * nkb * 128;
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            const int kb = min(k0 + j, nkb - 1);
+            const PsFrag3 f = ps_split8(src[(kb * 2 + 0) * 64 + lane], src[(kb * 2 + 1) * 64 + lane]);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) wreg[j][pl] = f.p[pl];
+        }
+    }
+    auto wait_seen = [&](int g, unsigned pub) -> bool {
+        unsigned spins = 0;
+        while (seen[g] < pub) {
+            __builtin_amdgcn_s_sleep(1);
+            if (*lerr != 0 || ++spins > (PS_SPIN_MAX << 2)) { *lerr = 1; return false; }
+        }
+        return true;
+    };
+    float4 xb[NBW][2];                                        // fp32 fragments of the next group-step (two 16-byte halves per k-block)
+    auto issue_blk = [&](int j, __amdgpu_buffer_rsrc_t r) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) xb[j][hf] = ps_ld16_sc1(r, (unsigned)((((k0 + j) * 2 + hf) * 1024) + lane * 16));
+    };
+    auto issue_all = [&](__amdgpu_buffer_rsrc_t r) {
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) issue_blk(j, r);
+    };
+    if (n_gs > 0) {
+        if (!wait_seen(0, 1u)) return;
+        issue_all(xregion(0, p.t0 & 1));
+    }
+    const int i16 = lane & 15, q4 = lane >> 4;
+    for (int i = 0; i < n_gs; ++i) {
+        const int g = i % NG, in = i + 1, gn = in % NG, tn = p.t0 + in / NG;
+        const bool has_next = in < n_gs;
+        const unsigned pubn = (unsigned)(in / NG + 1);
+#if defined(PS_EXP) && PS_EXP == 2      // timing experiment: never refill between the MFMAs
+        const bool early = false;
+#else
+        const bool early = has_next && seen[gn] >= pubn;
+#endif
+        const __amdgpu_buffer_rsrc_t nxr = xregion(gn, tn & 1);
+        PS_STAMP(stamps, 2 * i, tid == 64 * 5);
+        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            const PsFrag3 f3 = ps_split8(xb[j][0], xb[j][1]);         // exact 3-way split here: 4 B per element over the L2 instead of 6
+            const PsFrag (&a)[3] = f3.p;
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2].v, wreg[j][0].v, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0].v, wreg[j][2].v, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1].v, wreg[j][1].v, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1].v, wreg[j][0].v, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0].v, wreg[j][1].v, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0].v, wreg[j][0].v, acc1, 0, 0, 0);
+            if (early) issue_blk(j, nxr);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float* rw = red + (g * 8 + wave) * 256;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rw[(4 * q4 + r) * 16 + i16] = acc0[r] + acc1[r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(const_cast<unsigned*>(done) + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        PS_STAMP(stamps, 2 * i + 1, tid == 64 * 5);
+        if (has_next && !early) {
+            if (!wait_seen(gn, pubn)) return;
+            issue_all(nxr);
+        }
+    }
+#ifdef PS_PROF
+    if (p.prof && blockIdx.x == 0 && wave == 5) for (int i = lane; i < 512; i += 64) p.prof[i] = stamps[i];
+#endif
+}
+
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // pdec: attention LSTM + location-sensitive attention of the teacher-forced schedule, all steps in one launch (B <= 64).
 // Per step two phases with one grid barrier after each (see the file header):
@@ -1065,6 +1260,7 @@ bool pgen_supported(const DecoderArgs& a) {
 }
 
 unsigned long long* g_ps_prof = nullptr;      // timeline buffer of the micro-benchmark harness (NULL in the library)
+bool g_pgen7_off = false;                     // harness switch: pgen4 (bit-equality check of the two forms)
 bool g_pdec_poll_off = false;                 // harness switch: barrier-only hand-off of h (bit-equality check of the two forms)
 
 // generator LSTM steps [t0, t1) in one launch (h_gen[t0] / c_gen[t0] are the initial state)
@@ -1087,7 +1283,18 @@ int pgen_launch(const DecoderArgs& a, int t0, int t1, hipStream_t s) {
     p.prof = g_ps_prof;
     MTTS_CHECK_HIP(hipMemsetAsync(ws, 0, PS_ERR_OFF, s));           // counters (the error word is sticky until the host reads it)
     const int RT = (a.B + 15) / 16;
-    static const int variant = [] { const char* e = getenv("MTTS_PGEN"); return e ? atoi(e) : 2; }();
+    static const int variant = [] { const char* e = getenv("MTTS_PGEN"); return e ? atoi(e) : 3; }();      // 1: one barrier per step; 2: dataflow, bf16-plane exchange; 3: dataflow, fp32 exchange
+    if (variant != 1 && variant != 2 && a.precision == 0 && !g_pgen7_off) {      // dataflow pipeline with the fp32 exchange (MTTS_PGEN=2: bf16-plane exchange)
+        size_t lds4 = (size_t)RT * 8 * 256 * 4 + 64;
+#ifdef PS_PROF
+        lds4 += PS_PROF * 8;
+#endif
+#define PGEN7_GO(G) hipLaunchKernelGGL((pgen7_kernel<G>), dim3(PS_WGS), dim3(PS4_THREADS), lds4, s, p);
+        if (RT == 1) PGEN7_GO(1) else if (RT == 2) PGEN7_GO(2) else if (RT == 3) PGEN7_GO(3) else PGEN7_GO(4)
+#undef PGEN7_GO
+        MTTS_CHECK_LAUNCH("pgen7_kernel");
+        return 0;
+    }
     if (variant != 1 && a.precision == 0) {      // dataflow pipeline: 8 multiplier waves + one service wave per 16-row group
         size_t lds4 = (size_t)RT * 8 * 256 * 4 + 64;
 #ifdef PS_PROF

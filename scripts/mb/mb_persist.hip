@@ -84,12 +84,34 @@ int main(int argc, char** argv) {
         printf("pgen B=%d: max |h, c - host double| over %d steps = %.3e  %s\n", B, Tc, worst, worst < 2e-5 ? "OK" : "MISMATCH");
     }
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int rep = 0; rep < 3; ++rep) {
-        (void)hipEventRecord(e0, 0);
-        if (pgen_launch(a, 0, T, 0)) { printf("pgen_launch failed: %s\n", g_mtts_err); return 1; }
-        (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
-        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
-        printf("pgen  B=%d T=%d: %.3f ms = %.2f us per step (status %d)\n", B, T, ms, ms * 1e3 / T, mtts_decoder_persist_status(a.persist_ws, 0));
+    {   // the fp32-exchange form (pgen7) must reproduce the bf16-plane form (pgen4) bit for bit
+        const int Tq = T < 60 ? T : 60;
+        std::vector<float> ref_h, ref_c, ref_g;
+        for (int pass = 0; pass < 2; ++pass) {
+            (void)hipMemset(a.h_gen, 0, (size_t)(T + 1) * B * H * 4); (void)hipMemset(a.c_gen, 0, (size_t)(T + 1) * B * H * 4); (void)hipMemset(a.gates_gen, 0, (size_t)T * B * 4 * H * 4);
+            g_pgen7_off = pass == 0;
+            if (pgen_launch(a, 0, Tq, 0)) { printf("pgen_launch failed: %s\n", g_mtts_err); return 1; }
+            (void)hipDeviceSynchronize();
+            std::vector<float> hh((size_t)(Tq + 1) * B * H), cc((size_t)(Tq + 1) * B * H), gg((size_t)Tq * B * 4 * H);
+            (void)hipMemcpy(hh.data(), a.h_gen, hh.size() * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(cc.data(), a.c_gen, cc.size() * 4, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(gg.data(), a.gates_gen, gg.size() * 4, hipMemcpyDeviceToHost);
+            printf("pgen%d correctness run: status %d\n", pass ? 7 : 4, mtts_decoder_persist_status(a.persist_ws, 0));
+            if (pass == 0) { ref_h = hh; ref_c = cc; ref_g = gg; continue; }
+            size_t bad = 0;
+            for (size_t k = 0; k < hh.size(); ++k) bad += memcmp(&hh[k], &ref_h[k], 4) != 0 || memcmp(&cc[k], &ref_c[k], 4) != 0;
+            for (size_t k = 0; k < gg.size(); ++k) bad += memcmp(&gg[k], &ref_g[k], 4) != 0;
+            printf("  pgen7 vs pgen4 over %d steps (h, c, gates): %zu values differ  %s\n", Tq, bad, bad ? "MISMATCH" : "OK");
+        }
+    }
+    for (int variant = 0; variant < 2; ++variant) {
+        g_pgen7_off = variant == 0;
+        for (int rep = 0; rep < 3; ++rep) {
+            (void)hipEventRecord(e0, 0);
+            if (pgen_launch(a, 0, T, 0)) { printf("pgen_launch failed: %s\n", g_mtts_err); return 1; }
+            (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+            float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+            printf("pgen%d B=%d T=%d: %.3f ms = %.2f us per step (status %d)\n", variant ? 7 : 4, B, T, ms, ms * 1e3 / T, mtts_decoder_persist_status(a.persist_ws, 0));
+        }
     }
 #ifdef PS_PROF
     std::vector<unsigned long long> hp_gen(PS_PROF); (void)hipMemcpy(hp_gen.data(), prof, PS_PROF * 8, hipMemcpyDeviceToHost);
