@@ -11,7 +11,11 @@
 //
 // Kernels
 //   pgen_kernel  generator LSTM of the teacher-forced schedule (reference modules/tacotron2.py:187-188 with the input projection
-//                hoisted into one GEMM): per step  gates = pre_gen[t] + h_gen[t] W_hh^T -> cell -> h_gen[t+1]; 1 barrier per step.
+//                hoisted into one GEMM): per step  gates = pre_gen[t] + h_gen[t] W_hh^T -> cell -> h_gen[t+1]; 1 barrier per step
+//                (bf16 mode, MTTS_PGEN=1).
+//   pgen7_kernel the same recurrence as a DATAFLOW pipeline (fp32 default): multiplier waves with register-stationary weight planes, one
+//                service wave per 16-row group, no workgroup barrier in the loop; fp32 exchange.  pgen4_kernel = the same with a
+//                bf16-plane exchange (MTTS_PGEN=2; the harness checks that both return the same bits).
 //   pdec_kernel  attention LSTM + location-sensitive attention (reference modules/tacotron2.py:184-186, modules/attention.py:39-86,
 //                modules/layers.py:18-47): per step
 //                  phase 1 (column role: workgroup c owns LSTM units [4c, 4c+4)):  gates = pre_att[t] + [ctx_t | h_t] W^T -> cell
@@ -21,6 +25,8 @@
 //                           filter bank on MFMA, exact 3-way bf16 split) -> 4-way exchange of the partial energies (tagged 8-byte
 //                           granules) -> masked softmax, cumulative alignment (stays in LDS), context columns -> ctx_{t+1}
 //                                                                                                            | grid barrier
+//                The query does not wait for the first barrier: it polls the own sample's h row (sentinel pre-filled by the host) -
+//                the payload is the flag; the barrier is consumed after the attention step (PsDec.poll_h, MTTS_PDEC_POLL=0: off).
 // Arithmetic is the step kernels' (lstm_step.hip): fp32 operands split exactly into three bf16 planes, six
 // v_mfma_f32_16x16x32_bf16 terms per product, fp32 accumulation; the cell / attention math is fp32.
 //
@@ -70,12 +76,6 @@ union PsFrag { bf16x8 v; unsigned u[4]; };
 struct PsFrag3 { PsFrag p[3]; };
 __device__ __forceinline__ PsFrag3 ps_split8(const float4& lo, const float4& hi) {      // 8 consecutive k -> 3 bf16 planes
     PsFrag3 f;
-#if defined(PS_EXP) && PS_EXP == 3      // timing experiment (wrong numbers): no split arithmetic
-    f.p[0].u[0] = __float_as_uint(lo.x); f.p[0].u[1] = __float_as_uint(lo.y); f.p[0].u[2] = __float_as_uint(lo.z); f.p[0].u[3] = __float_as_uint(lo.w);
-    f.p[1].u[0] = __float_as_uint(hi.x); f.p[1].u[1] = __float_as_uint(hi.y); f.p[1].u[2] = __float_as_uint(hi.z); f.p[1].u[3] = __float_as_uint(hi.w);
-    f.p[2] = f.p[0];
-    return f;
-#endif
     ps_split_pair(lo.x, lo.y, f.p[0].u[0], f.p[1].u[0], f.p[2].u[0]);
     ps_split_pair(lo.z, lo.w, f.p[0].u[1], f.p[1].u[1], f.p[2].u[1]);
     ps_split_pair(hi.x, hi.y, f.p[0].u[2], f.p[1].u[2], f.p[2].u[2]);
@@ -458,9 +458,6 @@ __device__ __forceinline__ void ps_xq_store4(__amdgpu_buffer_rsrc_t r, int i16, 
     unsigned a[3], b[3];
     ps_split_pair(v.x, v.y, a[0], a[1], a[2]);
     ps_split_pair(v.z, v.w, b[0], b[1], b[2]);
-#if defined(PS_EXP) && PS_EXP == 1      // timing experiment (wrong layout): one 16-byte store per row instead of three 8-byte ones
-    { u32x4 w; w.x = a[0]; w.y = b[0]; w.z = a[1]; w.w = b[1]; __builtin_amdgcn_raw_buffer_store_b128(w, r, ps_xq_off(i16, k & ~7, 0), 0, 16); return; }
-#endif
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
         typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
@@ -644,11 +641,7 @@ __global__ __launch_bounds__(PS4_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
         const int g = i % NG, in = i + 1, gn = in % NG, tn = p.t0 + in / NG;
         const bool has_next = in < n_gs;
         const unsigned pubn = (unsigned)(in / NG + 1);
-#if defined(PS_EXP) && PS_EXP == 2      // timing experiment: never refill between the MFMAs
-        const bool early = false;
-#else
         const bool early = has_next && seen[gn] >= pubn;
-#endif
         const __amdgpu_buffer_rsrc_t nxr = xregion(gn, tn & 1);
         PS_STAMP(stamps, 2 * i, tid == 64 * 5);
         f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -840,11 +833,7 @@ __global__ __launch_bounds__(PS4_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
         const int g = i % NG, in = i + 1, gn = in % NG, tn = p.t0 + in / NG;
         const bool has_next = in < n_gs;
         const unsigned pubn = (unsigned)(in / NG + 1);
-#if defined(PS_EXP) && PS_EXP == 2      // timing experiment: never refill between the MFMAs
-        const bool early = false;
-#else
         const bool early = has_next && seen[gn] >= pubn;
-#endif
         const __amdgpu_buffer_rsrc_t nxr = xregion(gn, tn & 1);
         PS_STAMP(stamps, 2 * i, tid == 64 * 5);
         f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1026,9 +1015,6 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         }
         PD_STAMP(2);
         ps_bar_arrive(p.sync, ++epoch);
-#if !(defined(PS_EXP) && PS_EXP == 5)
-#define PD_PREFETCH_EARLY 1
-#endif
         float4 wq4[16]; float4 mem4[PD_NCM];
         auto pd_prefetch = [&]() {
         // operands of phase 2 that do not depend on h_{t+1}: requested behind the arrive, landing while the barrier completes.
@@ -1049,9 +1035,7 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             }
         }
         };
-#ifdef PD_PREFETCH_EARLY
         pd_prefetch();
-#endif
         if (cellthr) {
             const size_t o = ((size_t)(t + 1) * B + row) * H + u;
             p.c[o] = c_state;
@@ -1066,9 +1050,6 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         // re-read it until no sentinel is left (the payload is the flag: one store -> load hop instead of drain -> two-level arrive ->
         // poll -> fetch).  The barrier itself is then waited for after the attention step, where it has long completed.
         if (!p.poll_h && !ps_bar_wait(p.sync, epoch)) return;
-#ifndef PD_PREFETCH_EARLY
-        pd_prefetch();
-#endif
         PD_STAMP(3);
 
         // ================= phase 2: attention (sample role) =================
