@@ -53,3 +53,13 @@ def test_decoder_forward_forms_agree(tmp_path):
         ref = steps[k]
         rel = ((v.double() - ref.double()).norm() / ref.double().norm().clamp_min(1e-30)).item()
         assert rel <= 2e-5, f'{k}: persistent vs per-step launches, relative L2 {rel:.3e}'
+
+
+# Shape edges of the persistent kernels (csrc/persist.hip: 1..4 row tiles of 16, ragged last tile, a single sample, the maximal
+# encoder length 128 and a very short one, both memory widths Dm = 544 / 288, ragged text lengths): forward in train mode with
+# injected dropout draws against the CPU oracle (mel outputs, stop logits, alignments).
+@pytest.mark.parametrize('preset,B,L,T', [('shared_training', 1, 7, 10), ('shared_training', 17, 128, 6), ('shared_training', 33, 40, 12),
+                                          ('shared_training', 49, 25, 9), ('shared_training', 63, 128, 5), ('generated_switching', 40, 30, 8)])
+def test_persistent_kernels_shape_edges_match_oracle(preset, B, L, T):
+    from tests.test_gpu_more import run_train_step_case
+    run_train_step_case(preset, B, L, T, {}, check_grads=False)
