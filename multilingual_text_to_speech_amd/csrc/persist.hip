@@ -1065,7 +1065,7 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                                                            __float_as_uint(v.z) == PS_SENTINEL || __float_as_uint(v.w) == PS_SENTINEL) != 0ull) {
                             __builtin_amdgcn_s_sleep(1);
                             v = ps_ld16_sc1(hr, tid * 16);
-                            if (++spins > PS_SPIN_MAX) { __hip_atomic_store(p.sync.err, 2u, PS_RLX, PS_AGENT); break; }
+                            if (++spins > (PS_SPIN_MAX >> 3)) { __hip_atomic_store(p.sync.err, 2u, PS_RLX, PS_AGENT); break; }      // every retry is a ~1 us round trip: ~0.5 s
                         }
                     }
                     *reinterpret_cast<float4*>(hs + 4 * tid) = v;
