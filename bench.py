@@ -81,6 +81,8 @@ def train_step(model, crit, opt, buckets, batch, hp, teacher_forcing=1.0):
         torch.nn.utils.clip_grad_norm_(model.parameters(), hp.gradient_clipping)
         opt.step()
     crit.update_states()
+    from multilingual_text_to_speech_amd.kernels import poll_device_errors
+    poll_device_errors(dev)          # non-blocking: raises for what the previous step's poll fetched (the guarded Adam step protects the weights)
     return loss
 
 
@@ -121,6 +123,56 @@ def decoder_forward_us(model, hp, batch, L, repeats=3):
             times.append(e0.elapsed_time(e1) * 1e3)
     steady = sorted(times[1:])
     return steady[len(steady) // 2], enc, spk, lang
+
+
+def decoder_backward_us(model, hp, batch, L, repeats=2):
+    """Median time (us) of the whole decoder BACKWARD (mtts_decoder_bwd: both recurrence chains, the per-chunk weight-gradient and
+    input-gradient GEMMs, the batched tail), bracketed by HIP events on the launch stream (the helper streams join before the call
+    returns).  The forward runs un-timed in front of it; random upstream gradients for mels, stop logits and alignments."""
+    import multilingual_text_to_speech_amd.kernels as K
+    langs = batch['languages']
+    lang = langs.unsqueeze(1).expand(-1, L) if langs is not None else None
+    spk = batch['speakers'].unsqueeze(1).expand(-1, L) if batch['speakers'] is not None else None
+    with torch.no_grad():
+        emb = K.embedding(model._embedding.weight, batch['text'], 0)
+        enc = model._encoder(emb, batch['text_length'], lang)
+    dec_params = [p for p in model._decoder.parameters() if p.requires_grad]
+    times = []
+    for _ in range(repeats + 1):
+        e_in = enc.detach().clone().requires_grad_(True)
+        outs = model._decoder(e_in, batch['text_length'], batch['target'], 1.0, spk, lang)
+        gs = [torch.randn_like(o) * 1e-3 for o in outs]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        torch.autograd.grad(list(outs), [e_in] + dec_params, gs, allow_unused=True)
+        e1.record()
+        e1.synchronize()
+        times.append(e0.elapsed_time(e1) * 1e3)
+        del outs, gs, e_in
+    steady = sorted(times[1:])
+    return steady[len(steady) // 2]
+
+
+def backward_roofline(model, hp, batch, B, L, T, preset, dtype='f32'):
+    """'backward re-reads the same tensors plus saved per-step state: bwd algorithmic bytes = 2 x fwd + saved-state
+    traffic, reported separately'.  Saved state per sample and step (written by the forward, read by the backward, fp32): h / c of
+    both cells (4H), activated gates of both cells (8H), context (Dm), cumulative alignment + alignment (2L), query (A), prenet
+    activations of both layers (2P), frame + stop (M + 1)."""
+    us = decoder_backward_us(model, hp, batch, L)
+    us_step = us / T
+    alg = step_algorithmic(hp, B, L)
+    d = model_dims(hp)
+    saved = 12 * d['H'] + d['Dm'] + 2 * L + d['A'] + 2 * d['P'] + d['M'] + 1
+    fwd_bytes = alg['bytes'] if dtype != 'bf16' else 2.0 * alg['weights'] + 4.0 * B * alg['act_per_sample']
+    bytes_step = 2.0 * fwd_bytes + 2.0 * 4.0 * B * saved          # saved state: one write (forward) + one read (backward)
+    gbps = bytes_step / (us_step * 1e-6) / 1e9
+    return {'bound': 'hbm', 'what': f'decoder BACKWARD per step (teacher forced), params/{preset}, batch {B}, L={L}: attention backward, both LSTM '
+                                    'cell backwards, per-step input-gradient products, weight-gradient GEMMs, batched tail',
+            'achieved': round(gbps, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(gbps / 8000.0, 4), 'us_per_step': round(us_step, 2),
+            'ms_per_backward': round(us * 1e-3, 2), 'bytes_per_step': bytes_step,
+            'bytes_formula': '2 x forward algorithmic bytes + (write + read) of the saved per-step state', 'saved_state_elems_per_sample': saved,
+            'flop_per_step': 2.0 * alg['flop'], 'fp32_mfma_frac_of_157TF': round(2.0 * alg['flop'] / (us_step * 1e-6) / 157.3e12, 4),
+            'frames_timed': T, 'dtype': dtype}
 
 
 def step_roofline(model, hp, batch, B, L, T, preset, dtype='f32'):
@@ -507,6 +559,10 @@ def main():
         empty_s = (float(lib.mtts_prof_empty_ms()) / max(cnt.value, 1)) * 1e-3
         avg_s = max(raw_s - empty_s, 1e-9)
         roof = step_roofline(model, hp, batch, B, L, T, args.preset, args.dtype)
+        try:
+            roof_bwd = backward_roofline(model, hp, batch, B, L, T, args.preset, args.dtype)
+        except Exception as exc:      # reporting only
+            roof_bwd = {'error': repr(exc)[:200]}
         persistent = cnt.value > 0 and cnt.value <= 2 * args.steps          # one sample per train step = the persistent launch
         if persistent:
             # algorithmic operands of chain A per step: recurrent LSTM weights + query / location parameters read once, per sample the
@@ -547,7 +603,7 @@ def main():
                                    f'{args.dtype}, random-init weights', 'gemm_core': GEMM_CORE[args.dtype],
                        'global_batch': B * world, 'parallelism': f'dp{world}',
                        'loss': float(loss.item())},
-            'roofline': roof,
+            'roofline': roof, 'roofline_bwd': roof_bwd,
         }
         if world == 1 and not args.no_secondary:
             # free the training step's memory first; each leg is reporting only and must never cost the headline number
@@ -557,6 +613,8 @@ def main():
                 traffic, why = measure_traffic(args.preset, B, args.dtype)
                 roof['traffic'] = traffic['bytes_per_step'] if traffic else None
                 roof['traffic_detail'] = traffic if traffic else {'error': why}
+                if traffic:      # what actually crossed the fabric per step against the same peak (the recurrent weights stay on chip)
+                    roof['traffic_frac'] = round(traffic['bytes_per_step'] / (roof['us_per_step'] * 1e-6) / 8e12, 4)
             except Exception as exc:
                 roof['traffic_detail'] = {'error': repr(exc)[:200]}
             # batch 240 = the valid batch next to the north star's 256 on ONE GPU; batch 40 = what one rank of BASELINE configs[3]
@@ -564,8 +622,12 @@ def main():
             for key, nb, dt_ in (('roofline_b240', 240, 'f32'), ('roofline_b240_bf16', 240, 'bf16'), ('roofline_b40_bf16', 40, 'bf16')):
                 try:
                     line[key] = secondary_step_roofline('generated_switching', nb, L_CHARS, 300, device, dt_)
+                    torch.cuda.empty_cache()
+                    traffic, why = measure_traffic('generated_switching', nb, dt_, timeout=180)
+                    line[key]['traffic'] = traffic['bytes_per_step'] if traffic else None
+                    line[key]['traffic_detail'] = traffic if traffic else {'error': why}
                 except Exception as exc:
-                    line[key] = {'error': repr(exc)[:200]}
+                    line.setdefault(key, {})['error'] = repr(exc)[:200]
             _C.set_precision('bf16' if args.dtype == 'bf16' else 'fp32')
             try:
                 line['inference'] = inference_bench(device)

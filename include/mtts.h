@@ -217,8 +217,6 @@ typedef struct LstmPackArgs {
     const float* b_ih;     /* optional: bias_u[4u + g] = b_ih[gH + u] + b_hh[gH + u] */
     const float* b_hh;
     float* bias_u;
-    int plain_rows;        /* > 0: a plain [plain_rows, K] weight in identity row order (zero rows up to the next multiple of 128;
-                              dst needs mtts_ksplit_packed_weight_bytes) instead of an LSTM matrix in unit-major order */
 } LstmPackArgs;
 
 typedef struct LstmStepArgs {
@@ -255,8 +253,6 @@ typedef struct LstmStepArgs {
 int mtts_lstm_step_ksplit(int k_total);                    /* upper bound of the slab count over every nb_max >= 4 */
 long mtts_lstm_step_partial_floats(int B, int H, int k_total);
 long mtts_lstm_packed_weight_bytes(int H, int k_total, int precision);
-long mtts_ksplit_packed_weight_bytes(int N, int k_total, int precision);
-long mtts_ksplit_partial_floats(int B, int N, int k_total);
 int mtts_lstm_pack_weights(const LstmPackArgs* args, void* stream);
 /* dst[(4u + g) K + k] = src[(gH + u) ld + k]: rows of a [4H, K] LSTM matrix into unit-major order (for the hoisted projection) */
 int mtts_lstm_rows_unit_major(const float* src, int ld, int H, int K, float* dst, void* stream);
@@ -469,9 +465,6 @@ typedef struct AttnBwdArgs {
     int n_part;
     long part_ks;
     int part_ld;
-    float* hsum_out;       /* optional [B, hsum_cols]: sum over the n_part slabs of columns [Dm, Dm + hsum_cols) (the h-columns of a
-                              combined [ctx | h] input-gradient product), written for the cell backward that follows */
-    int hsum_cols;
     float* dq;             /* [B,A] zero-initialised, accumulated atomically */
     float* dMt;            /* [B,L,A] accumulated (+=) */
     float* dU_slab;        /* [B*nch][A*ksz] accumulated (+=) */
@@ -507,9 +500,6 @@ typedef struct DecoderGradArgs {
     float* dG_gen;         /* [T,B,4H] */
     float* dG_att_p;       /* [T][Bp*4H] MFMA tile order copies (optional) */
     float* dG_gen_p;
-    void* att_w_rec_T2p;   /* optional: [W_ih[:, P:] | W_hh]^T ([Dm+H, 4H]) packed for the K-split kernel (mtts_ksplit_packed_weight_bytes(Dm+H, 4H, 0)) */
-    float* part_rec;       /* optional: mtts_ksplit_partial_floats(B, Dm+H, 4H) floats: partial slabs of dG_att x [W_ih[:, P:] | W_hh] */
-    float* dh_rec_sum;     /* optional: [B,H] slab sum of the h-columns (written by the attention backward) */
     float* att_w_rec_Tp;   /* packed [Dm+H, 4H] */
     float* gen_w_hh_Tp;    /* packed [H, 4H] */
     float* dHG;            /* [T,B,H] */
@@ -633,6 +623,10 @@ typedef struct AdamArgs {
     float eps;
     float step_size;           /* lr / (1 - beta1^t) */
     float inv_sqrt_bc2;        /* 1 / sqrt(1 - beta2^t) */
+    const int* guard;          /* NULL, or the device error words of this GPU (int[2]: [0] invalid input seen by a kernel, [1] a
+                                  persistent decoder kernel gave up on a hand-off, DecoderArgs.persist_err).  With a guard the update
+                                  is SKIPPED on the device (no host synchronisation) when guard[1] != 0 or the gradient norm is not
+                                  finite: the step whose decode was invalid never reaches the weights; norm_out[1] is then -1 */
     int phase;                 /* 0: norm + update over this table; 1: only the global gradient norm / clip coefficient into norm_out
                                   (table = ALL parameters); 2: only the update, with the clip coefficient already in norm_out[1]
                                   (table = one parameter group / bias-correction step: train.py:261-270 trains the encoder with
@@ -721,7 +715,7 @@ int mtts_sizeof_struct(int which);
  * ELEMENTS the caller must allocate for a caller-provided buffer of the argument blocks, by FIELD NAME (the struct member's
  * name; per-layer arrays: "prenet_act", "prenet_mask", "prenet_wp0", "prenet_wp1", "prenet_w_T0" (first layer) / "prenet_w_T").
  * Fill the shape fields first (DecoderArgs: B, L, T, M, P, H, A, Dm, ksz, C, n_prenet, kq, fast, precision; DecoderGradArgs: ksb,
- * ksb_ctx, nch; BiLstmArgs: B, L, Cin, H).  Element = float, except att_w2p / gen_w2p / att_w_rec_T2p / persist_ws (bytes) and the
+ * ksb_ctx, nch; BiLstmArgs: B, L, Cin, H).  Element = float, except att_w2p / gen_w2p / persist_ws (bytes) and the
  * keep-flag masks (uint8).  -1 = unknown field.  Replaces the size formulas a binding would otherwise copy from the comments. */
 long mtts_decoder_buffer_elems(const DecoderArgs* args, const char* field);
 long mtts_decoder_grad_buffer_elems(const DecoderArgs* fwd, const DecoderGradArgs* grad, const char* field);

@@ -76,11 +76,6 @@ def decoder_bwd(ctx, dspec, dstop, dalign):
         buf('dG_gen_p', zp('dG_gen_p'))
         buf('att_w_rec_Tp', E('att_w_rec_Tp'))
         buf('gen_w_hh_Tp', E('gen_w_hh_Tp'))
-    if st.fast and H % 32 == 0 and Dm % 4 == 0 and B <= 64 and os.environ.get('MTTS_GBWD', '0') == '1':
-        # experiment (off by default, see csrc/decoder_bwd.hip): K-split input-gradient product of chain A
-        buf('att_w_rec_T2p', torch.empty(n_of('att_w_rec_T2p'), dtype=torch.uint8, device=dev))
-        buf('part_rec', E('part_rec'))
-        buf('dh_rec_sum', E('dh_rec_sum'))
     if not st.fast:      # general schedule (teacher forcing < 1): per-step chain with transposed full weights
         buf('att_w_ih_T', E('att_w_ih_T'))
         buf('gen_w_ih_T', E('gen_w_ih_T'))

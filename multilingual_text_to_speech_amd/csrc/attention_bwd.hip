@@ -118,8 +118,6 @@ __global__ __launch_bounds__(ATB_THREADS) void attn_bwd_kernel(AttnBwdArgs p) {
     attn_bwd_body<NP>(p, sm, blockIdx.x, blockIdx.y);
 }
 
-bool attn_bwd_fast_supported(const AttnBwdArgs& p, int max_part) { return attn_bwd_fast_ok(p, max_part); }
-
 MTTS_API int mtts_attn_step_bwd(const AttnBwdArgs* args, void* stream) {
     const AttnBwdArgs& p = *args;
     MTTS_REQUIRE((p.ksz & 1) == 1, "attention kernel size must be odd (got %d)", p.ksz);
@@ -127,11 +125,9 @@ MTTS_API int mtts_attn_step_bwd(const AttnBwdArgs* args, void* stream) {
     const size_t lds = sizeof(float) * ((size_t)5 * p.A + 2 * p.L + (p.L + p.ksz - 1) + (size_t)p.A * p.ksz + p.Dm + lc +
                                         (size_t)lc * p.A + (lc + p.ksz - 1) + 16);
     const size_t lds_fast = attn_bwd_fast_lds(p);
-    const bool fast = attn_bwd_fast_ok(p, BNP_BIG);
-    MTTS_REQUIRE(fast || !p.hsum_out, "attn_bwd: hsum_out needs the fast kernel (A = 64/128, n_part <= %d)", BNP_BIG);
+    const bool fast = attn_bwd_fast_ok(p);
     MTTS_REQUIRE(fast || lds <= 64 * 1024, "attn_bwd: LDS request %zu too large (raise nch)", lds);
-    if (fast && p.n_part > BNP_MAX) hipLaunchKernelGGL(attn_bwd_kernel<BNP_BIG>, dim3(p.B, p.nch), dim3(ATB_THREADS), lds_fast, (hipStream_t)stream, p);
-    else if (fast) hipLaunchKernelGGL(attn_bwd_kernel<BNP_MAX>, dim3(p.B, p.nch), dim3(ATB_THREADS), lds_fast, (hipStream_t)stream, p);
+    if (fast) hipLaunchKernelGGL(attn_bwd_kernel<BNP_MAX>, dim3(p.B, p.nch), dim3(ATB_THREADS), lds_fast, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(attn_bwd_generic_kernel, dim3(p.B, p.nch), dim3(ATB_THREADS), lds, (hipStream_t)stream, p);
     MTTS_CHECK_LAUNCH("attn_bwd_kernel");
     return 0;

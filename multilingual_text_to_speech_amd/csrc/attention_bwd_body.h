@@ -26,7 +26,6 @@ constexpr int BNU_MAX = 8;    // filter-bank elements per thread
 constexpr int BNR_MAX = 4;    // own rows per wave
 constexpr int BND_MAX = 9;    // memory floats per lane per row (Dm <= 576)
 constexpr int BNP_MAX = 8;    // partial slabs (fused launch, 128-VGPR budget)
-constexpr int BNP_BIG = 24;   // partial slabs of the stand-alone kernel fed by the K-split [ctx | h] input-gradient product
 constexpr int BNX_MAX = 2;    // context floats per thread (Dm <= 1024)
 constexpr int BUP_LD = 36;    // U row (32 taps + pad)
 constexpr int BROWS = 32;     // padded row count of a chunk
@@ -77,17 +76,6 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& p, float* sm, c
         for (int k = 0; k < NP; ++k) g += pp[k];
         dcx[j] = g;
         cx[j] = p.ctx[(long)b * Dm + d];
-    }
-    if (p.hsum_out) {      // h-columns [Dm, Dm + hsum_cols) of the same slabs, summed for the cell backward that follows this kernel
-        const int hc = (p.hsum_cols + p.nch - 1) / p.nch, h1 = min(p.hsum_cols, (ch + 1) * hc);
-        for (int i = ch * hc + tid; i < h1; i += ATB_THREADS) {
-            float pp[NP], g = 0.f;
-#pragma unroll
-            for (int k = 0; k < NP; ++k) pp[k] = (k < p.n_part) ? p.part[(long)k * p.part_ks + (long)b * p.part_ld + Dm + i] : 0.f;
-#pragma unroll
-            for (int k = 0; k < NP; ++k) g += pp[k];
-            p.hsum_out[(long)b * p.hsum_cols + i] = g;
-        }
     }
     float memr[BNR_MAX][BND_MAX];
 #pragma unroll

@@ -124,10 +124,6 @@ int add3(float* out, int ldo, const float* a, int lda, const float* b, int ldb, 
          bool accumulate, hipStream_t s);
 int attn_bwd_plus_skinny(const AttnBwdArgs& a, const SkinnyArgs& k, hipStream_t s);
 int lstm_step_launch(const LstmStepArgs& a, hipStream_t s);
-int ksplit_gemm_launch(const float* x, int K, int ldx, const void* wp, int B, int N, float* part, int precision, int ks_want, int* ks_out,
-                       hipStream_t s);
-bool attn_bwd_fast_supported(const AttnBwdArgs& p, int max_part);
-int lstm_step2_launch(const LstmStepArgs& a, const LstmStepArgs& b, hipStream_t s);
 int sum_slabs(const float* part, int n, long stride, int ldp, const float* bias, float* out, int rows, int cols, int ldo, int act, hipStream_t s);
 // persistent recurrences (persist.hip)
 bool persist_enabled();

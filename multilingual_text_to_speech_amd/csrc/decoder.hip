@@ -38,10 +38,6 @@ static SkSeg seg_h(const float* rowmajor, const float* packed, int t, int B, int
 // Chain B of the fast schedule for steps [c0, c1): generator-LSTM input gates (batched), the recurrent steps and the
 // frame/stop projection (batched).  Runs on its own low-priority stream behind chain A (see side_stream()).
 static bool gen_uses_lstep(const DecoderArgs& a) {
-    // MTTS_GEN_SKINNY=1 (experiment): the generator LSTM's recurrent step as ONE launch of the round-1 kernel (16 gate columns per
-    // workgroup over the whole K = H, fused cell) instead of the K-split gate GEMM + cell kernel pair
-    static const bool skinny = [] { const char* e = getenv("MTTS_GEN_SKINNY"); return e && e[0] == '1'; }();
-    if (skinny) return false;
     return a.fast && a.gen_w2p && a.gen_bias_u && a.gen_w_ih_u && a.gate_part_gen && (a.H & 31) == 0;
 }
 
@@ -208,20 +204,14 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
                             use_ls ? P : P + Dm, 4 * H, false, false, 1.f, 0.f, nullptr, 0, s));
     }
 
-    // fast schedule: chain B trails chain A by one chunk on the side stream.
-    // MTTS_FUSE2=1 (experiment, off): the generator LSTM's step t - CH rides in the SAME two launches as the attention LSTM's
-    // step t (lstm_step2_launch), everything on the caller's stream.  Measured 53.9 vs 50.5 us per decoder step and 94.7 vs
-    // 92.0 ms per train step: although the two chains' step kernels hardly overlap (4 % of the wall time), the side stream
-    // fills exactly the ramp / drain / boundary gaps of chain A, and a 512-workgroup fused launch has a longer tail than two
-    // 256-workgroup launches on two queues.
+    // fast schedule: chain B trails chain A by one chunk on the side stream (sharing launches between the two chains was measured
+    // slower: the side stream fills exactly the ramp / drain / boundary gaps of chain A)
     const int CH = decoder_chunk();
-    static const bool want_fuse2 = [] { const char* e = getenv("MTTS_FUSE2"); return e && e[0] == '1'; }();
-    const bool fuse2 = use_ls && gen_uses_lstep(a) && want_fuse2;
     // persistent generator LSTM (persist.hip): chain B runs AFTER chain A as input GEMM (all steps) -> one persistent launch
     // -> projection GEMM (all steps), everything on the caller's stream
-    const bool pg = a.fast && !fuse2 && gen_uses_lstep(a) && pgen_supported(a);
-    hipStream_t sb = (a.fast && !fuse2 && !pg) ? side_stream(s) : nullptr;
-    if (a.fast && !fuse2 && !pg && !sb) return mtts_fail("decoder: cannot create the side stream");
+    const bool pg = a.fast && gen_uses_lstep(a) && pgen_supported(a);
+    hipStream_t sb = (a.fast && !pg) ? side_stream(s) : nullptr;
+    if (a.fast && !pg && !sb) return mtts_fail("decoder: cannot create the side stream");
     // persistent attention LSTM + attention (persist.hip): chain A of the fast schedule as ONE launch
     const bool pd = pg && use_ls && pdec_supported(a);
     if (pd) {      // (bench.py samples the whole launch with HIP events: mtts_prof_begin / mtts_prof_end)
@@ -230,7 +220,6 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
         if (sampled) prof_sample(0, s, 1);
     }
     for (int t = a.t0; t < a.t1 && !pd; ++t) {
-        if (fuse2 && t > a.t0 && ((t - a.t0) % CH) == 0) MTTS_TRY(gen_pre(a, t - CH, t, 0, s));      // input gates of the chunk chain B enters now
         const bool teach = a.frames_in && a.teacher && a.teacher[t];
         if (!teach) {
             // prenet on the model's own previous frame (tacotron2.py:181), out slot t holds frame t-1 (slot 0 = zeros)
@@ -272,8 +261,7 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
             }
             k.w_query = a.w_query; k.A = A; k.qpart = a.qpart;
             const bool sampled = prof_sample(t, s, 0);
-            if (fuse2 && t - CH >= a.t0) MTTS_TRY(lstm_step2_launch(k, gen_step_args(a, t - CH), s));
-            else MTTS_TRY(lstm_step_launch(k, s));
+            MTTS_TRY(lstm_step_launch(k, s));
             if (sampled) prof_sample(t, s, 1);
         } else {   // attention LSTM (tacotron2.py:184-185)
             SkinnyArgs k; memset(&k, 0, sizeof(k));
@@ -367,19 +355,13 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
                 }
             }
         }
-        if (a.fast && !fuse2 && !pg && (((t + 1 - a.t0) % CH) == 0 || t + 1 == a.t1)) {
+        if (a.fast && !pg && (((t + 1 - a.t0) % CH) == 0 || t + 1 == a.t1)) {
             const int c1 = t + 1, c0 = a.t0 + ((c1 - a.t0 - 1) / CH) * CH;
             hipEvent_t ev = pool_event(s);
             MTTS_CHECK_HIP(hipEventRecord(ev, s));
             MTTS_CHECK_HIP(hipStreamWaitEvent(sb, ev, 0));
             MTTS_TRY(gen_chunk(a, c0, c1, sb));
         }
-    }
-    if (fuse2) {      // tail: chain B's last chunk on its own, then ONE projection GEMM pair over all steps
-        const int last0 = a.t0 + ((nsteps - 1) / CH) * CH;                 // first step of the last (possibly ragged) chunk
-        MTTS_TRY(gen_pre(a, last0, a.t1, 0, s));
-        MTTS_TRY(gen_steps(a, nsteps > CH ? a.t1 - CH : a.t0, a.t1, s));
-        return gen_proj(a, a.t0, a.t1, 0, s);
     }
     if (pg) {
         MTTS_TRY(gen_pre(a, a.t0, a.t1, 0, s));

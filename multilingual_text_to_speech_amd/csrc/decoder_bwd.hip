@@ -230,27 +230,6 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
     if (g.att_w_rec_Tp) MTTS_TRY(mtts_pack_weight(g.att_w_rec_T, 4 * H, Dm + H, 4 * H, 0, g.att_w_rec_Tp, s));
     if (g.gen_w_hh_Tp) MTTS_TRY(mtts_pack_weight(g.gen_w_hh_T, 4 * H, H, 4 * H, 0, g.gen_w_hh_Tp, s));
     const long Bp4H = (long)((B + 15) & ~15) * 4 * H;
-    // MTTS_GBWD=1 (experiment, off): chain A's input-gradient product dG_att(t) x [W_ih[:, P:] | W_hh] as ONE K-split launch
-    // (lstm_gates_kernel over the packed transposed weight): 19 partial slabs of [B, Dm + H]; the attention backward sums its
-    // ctx-columns AND the h-columns (for the cell backward after it), replacing the ctx-column skinny launch and the skinny role of
-    // the fused attention launch.  Gradient-parity green, but measured 92.6-93.2 vs 91.3-91.7 ms per train step: the attention
-    // backward pays for summing 19 x 1568 partials per sample (22.8 vs 18.1 us), and a 247-workgroup / 226-VGPR launch leaves the
-    // weight-gradient GEMMs of the third stream nothing to overlap with (backward wall 48 vs 42 ms under the profiler).
-    static const bool want_gbwd = [] { const char* e = getenv("MTTS_GBWD"); return e && e[0] == '1'; }();
-    const int KSR = 19;
-    bool use_g = want_gbwd && g.att_w_rec_T2p && g.part_rec && g.dh_rec_sum && (H & 7) == 0 && B <= 64;
-    if (use_g) {
-        AttnBwdArgs probe; memset(&probe, 0, sizeof(probe));
-        probe.B = B; probe.L = L; probe.A = A; probe.Dm = Dm; probe.ksz = a.ksz; probe.nch = g.nch; probe.n_part = KSR;
-        use_g = attn_bwd_fast_supported(probe, 24);
-    }
-    if (use_g) {
-        LstmPackArgs k; memset(&k, 0, sizeof(k));
-        k.w[0] = g.att_w_rec_T; k.K[0] = 4 * H; k.ldw[0] = 4 * H; k.nseg = 1; k.H = H; k.precision = 0; k.dst = g.att_w_rec_T2p;
-        k.plain_rows = Dm + H;
-        MTTS_TRY(mtts_lstm_pack_weights(&k, s));
-    }
-
     const float* dout1 = g.dout + (long)B * Mo;      // slot 1 = step 0
     // ---- projection backward (batched): dHG = dout W_out[:, :H],  dctx_all[1:] = dout W_out[:, H:]
     MTTS_TRY(gm(dout1, a.w_out, g.dHG, TB, H, M + 1, Mo, H + Dm, H, false, true, 0.f, s));
@@ -380,13 +359,7 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
                 if (t < T - 1) { q.part = part_ctx; q.n_part = ksc; q.part_ks = BD; q.part_ld = Dm; }
                 q.dq = g.dq_all + t * BA; q.dMt = g.dMt; q.dU_slab = g.dU_slab; q.dv_slab = g.dv_slab; q.dbias_slab = g.dbias_slab;
                 q.B = B; q.L = L; q.A = A; q.Dm = Dm; q.ksz = a.ksz; q.nch = g.nch;
-                if (use_g) {
-                    if (t < T - 1) {
-                        q.part = g.part_rec; q.n_part = KSR; q.part_ks = (long)B * (Dm + H); q.part_ld = Dm + H;
-                        q.hsum_out = g.dh_rec_sum; q.hsum_cols = H;
-                    }
-                    MTTS_TRY(mtts_attn_step_bwd(&q, s));
-                } else if (t < T - 1) {     // fat launch with the h-columns of step t+1's input gradient
+                if (t < T - 1) {     // fat launch with the h-columns of step t+1's input gradient
                     SkinnyArgs k; memset(&k, 0, sizeof(k));
                     k.nseg = 1; k.B = B; k.N = H; k.ksplit = ksb;
                     k.seg[0] = gemm_seg(t + 1, true);
@@ -402,18 +375,15 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
                 k.seg[0] = SkSeg{g.dq_all + t * BA, g.w_query_T, A, A, A, 0, 0};
                 k.dh_a = g.dHA + t * BH; k.ld_dh_a = H;
                 if (t < T - 1) { k.part = part_h; k.n_part = ksb; k.part_ks = BH; k.part_ld = H; k.part_col0 = 0; }
-                if (use_g && t < T - 1) { k.part = g.dh_rec_sum; k.n_part = 1; k.part_ks = 0; }
                 k.gates = a.gates_att + t * B4H; k.c_prev = a.c_att + t * BH;
                 k.dc_in = g.dc_att + ((t + 1) & 1) * BH; k.dc_out = g.dc_att + (t & 1) * BH;
                 if (a.zone) { k.dh_b = g.dh_carry_att + ((t + 1) & 1) * BH; k.dh_carry_out = g.dh_carry_att + (t & 1) * BH; }
                 k.dgates_out = g.dG_att + t * B4H; k.ld_dgates = 4 * H;
-                k.dg_pack_out = (g.dG_att_p && !use_g) ? g.dG_att_p + t * Bp4H : nullptr;
+                k.dg_pack_out = g.dG_att_p ? g.dG_att_p + t * Bp4H : nullptr;
                 bwd_reg(a, k, a.att_hmask, a.att_cmask, t);
                 MTTS_TRY(skinny_launch(k, s));
             }
-            if (t > 0 && use_g) {   // d[ctx_{t-1} | h_att_{t-1}] = dG_att_t [W_ih[:, P:] | W_hh]: 19 K-slices x 13 column tiles
-                MTTS_TRY(ksplit_gemm_launch(g.dG_att + t * B4H, 4 * H, 4 * H, g.att_w_rec_T2p, B, Dm + H, g.part_rec, 0, KSR, nullptr, s));
-            } else if (t > 0) {   // d ctx_{t-1} = dG_att_t W_ih[:, P:]  (critical path of the next attention backward)
+            if (t > 0) {   // d ctx_{t-1} = dG_att_t W_ih[:, P:]  (critical path of the next attention backward)
                 SkinnyArgs q; memset(&q, 0, sizeof(q));
                 q.nseg = 1; q.B = B; q.N = Dm; q.ksplit = ksc;
                 q.seg[0] = gemm_seg(t, false);

@@ -23,8 +23,7 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_plus_skinny_kernel(AttnBwdArgs
 
 // Falls back to two separate launches when the fused preconditions do not hold.
 int attn_bwd_plus_skinny(const AttnBwdArgs& a, const SkinnyArgs& k, hipStream_t s) {
-    static const bool no_fat = [] { const char* e = getenv("MTTS_NO_FAT"); return e && e[0] == '1'; }();      // A/B switch: two launches
-    const bool fusable = !no_fat && attn_bwd_fast_ok(a) && k.lstm == 0 && k.B > 32 && k.B <= 64 && k.nseg == 1 && k.ksplit >= 1;
+    const bool fusable = attn_bwd_fast_ok(a) && k.lstm == 0 && k.B > 32 && k.B <= 64 && k.nseg == 1 && k.ksplit >= 1;
     if (!fusable) {
         MTTS_TRY(mtts_attn_step_bwd(&a, s));
         return skinny_launch(k, s);

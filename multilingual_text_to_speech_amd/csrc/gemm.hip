@@ -759,159 +759,6 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(GemmArgs p, float* g_
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// gemm_pipe_persist_kernel (MTTS_GEMM_PERSIST=1): the same stream as gemm_pipe_kernel, but 256 workgroups walk ALL tiles of a plain
-// GEMM and the load stream runs across tile boundaries: while a tile's last K blocks are multiplied, the next tile's first two
-// blocks are already being fetched and split, so only the epilogue remains of the ~9.5 us a tile costs outside its K loop.
-// The stage of a K block is a compile-time constant of the stream, hence every tile takes an EVEN number of blocks: an odd K range
-// is padded with one block of zeros (descriptors with num_records 0 make every load return 0).  At a tile boundary stage 0 already
-// holds the next tile's first block, so the epilogue transposes through the free stage-1 halves of the LDS image, 32 rows at a time.
-// Plain GEMMs without split-K / grid.z and with a vectorisable epilogue only (host side checks).
-// Status: bit-identical to the other cores (tests/test_gpu_gemm_pipe.py) but NOT faster yet - 10.1 us + 1.33 us per K block per tile
-// against 9.4 + 1.28 (scripts/dbg_gemm_k.py): the branches in the stream cost ~4 % of the main loop and the two-pass epilogue with
-// its barrier costs what launch + prologue + one-pass epilogue did - hence opt-in.
-template <bool TA, bool TB>
-__global__ __launch_bounds__(256, 2) void gemm_pipe_persist_kernel(GemmArgs p, float* g_ws) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    char* lds = reinterpret_cast<char*>(smem);
-    const int ntx = (p.N + BN - 1) / BN, nty = (p.M + BM - 1) / BM;
-    const int nt = ntx * nty, G = gridDim.x;
-    const int n_my = (nt - (int)blockIdx.x + G - 1) / G;                 // tiles blockIdx.x, blockIdx.x + G, ...
-    const float* A = p.A; const float* B = p.B;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    const int li = lane & 31, lq = lane >> 5;
-    const int nkb = p.K / BK, nkb_p = nkb + (nkb & 1);
-    const int q8 = tid >> 3, k8 = tid & 7;
-    auto tile_of = [&](int i, int& m0, int& n0) {
-        int id = blockIdx.x + i * G;
-        const int q = nt / 8, r = nt % 8, xcd = id % 8, idx = id / 8;       // XCD-aware tile order (see gemm_mfma_kernel)
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        m0 = (id / ntx) * BM; n0 = (id % ntx) * BN;
-    };
-    const long extA = TA ? ((long)(p.K - 1) * p.lda + p.M) * 4 : ((long)(p.M - 1) * p.lda + p.K) * 4;
-    const long extB = TB ? ((long)(p.K - 1) * p.ldb + p.N) * 4 : ((long)(p.N - 1) * p.ldb + p.K) * 4;
-    const unsigned stepA = TA ? (unsigned)p.lda * (BK * 4) : BK * 4, stepB = TB ? (unsigned)p.ldb * (BK * 4) : BK * 4;
-
-    // load-stream state per operand: tile ordinal, K blocks until the next event (zero block / tile switch), ONE descriptor whose base
-    // is the tile's first row, per-slab offsets in VGPRs (four descriptors per operand spilled scalar registers), K position in soff
-    __amdgpu_buffer_rsrc_t rsrcA[4], rsrcB[4];
-    unsigned voffA[4], voffB[4], soffA = 0, soffB = 0;
-    int tiA = 0, tiB = 0, cntA = nkb, cntB = nkb;
-    bool padA = (nkb & 1) != 0, padB = padA;
-    auto set_tile_A = [&](int i, bool zero) {
-        int m0, n0; tile_of(i, m0, n0);
-        const long sa = (TA ? (long)m0 : (long)m0 * p.lda) * 4;
-        rsrcA[0] = rsrcA[1] = rsrcA[2] = rsrcA[3] =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(A)) + sa, 0, zero ? 0 : (int)max(0L, extA - sa), 0x00020000);
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-            voffA[it] = TA ? (unsigned)(((long)(4 * k8 + it) * p.lda + min(4 * q8, max(p.M - m0 - 4, 0))) * 4)
-                           : (unsigned)(((long)(q8 + 32 * it) * p.lda + 4 * k8) * 4);
-    };
-    auto set_tile_B = [&](int i, bool zero) {
-        int m0, n0; tile_of(i, m0, n0);
-        const long sb = (TB ? (long)n0 : (long)n0 * p.ldb) * 4;
-        rsrcB[0] = rsrcB[1] = rsrcB[2] = rsrcB[3] =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(B)) + sb, 0, zero ? 0 : (int)max(0L, extB - sb), 0x00020000);
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-            voffB[it] = TB ? (unsigned)(((long)(4 * k8 + it) * p.ldb + min(4 * q8, max(p.N - n0 - 4, 0))) * 4)
-                           : (unsigned)(((long)(q8 + 32 * it) * p.ldb + 4 * k8) * 4);
-    };
-    auto nextA = [&]() {
-        soffA += stepA;
-        if (--cntA != 0) return;
-        if (padA) { padA = false; cntA = 1; set_tile_A(min(tiA, n_my - 1), true); }          // the zero block that makes the count even
-        else { ++tiA; soffA = 0; cntA = nkb; padA = (nkb & 1) != 0; set_tile_A(min(tiA, n_my - 1), tiA >= n_my); }
-    };
-    auto nextB = [&]() {
-        soffB += stepB;
-        if (--cntB != 0) return;
-        if (padB) { padB = false; cntB = 1; set_tile_B(min(tiB, n_my - 1), true); }
-        else { ++tiB; soffB = 0; cntB = nkb; padB = (nkb & 1) != 0; set_tile_B(min(tiB, n_my - 1), tiB >= n_my); }
-    };
-    set_tile_A(0, false); set_tile_B(0, false);
-
-    const int wrA = TA ? 4 * q8 : q8, wrB = TB ? 4 * q8 : q8;
-    const unsigned waA = wrA * SP_ROW_B + (((k8 >> 1) ^ ((wrA >> 2) & 3)) * 16) + (k8 & 1) * 8;
-    const unsigned waB = wrB * SP_ROW_B + (((k8 >> 1) ^ ((wrB >> 2) & 3)) * 16) + (k8 & 1) * 8;
-    unsigned ra[2][2], rb[2][2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int rowa = wm + i * 32 + li, rowb = wn + i * 32 + li;
-            ra[ks][i] = rowa * SP_ROW_B + (((2 * ks + lq) ^ ((rowa >> 2) & 3)) * 16);
-            rb[ks][i] = rowb * SP_ROW_B + (((2 * ks + lq) ^ ((rowb >> 2) & 3)) * 16) + PP_OPERAND_B;
-        }
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    u32x4 RA[MTTS_PIPE_SETS][4], RB[MTTS_PIPE_SETS][4];
-    PipeTmp tmp;
-    bf16x8 f0a[2][3], f0b[2][3], f1a[2][3], f1b[2][3];
-
-    // prologue (once per workgroup): block 0 of the first tile -> stage 0, block 1 in flight, first fragments
-#define PP_NXT 0
-#pragma unroll
-    for (int it = 0; it < 4; ++it) { PP_LD(A, it) PP_LD(B, it) }
-    PP_NEXT(A) PP_NEXT(B)
-    PP_FILL_ALL(A)
-    PP_FILL_ALL(B)
-#pragma unroll
-    for (int it = 0; it < 4; ++it) { PP_LD(A, it) PP_LD(B, it) }
-    PP_NEXT(A) PP_NEXT(B)
-#undef PP_NXT
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) { PP_RDA(f0, 0, i, pl, 0) PP_RDB(f0, 0, i, pl, 0) }
-
-    // epilogue scratch of this wave: 32 rows x 72 floats inside the stage-1 half of operand A's (waves 0, 1) or B's (waves 2, 3) image
-    float* T = reinterpret_cast<float*>(lds + (wave < 2 ? PP_STAGE_B : PP_OPERAND_B + PP_STAGE_B) + (wave & 1) * (32 * EP_LD * 4));
-    const int c4 = lane & 15, rr = lane >> 4;
-    for (int ti = 0; ti < n_my; ++ti) {
-        for (int n = nkb_p >> 1; n > 0; --n) {
-#define PP_CUR 0
-#define PP_NXT 1
-#include MTTS_PIPE_BODY
-#undef PP_CUR
-#undef PP_NXT
-#define PP_CUR 1
-#define PP_NXT 0
-#include MTTS_PIPE_BODY
-#undef PP_CUR
-#undef PP_NXT
-        }
-        // stage 1 is free now (every wave passed the last block barrier after its last read of it); stage 0 holds the next tile
-        int m0, n0; tile_of(ti, m0, n0);
-        const int col = n0 + wn + 4 * c4;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * lq) * EP_LD + j * 32 + li] = acc[i][j][r];
-            __builtin_amdgcn_wave_barrier();
-            if (col < p.N) MTTS_EPI_DISPATCH(pipe_epilogue_rows_half, p, T, p.C, (long)p.ldc, p.bias, m0 + wm + i * 32, col, c4, rr);
-            __builtin_amdgcn_wave_barrier();
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        __syncthreads();                  // the next block's split stores go into stage 1
-    }
-}
 
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs p, float* g_ws) {
@@ -1080,9 +927,7 @@ MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
         const long tiles = (long)ntx * nty * p.batch * p.zt;
         const int nkb = cdiv(p.K, BK);
         if (g_ws_host && tiles < 512 && nkb >= 32) {
-            static const long helper_target = [] { const char* e = getenv("MTTS_HELPER_SPLIT_TARGET"); const long v = e ? atol(e) : 0; return v > 0 ? v : 512L; }();
-            static const long main_target = [] { const char* e = getenv("MTTS_MAIN_SPLIT_TARGET"); const long v = e ? atol(e) : 0; return v > 0 ? v : 1024L; }();
-            const long target = region == 0 ? main_target : helper_target;
+            const long target = region == 0 ? 1024L : 512L;      // workgroups wanted on the caller's stream / a helper stream
             S = (int)((target + tiles - 1) / tiles);
             if (S > nkb / 16) S = nkb / 16;
             if (S > 32) S = 32;
@@ -1098,19 +943,16 @@ MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
     // Helper-stream launches (side / weight-gradient stream) ask for 96 KiB of LDS: ONE GEMM workgroup per CU.  Every step
     // kernel of the decoder chains is built to fit beside it (<= 128 VGPRs, <= 64 KiB LDS: lstm_gates_kernel<., 4>,
     // skinny_kernel_lo, the attention kernels), so the latency-critical chain never waits for a 100-300 us GEMM workgroup to
-    // retire.  Same-box A/B, 20 steps: 89.2-89.6 ms per train step with the reservation, 91.4-91.9 without
-    // (MTTS_GEMM_RESERVE_CU=0), 95.5 with round 1's 150-VGPR step kernels.
-    static const bool reserve_cu = [] { const char* e = getenv("MTTS_GEMM_RESERVE_CU"); return !(e && e[0] == '0'); }();
-    const size_t lds = (p.nosplit && reserve_cu) ? (size_t)96 * 1024 : lds_base;
+    // retire.  Same-box A/B, 20 steps: 89.2-89.6 ms per train step with the reservation, 91.4-91.9 without, 95.5 with round 1's
+    // 150-VGPR step kernels.
+    const size_t lds = p.nosplit ? (size_t)96 * 1024 : lds_base;
     hipStream_t s = (hipStream_t)stream;
     // the attribute is per DEVICE (one process may drive several): one flag per device ordinal
     static bool attr_done_dev[64] = {false};
     int dev_ = 0; (void)hipGetDevice(&dev_);
     bool& attr_done = attr_done_dev[dev_ & 63];
     if (!attr_done) {   // > 64 KiB of dynamic LDS needs the opt-in attribute
-        const void* kernels[19] = {(const void*)gemm_pipe_persist_kernel<false, false>, (const void*)gemm_pipe_persist_kernel<false, true>,
-                                   (const void*)gemm_pipe_persist_kernel<true, false>, (const void*)gemm_pipe_persist_kernel<true, true>,
-                                   (const void*)gemm_pipe_kernel<false, false, 1>, (const void*)gemm_pipe_kernel<false, true, 2>,
+        const void* kernels[15] = {(const void*)gemm_pipe_kernel<false, false, 1>, (const void*)gemm_pipe_kernel<false, true, 2>,
                                    (const void*)gemm_pipe_kernel<true, true, 3>,(const void*)gemm_mfma_kernel<false, false>, (const void*)gemm_mfma_kernel<false, true>,
                                    (const void*)gemm_mfma_kernel<true, false>, (const void*)gemm_mfma_kernel<true, true>,
                                    (const void*)gemm_split_kernel<false, false>, (const void*)gemm_split_kernel<false, true>,
@@ -1137,18 +979,7 @@ MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
         else if (p.shift_mode == 1 && !p.transA && p.Kc % BK == 0 && p.transB && (p.b_tap & 3) == 0) pipe = 2;
         else if (p.shift_mode == 2 && p.transA && p.transB && p.taps == 1 && p.seq_len >= BK) pipe = 3;
     }
-    // persistent variant (opt-in, MTTS_GEMM_PERSIST=1): plain GEMMs with more tiles than CUs, no split-K / grid.z, vectorisable epilogue
-    static const bool persist_on = [] { const char* e = getenv("MTTS_GEMM_PERSIST"); return e && e[0] == '1'; }();
-    const bool persist = persist_on && pipe == 0 && S == 1 && p.batch * p.zt == 1 && (long)ntx * nty > 256 && (p.ldc & 3) == 0 && (p.N & 3) == 0 &&
-                         aligned16(p.C) && (!p.mask || ((p.ldmask & 3) == 0 && (reinterpret_cast<uintptr_t>(p.mask) & 3) == 0));
-    if (persist) {
-        const size_t ldsp = 2 * PP_OPERAND_B;
-        const dim3 gp(256);
-        if (!p.transA && !p.transB) hipLaunchKernelGGL((gemm_pipe_persist_kernel<false, false>), gp, dim3(256), ldsp, s, p, ws);
-        else if (!p.transA && p.transB) hipLaunchKernelGGL((gemm_pipe_persist_kernel<false, true>), gp, dim3(256), ldsp, s, p, ws);
-        else if (p.transA && !p.transB) hipLaunchKernelGGL((gemm_pipe_persist_kernel<true, false>), gp, dim3(256), ldsp, s, p, ws);
-        else hipLaunchKernelGGL((gemm_pipe_persist_kernel<true, true>), gp, dim3(256), ldsp, s, p, ws);
-    } else if (pipe >= 0) {
+    if (pipe >= 0) {
         const size_t ldsp = 2 * PP_OPERAND_B;
         if (pipe == 1) hipLaunchKernelGGL((gemm_pipe_kernel<false, false, 1>), grid, dim3(256), ldsp, s, p, ws);
         else if (pipe == 2) hipLaunchKernelGGL((gemm_pipe_kernel<false, true, 2>), grid, dim3(256), ldsp, s, p, ws);

@@ -106,7 +106,11 @@ __global__ __launch_bounds__(LT) void adam_norm_kernel(AdamArgs p) {
     if (threadIdx.x == 0) {
         const float norm = sqrtf(s);
         p.norm_out[0] = norm;
-        p.norm_out[1] = p.max_norm > 0.f ? fminf(1.f, p.max_norm / (norm + 1e-6f)) : 1.f;     // clip coefficient (torch semantics)
+        float coef = p.max_norm > 0.f ? fminf(1.f, p.max_norm / (norm + 1e-6f)) : 1.f;      // clip coefficient (torch semantics)
+        // guarded step: an invalid decode (persistent kernel gave up: error word set, NaN sentinels in its outputs) or a non-finite
+        // gradient must not reach the weights - the update kernels return at once on a negative coefficient
+        if (p.guard && (p.guard[1] != 0 || !(fabsf(norm) <= 3.0e38f))) coef = -1.f;
+        p.norm_out[1] = coef;
     }
 }
 
@@ -120,6 +124,7 @@ __global__ __launch_bounds__(LT) void adam_apply_kernel(AdamArgs p) {
     float* v = (float*)p.ptrs[4 * t + 3] + off;
     const int n = p.chunk_len[c];
     const float coef = p.norm_out[1];
+    if (coef < 0.f) return;                                   // guarded step skipped (adam_norm_kernel)
     for (int i = threadIdx.x; i < n; i += LT) {
         const float wi = w[i];
         const float gc = g[i] * coef;

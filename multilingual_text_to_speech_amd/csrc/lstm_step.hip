@@ -33,8 +33,7 @@ constexpr int LS_MIN_KS = 8;
 // nb_max = 4 selects the two-workgroups-per-CU instantiation (training: the step kernels then share CUs with the helper streams'
 // GEMM workgroups instead of waiting for them; 95.7 vs 97.5 ms per train step) at the price of more partial slabs.
 static inline int ls_ksplit(int nkb, int nb_max = 0) {
-    static const int nb_env = [] { const char* e = getenv("MTTS_LS_NB"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= LS_MAXKB) ? v : 0; }();
-    int nb = nb_env ? nb_env : (nb_max >= 1 && nb_max <= LS_MAXKB ? nb_max : LS_MAXKB);
+    const int nb = nb_max >= 1 && nb_max <= LS_MAXKB ? nb_max : LS_MAXKB;
     const int need = (nkb + nb - 1) / nb;
     return need > LS_MIN_KS ? need : LS_MIN_KS;
 }
@@ -67,12 +66,10 @@ struct LsPack {
     const float* w0; const float* w1; const float* w2;
     int K0, K1, K2, ld0, ld1, ld2;
     int H, nkb, precision;
-    int plain_rows;       // > 0: identity row order (row = 128 j + 16 w + i, zero beyond plain_rows) instead of the LSTM unit-major order
     void* dst;
 };
 
 __device__ __forceinline__ float ls_pack_src(const LsPack& p, int row, int k) {
-    if (p.plain_rows > 0 && row >= p.plain_rows) return 0.f;
     if (k < p.K0) return p.w0[(long)row * p.ld0 + k];
     k -= p.K0;
     if (k < p.K1) return p.w1[(long)row * p.ld1 + k];
@@ -81,7 +78,7 @@ __device__ __forceinline__ float ls_pack_src(const LsPack& p, int row, int k) {
 }
 
 __global__ void lstm_pack_kernel(LsPack p) {
-    const long rows = p.plain_rows > 0 ? (long)((p.plain_rows + LS_COLS - 1) / LS_COLS) * LS_COLS : (long)4 * p.H;
+    const long rows = (long)4 * p.H;
     const long total = rows * p.nkb * 32;
     const long n = p.precision ? total / 8 : total / 4;          // one lane-quantum (16 B) per thread
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
@@ -91,7 +88,7 @@ __global__ void lstm_pack_kernel(LsPack p) {
         const int kb = (int)(rest % p.nkb); const long jw = rest / p.nkb;
         const int w = (int)(jw & 7), j = (int)(jw >> 3);
         const int i = lane & 15, q = lane >> 4;
-        const int row = p.plain_rows > 0 ? 128 * j + 16 * w + i : (i & 3) * p.H + 32 * j + 4 * w + (i >> 2);
+        const int row = (i & 3) * p.H + 32 * j + 4 * w + (i >> 2);
         const int k = 32 * kb + 8 * q + 4 * h;
         if (p.precision) {
             unsigned o[4];
@@ -254,16 +251,6 @@ __global__ __launch_bounds__(LS_THREADS, (NB <= 4 ? 4 : 2)) void lstm_gates_kern
     lstm_gates_body<PREC, NB>(p, blockIdx.x, sm);
 }
 
-// Two independent gate GEMMs in ONE launch (attention LSTM of step t and generator LSTM of step t - chunk): the decoder's step
-// kernels fill the chip and serialise anyway, so a second launch only adds its ramp and drain (~3-4 us).  Workgroups [0, na)
-// belong to problem a.  (Both argument blocks are read through direct scalar loads: no address select on the kernel argument.)
-template <int PREC, int NB>
-__global__ __launch_bounds__(LS_THREADS) void lstm_gates2_kernel(LsGates a, LsGates b, int na) {
-    extern __shared__ __attribute__((aligned(16))) char sm[];
-    if ((int)blockIdx.x < na) lstm_gates_body<PREC, NB>(a, blockIdx.x, sm);
-    else lstm_gates_body<PREC, NB>(b, blockIdx.x - na, sm);
-}
-
 // ---------------------------------------------------------------------------------------------------------------------------
 // C: partial sum + LSTM cell + query partials.  Workgroup = 16 units x 16 rows, thread = one (row, unit).
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -361,12 +348,6 @@ __device__ __forceinline__ void lstm_cell_q_body(const LsCell& p, float (&hs)[16
 __global__ __launch_bounds__(256) void lstm_cell_q_kernel(LsCell p) {
     __shared__ float hs[16][17];
     lstm_cell_q_body(p, hs);
-}
-
-__global__ __launch_bounds__(256) void lstm_cell_q2_kernel(LsCell a, LsCell b) {      // blockIdx.z selects the problem
-    __shared__ float hs[16][17];
-    if (blockIdx.z == 0) lstm_cell_q_body(a, hs);
-    else lstm_cell_q_body(b, hs);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -526,18 +507,11 @@ MTTS_API long mtts_lstm_packed_weight_bytes(int H, int k_total, int precision) {
     return (long)4 * H * k_total * (precision ? 2 : 4);
 }
 
-// plain (non-LSTM) use of the K-split kernel: Y[B, N] partials = X[B, K] W[N, K]^T, N padded to 128-column tiles
-MTTS_API long mtts_ksplit_packed_weight_bytes(int N, int k_total, int precision) {
-    return (long)((N + LS_COLS - 1) / LS_COLS) * LS_COLS * k_total * (precision ? 2 : 4);
-}
-MTTS_API long mtts_ksplit_partial_floats(int B, int N, int k_total) { return (long)mtts_lstm_step_ksplit(k_total) * B * N; }
-
 MTTS_API int mtts_lstm_pack_weights(const LstmPackArgs* args, void* stream) {
     const LstmPackArgs& a = *args;
     MTTS_TRY(ls_check_segs(a.nseg, a.K, a.ldw, "mtts_lstm_pack_weights"));
-    MTTS_REQUIRE(a.plain_rows > 0 || (a.H > 0 && (a.H & 31) == 0), "mtts_lstm_pack_weights: H must be a multiple of 32 (H=%d)", a.H);
+    MTTS_REQUIRE(a.H > 0 && (a.H & 31) == 0, "mtts_lstm_pack_weights: H must be a multiple of 32 (H=%d)", a.H);
     LsPack p; memset(&p, 0, sizeof(p));
-    p.plain_rows = a.plain_rows;
     p.w0 = a.w[0]; p.K0 = a.K[0]; p.ld0 = a.ldw[0];
     p.w1 = a.nseg > 1 ? a.w[1] : a.w[0]; p.K1 = a.nseg > 1 ? a.K[1] : 0; p.ld1 = a.nseg > 1 ? a.ldw[1] : 0;
     p.w2 = a.nseg > 2 ? a.w[2] : a.w[0]; p.K2 = a.nseg > 2 ? a.K[2] : 0; p.ld2 = a.nseg > 2 ? a.ldw[2] : 0;
@@ -589,7 +563,6 @@ static int ls_set_attrs() {
     if (!attr_done) {
         MTTS_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_gates_kernel<0, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 7 * LS_PLANE_B));
         MTTS_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_gates_kernel<0, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 10 * LS_PLANE_B));
-        MTTS_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_gates2_kernel<0, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 7 * LS_PLANE_B));
         attr_done = true;
     }
     return 0;
@@ -611,50 +584,6 @@ int lstm_step_launch(const LstmStepArgs& a, hipStream_t s) {
     MTTS_CHECK_LAUNCH("lstm_gates_kernel");
     hipLaunchKernelGGL(lstm_cell_q_kernel, dim3(a.H / 16, (a.B + 15) / 16), dim3(256), 0, s, c);
     MTTS_CHECK_LAUNCH("lstm_cell_q_kernel");
-    return 0;
-}
-
-// G alone: partial slabs part[ks][B][N] of X[B, K] W[N, K]^T for a weight packed with plain_rows = N (K % 32 == 0); returns the
-// number of slabs through *ks_out.  Used by the decoder backward for dG x [W_ih[:, P:] | W_hh] (input gradient of the attention LSTM).
-int ksplit_gemm_launch(const float* x, int K, int ldx, const void* wp, int B, int N, float* part, int precision, int ks_want, int* ks_out,
-                       hipStream_t s) {
-    MTTS_REQUIRE(K > 0 && (K & 31) == 0 && (ldx & 3) == 0 && ((uintptr_t)x & 15) == 0, "ksplit_gemm: K %% 32 == 0, ldx %% 4 == 0, aligned x");
-    LsGates g; memset(&g, 0, sizeof(g));
-    g.x0 = g.x1 = g.x2 = x; g.K0 = K; g.ld0 = g.ld1 = g.ld2 = ldx;
-    g.wp = wp; g.nkb = K / 32; g.KS = ls_ksplit(g.nkb); g.B = B; g.N = N; g.part = part;
-    if (ks_want > g.KS) g.KS = ks_want;                 // more, shorter slices: fill the chip when N gives few column tiles
-    g.nbmax = (g.nkb + g.KS - 1) / g.KS;
-    MTTS_TRY(ls_set_attrs());
-    const dim3 grid(((N + LS_COLS - 1) / LS_COLS) * g.KS), blk(LS_THREADS);
-#define LS_LAUNCH(PREC, NB) hipLaunchKernelGGL((lstm_gates_kernel<PREC, NB>), grid, blk, (size_t)(PREC ? 1 : 3) * NB * LS_PLANE_B, s, g)
-    if (precision) {
-        if (g.nbmax <= 4) LS_LAUNCH(1, 4); else if (g.nbmax <= 7) LS_LAUNCH(1, 7); else LS_LAUNCH(1, 10);
-    } else {
-        if (g.nbmax <= 4) LS_LAUNCH(0, 4); else if (g.nbmax <= 7) LS_LAUNCH(0, 7); else LS_LAUNCH(0, 10);
-    }
-#undef LS_LAUNCH
-    MTTS_CHECK_LAUNCH("lstm_gates_kernel");
-    if (ks_out) *ks_out = g.KS;
-    return 0;
-}
-
-// Two LSTM steps (same B, H, precision; both K-slices <= 7 blocks) as ONE gate launch + ONE cell launch.
-int lstm_step2_launch(const LstmStepArgs& a, const LstmStepArgs& b, hipStream_t s) {
-    LsGates ga, gb; LsCell ca, cb;
-    MTTS_TRY(ls_marshal(a, ga, ca));
-    MTTS_TRY(ls_marshal(b, gb, cb));
-    if (a.B != b.B || a.H != b.H || a.precision != b.precision || ga.nbmax > 7 || gb.nbmax > 7) {
-        MTTS_TRY(lstm_step_launch(a, s));
-        return lstm_step_launch(b, s);
-    }
-    MTTS_TRY(ls_set_attrs());
-    const int ntile = (4 * a.H) / LS_COLS;
-    const int na = ntile * ga.KS, nb = ntile * gb.KS;
-    if (a.precision) hipLaunchKernelGGL((lstm_gates2_kernel<1, 7>), dim3(na + nb), dim3(LS_THREADS), (size_t)7 * LS_PLANE_B, s, ga, gb, na);
-    else hipLaunchKernelGGL((lstm_gates2_kernel<0, 7>), dim3(na + nb), dim3(LS_THREADS), (size_t)3 * 7 * LS_PLANE_B, s, ga, gb, na);
-    MTTS_CHECK_LAUNCH("lstm_gates2_kernel");
-    hipLaunchKernelGGL(lstm_cell_q2_kernel, dim3(a.H / 16, (a.B + 15) / 16, 2), dim3(256), 0, s, ca, cb);
-    MTTS_CHECK_LAUNCH("lstm_cell_q2_kernel");
     return 0;
 }
 

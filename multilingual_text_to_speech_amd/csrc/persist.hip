@@ -10,12 +10,11 @@
 // scripts/mb/mb_bcast.hip).
 //
 // Kernels
-//   pgen_kernel  generator LSTM of the teacher-forced schedule (reference modules/tacotron2.py:187-188 with the input projection
-//                hoisted into one GEMM): per step  gates = pre_gen[t] + h_gen[t] W_hh^T -> cell -> h_gen[t+1]; 1 barrier per step
-//                (bf16 mode, MTTS_PGEN=1).
-//   pgen7_kernel the same recurrence as a DATAFLOW pipeline (fp32 default): multiplier waves with register-stationary weight planes, one
-//                service wave per 16-row group, no workgroup barrier in the loop; fp32 exchange.  pgen4_kernel = the same with a
-//                bf16-plane exchange (MTTS_PGEN=2; the harness checks that both return the same bits).
+//   pgen7_kernel generator LSTM of the teacher-forced schedule (reference modules/tacotron2.py:187-188 with the input projection
+//                hoisted into one GEMM): per step  gates = pre_gen[t] + h_gen[t] W_hh^T -> cell -> h_gen[t+1], as a DATAFLOW pipeline
+//                (fp32): multiplier waves with register-stationary weight planes, one service wave per 16-row group, no workgroup
+//                barrier in the loop; fp32 exchange.
+//   pgen_kernel  the same recurrence with one grid barrier per step and bf16 weights in LDS: the bf16 path (precision 1).
 //   pdec_kernel  attention LSTM + location-sensitive attention (reference modules/tacotron2.py:184-186, modules/attention.py:39-86,
 //                modules/layers.py:18-47): per step
 //                  phase 1 (column role: workgroup c owns LSTM units [4c, 4c+4)):  gates = pre_att[t] + [ctx_t | h_t] W^T -> cell
@@ -409,26 +408,6 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 // ---------------------------------------------------------------------------------------------------------------------------
 struct PsBar2 { unsigned* cnt; unsigned* err; };      // cnt[(g * 8 + x) * 32]: counter x of row group g
 
-__device__ __forceinline__ void ps_arrive(const PsBar2& b, int g) {      // one lane; the wave has drained its stores
-    __hip_atomic_fetch_add(b.cnt + (g * 8 + (blockIdx.x & 7)) * 32, 1u, PS_RLX, PS_AGENT);
-}
-__device__ __forceinline__ unsigned ps_sample(const PsBar2& b, int g) {   // lanes 0-7: one counter each; other lanes: "reached"
-    const int lane = threadIdx.x & 63;
-    return lane < 8 ? __hip_atomic_load(b.cnt + (g * 8 + lane) * 32, PS_RLX, PS_AGENT) : 0xffffffffu;
-}
-// wave-wide wait; returns false on timeout / foreign error
-__device__ __forceinline__ bool ps_wait(const PsBar2& b, int g, unsigned target) {
-    unsigned spins = 0;
-    for (;;) {
-        if (__all(ps_sample(b, g) >= target)) return true;
-        __builtin_amdgcn_s_sleep(1);
-        if ((++spins & 1023u) == 0 && (spins > PS_SPIN_MAX || __hip_atomic_load(b.err, PS_RLX, PS_AGENT) != 0)) {
-            if ((threadIdx.x & 63) == 0) __hip_atomic_store(b.err, 2u, PS_RLX, PS_AGENT);
-            return false;
-        }
-    }
-}
-
 #ifdef PS_PROF
 #define PS_PROF_WORDS (2 * PS_PROF)
 #else
@@ -443,239 +422,19 @@ __device__ unsigned long long* g_ps_prof_dev = nullptr;
 #define PS_STAMP(buf, slot, who) do { } while (0)
 #endif
 
-// Exchange layout of the pipelined kernels ("XQ"): the producer splits its fp32 values ONCE into the three bf16 planes and every
-// consumer loads finished MFMA A-fragments (no per-consumer split arithmetic: 256 workgroups read what one wrote).  One 16-row
-// region: [k-block][plane][64 lanes][8 bf16], lane = 16 q4 + i16 holds row i16, k = 32 kb + 8 q4 .. + 7:
-//   byte offset = ((kb * 3 + pl) * 64 + q4 * 16 + i16) * 16 + (k & 4) * 2       for the four bf16 of k .. k+3 (k % 4 == 0)
-template <int NBW> struct PsLoads { u32x4 x[NBW][3]; };
-
-__device__ __forceinline__ unsigned ps_xq_off(int i16, int k, int pl) {
-    const int kb = k >> 5, j = k & 31, q4 = j >> 3;
-    return (unsigned)(((kb * 3 + pl) * 64 + q4 * 16 + i16) * 16 + (j & 4) * 2);
-}
-// publish four consecutive columns k .. k+3 of row i16 (three 8-byte write-through stores)
-__device__ __forceinline__ void ps_xq_store4(__amdgpu_buffer_rsrc_t r, int i16, int k, float4 v) {
-    unsigned a[3], b[3];
-    ps_split_pair(v.x, v.y, a[0], a[1], a[2]);
-    ps_split_pair(v.z, v.w, b[0], b[1], b[2]);
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
-        typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-        u32x2 w; w.x = a[pl]; w.y = b[pl];
-        __builtin_amdgcn_raw_buffer_store_b64(w, r, ps_xq_off(i16, k, pl), 0, 16);
-    }
-}
-
-// one k-block of the next group-step's fragments (blocks past k1 read out of range = 0)
-template <int NBW>
-__device__ __forceinline__ void ps_issue_block(PsLoads<NBW>& ld, int j, __amdgpu_buffer_rsrc_t xr, int k0, int k1, int lane) {
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
-        ld.x[j][pl] = __builtin_amdgcn_raw_buffer_load_b128(xr, (k0 + j < k1) ? (unsigned)((((k0 + j) * 3 + pl) * 1024) + lane * 16) : 0xfffffff0u, 0, 16);
-}
-template <int NBW>
-__device__ __forceinline__ void ps_issue16(PsLoads<NBW>& ld, __amdgpu_buffer_rsrc_t xr, int k0, int k1, int lane) {
-#pragma unroll
-    for (int j = 0; j < NBW; ++j) ps_issue_block<NBW>(ld, j, xr, k0, k1, lane);
-}
-
 // ---------------------------------------------------------------------------------------------------------------------------
-// pgen4: dataflow form of the pipelined recurrence.  Workgroup = 8 MULTIPLIER waves + one SERVICE wave per 16-row group (12 waves):
+// pgen7: DATAFLOW form of the generator recurrence.  Workgroup = 8 MULTIPLIER waves + one SERVICE wave per 16-row group (12 waves):
 //   multiplier wave w  owns the k-blocks [nkb w / 8, nkb (w + 1) / 8) for good: its weight planes (bf16 x 3) live in its REGISTERS for
-//                      the whole decode (no LDS or global weight traffic per step at all); per group-step it multiplies the prefetched
-//                      fragments, refills each fragment register with the next group-step's data the moment its MFMAs are issued,
-//                      leaves its partial sums in LDS and bumps the group's `done` counter (LDS atomic);
-//   service wave g     waits for done[g] (LDS), runs the LSTM cell of its 16 rows x 4 units, publishes h (XQ planes, write-through),
+//                      the whole decode (no LDS or global weight traffic per step at all); per group-step it splits and multiplies the
+//                      prefetched fp32 fragments, refills each fragment register with the next group-step's data the moment its MFMAs
+//                      are issued, leaves its partial sums in LDS and bumps the group's `done` counter (LDS atomic);
+//   service wave g     waits for done[g] (LDS), runs the LSTM cell of its 16 rows x 4 units, publishes h (fp32 XP quanta, write-through),
 //                      drains, arrives at the group's grid counters, polls them and posts `seen[g]` (LDS) when the publish has landed
 //                      from every workgroup - the multipliers only ever look at LDS.
 // No s_barrier after start-up: every wait is a data-flow condition, so the grid-barrier latency of one row group is covered by the
-// other groups' arithmetic.
+// other groups' arithmetic.  (scripts/mb/pgen4_variant.inc: the same kernel with a bf16-plane exchange, for bit-equality checks.)
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int PS4_THREADS = 768;
-
-template <int NG>
-__global__ __launch_bounds__(PS4_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void pgen4_kernel(PsGen p) {
-    extern __shared__ __attribute__((aligned(16))) char psm[];
-    constexpr int NBW = 4;                                    // k-blocks per multiplier wave (nkb = 32)
-    const int tid = threadIdx.x, lane = tid & 63, c = blockIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int H = p.H, B = p.B, nkb = H >> 5, N = 4 * H;
-    float* red = reinterpret_cast<float*>(psm);                                        // [NG][8][16][16]
-    volatile unsigned* done = reinterpret_cast<volatile unsigned*>(red + NG * 8 * 256);   // [4]  multiplier waves finished, per group (monotonic)
-    volatile unsigned* seen = done + 4;                                                // [4]  publish number that has landed, per group
-    volatile unsigned* lerr = done + 8;
-#ifdef PS_PROF
-    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(const_cast<unsigned*>(done) + 16);
-#endif
-    const PsBar2 bar{p.sync.cnt, p.sync.err};
-    if (tid < 12) done[tid] = 0;
-    __syncthreads();
-    const unsigned per_pub = PS_WGS / 8;
-    const int n_steps = p.t1 - p.t0, n_gs = n_steps * NG;
-    const unsigned xg_bytes = (unsigned)(nkb * 3072);
-    auto xregion = [&](int g, int par) { return ps_rsrc(reinterpret_cast<char*>(p.xp) + (size_t)(g * 2 + par) * xg_bytes, xg_bytes); };
-
-    if (wave >= 8) {
-        // =========================== service wave of row group g ===========================
-        const int g = wave - 8;
-        if (g >= NG) return;
-        const int rl = lane >> 2, uu = lane & 3, u = 4 * c + uu, row = 16 * g + rl;
-        const bool valid = row < B;
-        const int rowc = valid ? row : 0;
-        const float4 bias4 = *reinterpret_cast<const float4*>(p.bias_u + 4 * u);
-        float c_state = valid ? p.c[((size_t)p.t0 * B + row) * H + u] : 0.f;
-        float h_state = valid ? p.h[((size_t)p.t0 * B + row) * H + u] : 0.f;
-        // Two-level arrive (as ps_barrier): the counters that take 32 atomics per publish are polled by nobody; the polled word
-        // (top counter of the group) takes 8.  sub[g][x] = cnt[(g * 9 + 1 + x) * 32], top[g] = cnt[g * 9 * 32].
-        unsigned* top = bar.cnt + (g * 9) * 32;
-        unsigned* sub = bar.cnt + (g * 9 + 1 + (blockIdx.x & 7)) * 32;
-        auto arrive = [&](unsigned pub) {
-            if (lane == 0) {
-                const unsigned prev = __hip_atomic_fetch_add(sub, 1u, PS_RLX, PS_AGENT);
-                if (prev + 1 == pub * per_pub) __hip_atomic_fetch_add(top, 1u, PS_RLX, PS_AGENT);
-            }
-        };
-        auto land = [&](unsigned pub) -> bool {      // wait until publish `pub` of this group has arrived everywhere, then tell the multipliers
-            unsigned spins = 0;
-            while (__hip_atomic_load(top, PS_RLX, PS_AGENT) < pub * 8u) {
-                __builtin_amdgcn_s_sleep(1);
-                if ((++spins & 1023u) == 0 && (spins > PS_SPIN_MAX || __hip_atomic_load(bar.err, PS_RLX, PS_AGENT) != 0)) {
-                    if (lane == 0) { __hip_atomic_store(bar.err, 2u, PS_RLX, PS_AGENT); *lerr = 1; }
-                    return false;
-                }
-            }
-            if (lane == 0) seen[g] = pub;
-            return true;
-        };
-        {
-            const float4 h4 = ps_quad_gather(h_state);
-            if (valid && uu == 0) ps_xq_store4(xregion(g, p.t0 & 1), rl, 4 * c, h4);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            arrive(1u);
-            if (!land(1u)) return;
-        }
-        for (int s = 0; s < n_steps; ++s) {
-            const int t = p.t0 + s;
-            const float4 pre4 = *reinterpret_cast<const float4*>(p.pre + ((size_t)t * B + rowc) * N + 4 * u);
-            const size_t mo = ((size_t)t * B + rowc) * H + u;
-            const unsigned hm = p.hmask ? (unsigned)p.hmask[mo] : 1u, cm = p.cmask ? (unsigned)p.cmask[mo] : 1u;
-            {   // the eight partial sums of this group-step are in LDS
-                unsigned spins = 0;
-                while (done[g] < 8u * (unsigned)(s + 1)) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (*lerr != 0 || ++spins > (PS_SPIN_MAX << 2)) { if (lane == 0) { *lerr = 1; __hip_atomic_store(bar.err, 2u, PS_RLX, PS_AGENT); } return; }
-                }
-            }
-            PS_STAMP(stamps, 512 + 4 * s + 0, g == 0 && lane == 0);
-            const float* redg = red + g * (8 * 256);
-            float4 g4 = bias4;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) {
-                const float4 v = *reinterpret_cast<const float4*>(redg + w * 256 + rl * 16 + 4 * uu);
-                g4.x += v.x; g4.y += v.y; g4.z += v.z; g4.w += v.w;
-            }
-            g4.x += pre4.x; g4.y += pre4.y; g4.z += pre4.z; g4.w += pre4.w;
-            const float ig = sigmoidf_(g4.x), fg = sigmoidf_(g4.y), gg = tanhf_(g4.z), og = sigmoidf_(g4.w);
-            const float cp = c_state, hp = h_state;
-            const float cn = fg * cp + ig * gg;
-            const float hn = og * tanhf_(cn);
-            float ho, co = cn;
-            if (p.cell.zone == 1) { ho = hm ? hn : hp; co = cm ? cn : cp; }
-            else if (p.cell.zone == 2) { ho = p.cell.zh * hp + (1.f - p.cell.zh) * hn; co = p.cell.zc * cp + (1.f - p.cell.zc) * cn; }
-            else ho = p.hmask ? (hm ? hn * p.cell.hscale : 0.f) : hn;
-            c_state = co; h_state = ho;
-            const float4 h4 = ps_quad_gather(h_state);
-            if (valid && uu == 0) ps_xq_store4(xregion(g, (t + 1) & 1), rl, 4 * c, h4);
-            PS_STAMP(stamps, 512 + 4 * s + 1, g == 0 && lane == 0);
-            if (s + 1 < n_steps) {      // exchange first: drain the write-through stores, arrive; the saved state follows
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                arrive((unsigned)(s + 2));
-            }
-            PS_STAMP(stamps, 512 + 4 * s + 2, g == 0 && lane == 0);
-            if (valid) {
-                const size_t o = ((size_t)(t + 1) * B + row) * H + u;
-                if (uu == 0) *reinterpret_cast<float4*>(p.h + o) = h4;
-                p.c[o] = c_state;
-                if (p.gates) {
-                    float* go = p.gates + ((size_t)t * B + row) * N + u;
-                    go[0] = ig; go[H] = fg; go[2 * H] = gg; go[3 * H] = og;
-                }
-            }
-            if (s + 1 < n_steps && !land((unsigned)(s + 2))) return;
-            PS_STAMP(stamps, 512 + 4 * s + 3, g == 0 && lane == 0);
-        }
-#ifdef PS_PROF
-        if (p.prof && blockIdx.x == 0 && g == 0) for (int i = 512 + lane; i < PS_PROF; i += 64) p.prof[i] = stamps[i];
-#endif
-        return;
-    }
-
-    // =========================== multiplier wave ===========================
-    const int k0 = (nkb * wave) >> 3, k1 = (nkb * (wave + 1)) >> 3;
-    PsFrag wreg[NBW][3];
-    {
-        const float4* src = reinterpret_cast<const float4*>(p.w_packed) + (size_t)c * nkb * 128;
-#pragma unroll
-        for (int j = 0; j < NBW; ++j) {
-            const int kb = min(k0 + j, nkb - 1);
-            const PsFrag3 f = ps_split8(src[(kb * 2 + 0) * 64 + lane], src[(kb * 2 + 1) * 64 + lane]);
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) wreg[j][pl] = f.p[pl];
-        }
-    }
-    auto wait_seen = [&](int g, unsigned pub) -> bool {
-        unsigned spins = 0;
-        while (seen[g] < pub) {
-            __builtin_amdgcn_s_sleep(1);
-            if (*lerr != 0 || ++spins > (PS_SPIN_MAX << 2)) { *lerr = 1; return false; }
-        }
-        return true;
-    };
-    PsLoads<NBW> buf;
-    if (n_gs > 0) {
-        if (!wait_seen(0, 1u)) return;
-        ps_issue16<NBW>(buf, xregion(0, p.t0 & 1), k0, k1, lane);
-    }
-    const int i16 = lane & 15, q4 = lane >> 4;
-    for (int i = 0; i < n_gs; ++i) {
-        const int g = i % NG, in = i + 1, gn = in % NG, tn = p.t0 + in / NG;
-        const bool has_next = in < n_gs;
-        const unsigned pubn = (unsigned)(in / NG + 1);
-        const bool early = has_next && seen[gn] >= pubn;
-        const __amdgpu_buffer_rsrc_t nxr = xregion(gn, tn & 1);
-        PS_STAMP(stamps, 2 * i, tid == 64 * 5);
-        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < NBW; ++j) {
-            PsFrag a[3];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) { a[pl].u[0] = buf.x[j][pl].x; a[pl].u[1] = buf.x[j][pl].y; a[pl].u[2] = buf.x[j][pl].z; a[pl].u[3] = buf.x[j][pl].w; }
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2].v, wreg[j][0].v, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0].v, wreg[j][2].v, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1].v, wreg[j][1].v, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1].v, wreg[j][0].v, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0].v, wreg[j][1].v, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0].v, wreg[j][0].v, acc1, 0, 0, 0);
-            if (early) ps_issue_block<NBW>(buf, j, nxr, k0, k1, lane);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        float* rw = red + (g * 8 + wave) * 256;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rw[(4 * q4 + r) * 16 + i16] = acc0[r] + acc1[r];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(const_cast<unsigned*>(done) + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        PS_STAMP(stamps, 2 * i + 1, tid == 64 * 5);
-        if (has_next && !early) {
-            if (!wait_seen(gn, pubn)) return;
-            ps_issue16<NBW>(buf, nxr, k0, k1, lane);
-        }
-    }
-#ifdef PS_PROF
-    if (p.prof && blockIdx.x == 0 && wave == 5) for (int i = lane; i < 512; i += 64) p.prof[i] = stamps[i];
-#endif
-}
-
-
 
 template <int NG>
 __global__ __launch_bounds__(PS4_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void pgen7_kernel(PsGen p) {
@@ -1209,14 +968,74 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 // ---------------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------------
-static bool ps_device_ok() {
-    static int cus = [] {
+#include <mutex>
+#include <map>
+
+// Per-device state of the persistent launches.  A persistent kernel needs ALL its 256 workgroups resident at once (they spin on each
+// other); that is (a) checked per device and per kernel instance with the occupancy query (CU count, LDS and register budget of THIS
+// device - a CU-masked or partitioned GPU fails it and the per-step launch schedule runs instead), and (b) protected inside one process
+// by serialising persistent launches across streams: a launch on stream s first waits for the previous persistent launch of the device
+// if that one went to ANOTHER stream (two half-resident grids would starve each other until the bounded spins give up).  Other
+// processes on the same GPU cannot be seen from here: share a GPU between processes with MTTS_PERSIST=0.
+namespace {
+struct PsDevice {
+    std::mutex mu;
+    int cus = -1;                                   // multiProcessorCount, -1 = not queried yet
+    std::map<const void*, int> ready;               // kernel -> 1 ok / 0 does not fit (attribute set + occupancy checked)
+    hipEvent_t last_ev = nullptr; hipStream_t last_stream = nullptr; bool have_last = false;
+    std::map<const void*, unsigned*> err_of;        // workspace -> error word its kernels report to
+};
+PsDevice g_ps_dev[64];
+PsDevice& ps_dev() { int d = 0; (void)hipGetDevice(&d); return g_ps_dev[d & 63]; }
+
+bool ps_device_ok() {
+    PsDevice& D = ps_dev();
+    std::lock_guard<std::mutex> lk(D.mu);
+    if (D.cus < 0) {
         int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-        return prop.multiProcessorCount;
-    }();
-    return cus >= PS_WGS;
+        D.cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
+    }
+    return D.cus >= PS_WGS;
 }
+
+// dynamic-LDS attribute + co-residency of PS_WGS workgroups of `fn` on the current device, cached per (device, kernel)
+bool ps_kernel_ready(const void* fn, int threads, size_t lds) {
+    PsDevice& D = ps_dev();
+    std::lock_guard<std::mutex> lk(D.mu);
+    auto it = D.ready.find(fn);
+    if (it != D.ready.end()) return it->second != 0;
+    int ok = 0, per_cu = 0;
+    if (D.cus >= PS_WGS && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) == hipSuccess && (long)per_cu * D.cus >= PS_WGS)
+        ok = 1;
+    (void)hipGetLastError();
+    D.ready[fn] = ok;
+    return ok != 0;
+}
+
+// order this persistent launch behind the device's previous one when that went to another stream; call ps_launched() after the launch
+int ps_serialize(hipStream_t s) {
+    PsDevice& D = ps_dev();
+    std::lock_guard<std::mutex> lk(D.mu);
+    if (D.have_last && D.last_stream != s) MTTS_CHECK_HIP(hipStreamWaitEvent(s, D.last_ev, 0));
+    return 0;
+}
+int ps_launched(hipStream_t s) {
+    PsDevice& D = ps_dev();
+    std::lock_guard<std::mutex> lk(D.mu);
+    if (!D.last_ev) MTTS_CHECK_HIP(hipEventCreateWithFlags(&D.last_ev, hipEventDisableTiming));
+    MTTS_CHECK_HIP(hipEventRecord(D.last_ev, s));
+    D.last_stream = s; D.have_last = true;
+    return 0;
+}
+unsigned* ps_err_word(const DecoderArgs& a) {
+    unsigned* e = a.persist_err ? (unsigned*)a.persist_err : (unsigned*)((char*)a.persist_ws + PS_ERR_OFF);
+    PsDevice& D = ps_dev();
+    std::lock_guard<std::mutex> lk(D.mu);
+    D.err_of[a.persist_ws] = e;
+    return e;
+}
+}  // namespace
 
 // MTTS_PERSIST=0 switches the persistent recurrences off (the per-step launch schedule then runs everywhere)
 bool persist_enabled() {
@@ -1235,14 +1054,47 @@ MTTS_API long mtts_decoder_persist_ws_bytes(int B, int L, int H, int Dm, int A) 
     return ps_ws_eg_off(H, Dm) + 64L * 4 * PD_LMAX * 8 + 1024;
 }
 
-bool pgen_supported(const DecoderArgs& a) {
-    return persist_enabled() && a.fast && (a.precision == 0 || a.precision == 1) && a.H == 4 * PS_WGS && a.B >= 1 && a.B <= 64 && a.persist_ws &&
-           a.gen_w2p && a.gen_bias_u && a.pre_gen && a.persist_ws_bytes >= mtts_decoder_persist_ws_bytes(a.B, a.L, a.H, a.Dm, a.A);
-}
-
 unsigned long long* g_ps_prof = nullptr;      // timeline buffer of the micro-benchmark harness (NULL in the library)
-bool g_pgen7_off = false;                     // harness switch: pgen4 (bit-equality check of the two forms)
 bool g_pdec_poll_off = false;                 // harness switch: barrier-only hand-off of h (bit-equality check of the two forms)
+
+// ---- generator LSTM: kernel instance for a shape (fp32: the dataflow kernel pgen7; bf16: one barrier per step, bf16 weights in LDS)
+namespace {
+struct PsInst { const void* fn; int threads; size_t lds; };
+PsInst pgen_instance(int B, int H, int precision) {
+    const int RT = (B + 15) / 16;
+    PsInst k{nullptr, 0, 0};
+    if (precision == 0) {
+        k.threads = PS4_THREADS; k.lds = (size_t)RT * 8 * 256 * 4 + 64 + PS_PROF_WORDS * 4;
+        k.fn = RT == 1 ? (const void*)pgen7_kernel<1> : RT == 2 ? (const void*)pgen7_kernel<2> : RT == 3 ? (const void*)pgen7_kernel<3> : (const void*)pgen7_kernel<4>;
+    } else {
+        k.threads = PS_THREADS; k.lds = (size_t)(H / 32) * 1024 + 8 * 64 * 16 * 4;
+        k.fn = RT == 1 ? (const void*)pgen_kernel<1, 1> : RT == 2 ? (const void*)pgen_kernel<2, 1> : RT == 3 ? (const void*)pgen_kernel<3, 1> : (const void*)pgen_kernel<4, 1>;
+    }
+    return k;
+}
+size_t pdec_lds(int H, int Dm, int precision) {
+    size_t lds = (size_t)((Dm + H) / 32) * (precision ? 1024 : 2048) + 8 * 64 * 16 * 4 + PD_LMAX * 32 * 4 + (PD_LMAX + 64) * 4 + 2 * 3 * 64 * 16 + 64 * 4;
+#ifdef PS_PROF
+    lds += 300 * 8;
+#endif
+    return lds;
+}
+PsInst pdec_instance(int B, int H, int Dm, int precision) {
+    const int RT = (B + 15) / 16;
+    PsInst k{nullptr, PS_THREADS, pdec_lds(H, Dm, precision)};
+    if (precision) k.fn = RT == 1 ? (const void*)pdec_kernel<1, 1> : RT == 2 ? (const void*)pdec_kernel<2, 1> : RT == 3 ? (const void*)pdec_kernel<3, 1> : (const void*)pdec_kernel<4, 1>;
+    else k.fn = RT == 1 ? (const void*)pdec_kernel<1, 0> : RT == 2 ? (const void*)pdec_kernel<2, 0> : RT == 3 ? (const void*)pdec_kernel<3, 0> : (const void*)pdec_kernel<4, 0>;
+    return k;
+}
+}  // namespace
+
+bool pgen_supported(const DecoderArgs& a) {
+    if (!(persist_enabled() && a.fast && (a.precision == 0 || a.precision == 1) && a.H == 4 * PS_WGS && a.B >= 1 && a.B <= 64 && a.persist_ws &&
+          a.gen_w2p && a.gen_bias_u && a.pre_gen && a.persist_ws_bytes >= mtts_decoder_persist_ws_bytes(a.B, a.L, a.H, a.Dm, a.A)))
+        return false;
+    const PsInst k = pgen_instance(a.B, a.H, a.precision);
+    return ps_kernel_ready(k.fn, k.threads, k.lds);
+}
 
 // generator LSTM steps [t0, t1) in one launch (h_gen[t0] / c_gen[t0] are the initial state)
 int pgen_launch(const DecoderArgs& a, int t0, int t1, hipStream_t s) {
@@ -1259,45 +1111,25 @@ int pgen_launch(const DecoderArgs& a, int t0, int t1, hipStream_t s) {
         p.hmask = a.gen_hmask; p.cell.hscale = 1.f / (1.f - a.p_hidden);
     }
     char* ws = (char*)a.persist_ws;
-    p.sync.cnt = (unsigned*)ws; p.sync.err = a.persist_err ? (unsigned*)a.persist_err : (unsigned*)(ws + PS_ERR_OFF);
+    p.sync.cnt = (unsigned*)ws; p.sync.err = ps_err_word(a);
     p.xp = (float*)(ws + ps_ws_gen_off());
     p.prof = g_ps_prof;
+    MTTS_TRY(ps_serialize(s));
     MTTS_CHECK_HIP(hipMemsetAsync(ws, 0, PS_ERR_OFF, s));           // counters (the error word is sticky until the host reads it)
+    const PsInst k = pgen_instance(a.B, a.H, a.precision);
     const int RT = (a.B + 15) / 16;
-    static const int variant = [] { const char* e = getenv("MTTS_PGEN"); return e ? atoi(e) : 3; }();      // 1: one barrier per step; 2: dataflow, bf16-plane exchange; 3: dataflow, fp32 exchange
-    if (variant != 1 && variant != 2 && a.precision == 0 && !g_pgen7_off) {      // dataflow pipeline with the fp32 exchange (MTTS_PGEN=2: bf16-plane exchange)
-        size_t lds4 = (size_t)RT * 8 * 256 * 4 + 64;
-#ifdef PS_PROF
-        lds4 += PS_PROF * 8;
-#endif
-#define PGEN7_GO(G) hipLaunchKernelGGL((pgen7_kernel<G>), dim3(PS_WGS), dim3(PS4_THREADS), lds4, s, p);
+    if (a.precision == 0) {
+#define PGEN7_GO(G) hipLaunchKernelGGL((pgen7_kernel<G>), dim3(PS_WGS), dim3(PS4_THREADS), k.lds, s, p);
         if (RT == 1) PGEN7_GO(1) else if (RT == 2) PGEN7_GO(2) else if (RT == 3) PGEN7_GO(3) else PGEN7_GO(4)
 #undef PGEN7_GO
         MTTS_CHECK_LAUNCH("pgen7_kernel");
-        return 0;
-    }
-    if (variant != 1 && a.precision == 0) {      // dataflow pipeline: 8 multiplier waves + one service wave per 16-row group
-        size_t lds4 = (size_t)RT * 8 * 256 * 4 + 64;
-#ifdef PS_PROF
-        lds4 += PS_PROF * 8;
-#endif
-#define PGEN4_GO(G) hipLaunchKernelGGL((pgen4_kernel<G>), dim3(PS_WGS), dim3(PS4_THREADS), lds4, s, p);
-        if (RT == 1) PGEN4_GO(1) else if (RT == 2) PGEN4_GO(2) else if (RT == 3) PGEN4_GO(3) else PGEN4_GO(4)
-#undef PGEN4_GO
-        MTTS_CHECK_LAUNCH("pgen4_kernel");
-        return 0;
-    }
-    const size_t lds = (size_t)(a.H / 32) * (a.precision ? 1024 : 2048) + 8 * 64 * 16 * 4;
-#define PGEN_GO(R, PR)                                                                                                      \
-    {                                                                                                                       \
-        MTTS_CHECK_HIP(hipFuncSetAttribute((const void*)pgen_kernel<R, PR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((pgen_kernel<R, PR>), dim3(PS_WGS), dim3(PS_THREADS), lds, s, p);                                \
-    }
-    if (a.precision) { if (RT == 1) PGEN_GO(1, 1) else if (RT == 2) PGEN_GO(2, 1) else if (RT == 3) PGEN_GO(3, 1) else PGEN_GO(4, 1) }
-    else { if (RT == 1) PGEN_GO(1, 0) else if (RT == 2) PGEN_GO(2, 0) else if (RT == 3) PGEN_GO(3, 0) else PGEN_GO(4, 0) }
+    } else {
+#define PGEN_GO(R) hipLaunchKernelGGL((pgen_kernel<R, 1>), dim3(PS_WGS), dim3(PS_THREADS), k.lds, s, p);
+        if (RT == 1) PGEN_GO(1) else if (RT == 2) PGEN_GO(2) else if (RT == 3) PGEN_GO(3) else PGEN_GO(4)
 #undef PGEN_GO
-    MTTS_CHECK_LAUNCH("pgen_kernel");
-    return 0;
+        MTTS_CHECK_LAUNCH("pgen_kernel");
+    }
+    return ps_launched(s);
 }
 
 bool pdec_supported(const DecoderArgs& a) {
@@ -1308,7 +1140,9 @@ bool pdec_supported(const DecoderArgs& a) {
     static const bool off = [] { const char* e = getenv("MTTS_PDEC"); return e && e[0] == '0'; }();
     if (off) return false;
     const int nc4 = a.Dm / 16, ng = PS_THREADS / nc4;
-    return nc4 >= 1 && ng >= 1 && (a.L + ng - 1) / ng <= PD_NCM;
+    if (!(nc4 >= 1 && ng >= 1 && (a.L + ng - 1) / ng <= PD_NCM)) return false;
+    const PsInst k = pdec_instance(a.B, a.H, a.Dm, a.precision);
+    return ps_kernel_ready(k.fn, k.threads, k.lds);
 }
 
 // attention LSTM + attention, steps [t0, t1) in one launch; needs U, Mt, pre_att and the packed weights of mtts_decoder_fwd's set-up
@@ -1328,37 +1162,42 @@ int pdec_launch(const DecoderArgs& a, int t0, int t1, hipStream_t s) {
     p.w_query = a.w_query; p.memory = a.memory; p.Mt = a.Mt; p.U = a.U; p.att_bias = a.att_bias; p.v = a.w_energy; p.lengths = a.lengths;
     p.ctx = a.ctx; p.cum = a.cum; p.align = a.align; p.q_all = a.q_all;
     char* ws = (char*)a.persist_ws;
-    p.sync.cnt = (unsigned*)ws; p.sync.err = a.persist_err ? (unsigned*)a.persist_err : (unsigned*)(ws + PS_ERR_OFF);
+    p.sync.cnt = (unsigned*)ws; p.sync.err = ps_err_word(a);
     p.xp = (float*)(ws + ps_ws_att_off(a.H));
     p.eg = (unsigned long long*)(ws + ps_ws_eg_off(a.H, a.Dm));
+    MTTS_TRY(ps_serialize(s));
     MTTS_CHECK_HIP(hipMemsetAsync(ws, 0, PS_ERR_OFF, s));
     MTTS_CHECK_HIP(hipMemsetAsync(p.eg, 0, (size_t)64 * 4 * PD_LMAX * 8, s));
     static const bool poll_on = [] { const char* e = getenv("MTTS_PDEC_POLL"); return !(e && e[0] == '0'); }();
     p.poll_h = (poll_on && !g_pdec_poll_off) ? 1 : 0;
     if (p.poll_h)       // h rows of the steps this launch produces: sentinel until their owner's store lands
         MTTS_CHECK_HIP(hipMemsetAsync(a.h_att + (size_t)(t0 + 1) * a.B * a.H, 0xff, (size_t)(t1 - t0) * a.B * a.H * sizeof(float), s));
-    size_t lds = (size_t)((a.Dm + a.H) / 32) * (a.precision ? 1024 : 2048) + 8 * 64 * 16 * 4 + PD_LMAX * 32 * 4 + (PD_LMAX + 64) * 4 + 2 * 3 * 64 * 16 + 64 * 4;
+    const size_t lds = pdec_lds(a.H, a.Dm, a.precision);
 #ifdef PS_PROF
-    lds += 300 * 8;
     MTTS_CHECK_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_ps_prof_dev), &g_ps_prof, sizeof(g_ps_prof), 0, hipMemcpyHostToDevice, s));
 #endif
     const int RT = (a.B + 15) / 16;
-#define PDEC_GO(R, PR)                                                                                                      \
-    {                                                                                                                       \
-        MTTS_CHECK_HIP(hipFuncSetAttribute((const void*)pdec_kernel<R, PR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((pdec_kernel<R, PR>), dim3(PS_WGS), dim3(PS_THREADS), lds, s, p);                                \
-    }
+#define PDEC_GO(R, PR) hipLaunchKernelGGL((pdec_kernel<R, PR>), dim3(PS_WGS), dim3(PS_THREADS), lds, s, p);
     if (a.precision) { if (RT == 1) PDEC_GO(1, 1) else if (RT == 2) PDEC_GO(2, 1) else if (RT == 3) PDEC_GO(3, 1) else PDEC_GO(4, 1) }
     else { if (RT == 1) PDEC_GO(1, 0) else if (RT == 2) PDEC_GO(2, 0) else if (RT == 3) PDEC_GO(3, 0) else PDEC_GO(4, 0) }
 #undef PDEC_GO
     MTTS_CHECK_LAUNCH("pdec_kernel");
-    return 0;
+    return ps_launched(s);
 }
 
-// device error word of the last persistent launch on this workspace (0 = ok, 2 = a grid barrier timed out); synchronises
+// device error word of the persistent launches on this workspace (0 = ok, 2 = a hand-off timed out); synchronises the stream.
+// Reads the word the kernels actually report to: DecoderArgs.persist_err of the last launch on this workspace, or the word inside
+// the workspace when no launch named another.
 MTTS_API int mtts_decoder_persist_status(const void* persist_ws, void* stream) {
+    const unsigned* src = (const unsigned*)((const char*)persist_ws + PS_ERR_OFF);
+    {
+        PsDevice& D = ps_dev();
+        std::lock_guard<std::mutex> lk(D.mu);
+        auto it = D.err_of.find(persist_ws);
+        if (it != D.err_of.end()) src = it->second;
+    }
     unsigned v = 0;
-    if (hipMemcpyAsync(&v, (const char*)persist_ws + PS_ERR_OFF, 4, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return -1;
+    if (hipMemcpyAsync(&v, src, 4, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return -1;
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
     return (int)v;
 }

@@ -2,7 +2,7 @@
 // DecoderArgs / DecoderGradArgs / BiLstmArgs / BiLstmGradArgs, by field name.  A binding fills the shape fields of the argument
 // block (B, L, T, M, P, H, A, Dm, ksz, C, n_prenet, kq, fast, precision; ksb / ksb_ctx / nch of the gradient block) and asks here
 // instead of re-deriving the formulas of the header comments.  Element = float unless the field is documented in bytes
-// (att_w2p / gen_w2p / att_w_rec_T2p / persist_ws: bytes; masks: uint8 flags).  Returns -1 for an unknown field name.
+// (att_w2p / gen_w2p / persist_ws: bytes; masks: uint8 flags).  Returns -1 for an unknown field name.
 #include "common.h"
 
 static inline long r4(long x) { return (x + 3) & ~3L; }
@@ -52,7 +52,6 @@ MTTS_API long mtts_decoder_grad_buffer_elems(const DecoderArgs* fwd, const Decod
         {"w_out_T", (H + Dm) * Mo}, {"prenet_w_T0", M * P}, {"prenet_w_T", P * P},
         {"step_ws", B * ((P + Dm + H) + (2 * H + Dm) + (H + Dm) + M)}, {"frames_fed", T * B * M}, {"w_query_T", H * A},
         {"dG_att", T * B * 4 * H}, {"dG_gen", T * B * 4 * H}, {"dG_att_p", T * Bp * 4 * H}, {"dG_gen_p", T * Bp * 4 * H},
-        {"att_w_rec_T2p", mtts_ksplit_packed_weight_bytes((int)(Dm + H), (int)(4 * H), 0)}, {"part_rec", 24 * B * (Dm + H)}, {"dh_rec_sum", B * H},
         {"att_w_rec_Tp", r16(Dm + H) * 4 * H}, {"gen_w_hh_Tp", H * 4 * H},
         {"dHG", T * B * H}, {"dHA", T * B * H}, {"dctx_all", (T + 1) * B * Dm}, {"dctx_tot", (T + 1) * B * Dm}, {"dcum_all", (T + 1) * B * L},
         {"dq_all", T * B * A}, {"part_gen", ksb * B * H}, {"part_att", ksc * B * Dm + ksb * B * H},

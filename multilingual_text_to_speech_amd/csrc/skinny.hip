@@ -8,8 +8,8 @@ __global__ __launch_bounds__(NT) void skinny_kernel(SkinnyArgs p) {
     skinny_body<MT>(p, red, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
-// Low-register variant (2-deep load pipeline, <= 128 VGPRs): two 512-thread workgroups fit on one CU.  Used when the grid has more
-// workgroups than the chip has CUs (batch > 64: several row tiles per column block), where co-residency beats pipeline depth.
+// Low-register variant (2-deep load pipeline, <= 128 VGPRs): two 512-thread workgroups fit on one CU; used for every launch with
+// more than 32 rows (co-residency with the helper streams' GEMM workgroups beats pipeline depth).
 template <int MT>
 __global__ __launch_bounds__(NT, 4) void skinny_kernel_lo(SkinnyArgs p) {
     __shared__ float red[NW][MT * 16][17];
@@ -33,21 +33,18 @@ int skinny_launch(const SkinnyArgs& p, hipStream_t s) {
     if (p.lstm == 2) q.N = p.H;
     if (p.lstm == 1 && !q.h_prev) q.h_prev = q.c_prev;
     const int cbs = p.lstm == 1 ? cdiv(p.H, 4) : cdiv(q.N, 16);
-    // Default for more than 32 rows: the <= 128-VGPR variant.  The 4-deep one (153 VGPRs) is ~10 % faster alone, but cannot share a CU
-    // with two GEMM workgroups of the helper streams and then WAITS for them: 92.0-92.3 vs 94.4-94.8 ms per train step.
-    static const bool force_lo = [] { const char* e = getenv("MTTS_SKINNY_DEEP"); return !(e && e[0] == '1'); }();
     // LSTM cell backward (K <= the query width): the launch is all epilogue operands (16 loads per (row, unit)); one 16-row tile per
     // workgroup gives four times the workgroups to fetch them (bit-identical: same K chunks per wave, same reduction order).
-    static const bool cell_rows16 = [] { const char* e = getenv("MTTS_CELL_ROWS16"); return !(e && e[0] == '0'); }();
-    if (cell_rows16 && p.lstm == 2 && p.B > 16 && p.B <= 64 && q.seg[0].K <= 256 && q.nseg == 1 && ks == 1) {
+    if (p.lstm == 2 && p.B > 16 && p.B <= 64 && q.seg[0].K <= 256 && q.nseg == 1 && ks == 1) {
         hipLaunchKernelGGL(skinny_kernel<1>, dim3(cbs, cdiv(p.B, 16), 1), dim3(NT), 0, s, q);
         MTTS_CHECK_LAUNCH("skinny_kernel");
         return 0;
     }
     if (p.B <= 16) hipLaunchKernelGGL(skinny_kernel<1>, dim3(cbs, cdiv(p.B, 16), ks), dim3(NT), 0, s, q);
     else if (p.B <= 32) hipLaunchKernelGGL(skinny_kernel<2>, dim3(cbs, cdiv(p.B, 32), ks), dim3(NT), 0, s, q);
-    else if (force_lo || (long)cbs * cdiv(p.B, 64) * ks > 320) hipLaunchKernelGGL(skinny_kernel_lo<4>, dim3(cbs, cdiv(p.B, 64), ks), dim3(NT), 0, s, q);
-    else hipLaunchKernelGGL(skinny_kernel<4>, dim3(cbs, cdiv(p.B, 64), ks), dim3(NT), 0, s, q);
+    // more than 32 rows: the <= 128-VGPR variant.  A 4-deep load pipeline (153 VGPRs) is ~10 % faster alone, but cannot share a CU with
+    // two GEMM workgroups of the helper streams and then WAITS for them: 92.0-92.3 vs 94.4-94.8 ms per train step (round 2).
+    else hipLaunchKernelGGL(skinny_kernel_lo<4>, dim3(cbs, cdiv(p.B, 64), ks), dim3(NT), 0, s, q);
     MTTS_CHECK_LAUNCH("skinny_kernel");
     return 0;
 }

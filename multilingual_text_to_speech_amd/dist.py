@@ -151,10 +151,16 @@ def global_mean_scale(n_local, device):
     (which averages over ranks): mean_global = (1 / world) * sum_r [ local_mean_r * n_local_r * world / n_global ].
     Used for the adversarial classifier loss, a mean over the VALID characters of the batch (reference
     modules/classifier.py:62-69 on the gathered global batch): shards with different text lengths hold different numbers of them.
-    Returns a 1-element tensor on `device` (no host synchronisation); 1.0 when not running data parallel."""
+    `n_local` may be a python number or a (device) tensor - a tensor is used as it is, so the caller's stream never waits for the
+    host.  Returns a 1-element tensor on `device`; 1.0 when not running data parallel.  A COLLECTIVE: every rank must call it the
+    same number of times (TacotronLoss does so in the sharded training step only)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return torch.ones(1, dtype=torch.float32, device=device)
     world = dist.get_world_size()
-    total = torch.tensor([float(n_local)], dtype=torch.float32, device=device)
+    if torch.is_tensor(n_local):
+        local = n_local.detach().to(device=device, dtype=torch.float32).reshape(1)
+    else:
+        local = torch.tensor([float(n_local)], dtype=torch.float32, device=device)
+    total = local.clone()
     dist.all_reduce(total, op=dist.ReduceOp.SUM)
-    return (float(n_local) * world) / total.clamp_min(1.0)
+    return (local * world) / total.clamp_min(1.0)

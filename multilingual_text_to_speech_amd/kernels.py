@@ -142,6 +142,32 @@ def check_device_errors(device=None):
                                'hp.speaker_number or language id >= hp.language_number); the row was read as zeros')
 
 
+_ERR_POLL = {}
+
+
+def poll_device_errors(device=None):
+    """check_device_errors without stalling the stream: enqueues a copy of this GPU's error words into pinned host memory and raises
+    for what the PREVIOUS poll fetched (if that copy has completed - after a whole train step it has).  Called once per optimizer step
+    by bench.train_step: a persistent decoder kernel that gave up is reported one step later, and the guarded optimizer step
+    (AdamArgs.guard) has kept the invalid step away from the weights in the meantime."""
+    for key, flag in list(_ERR_FLAGS.items()):
+        if device is not None and (torch.device(device).index or 0) != key:
+            continue
+        st = _ERR_POLL.get(key)
+        if st is None:
+            st = _ERR_POLL[key] = dict(host=torch.zeros(2, dtype=torch.int32).pin_memory(), event=None)
+        if st['event'] is not None:
+            if not st['event'].query():
+                continue                               # the previous copy is still in flight: look again at the next call
+            st['event'] = None
+            if int(st['host'][0]) != 0 or int(st['host'][1]) != 0:
+                check_device_errors(flag.device)       # synchronises, clears the words and raises with the full message
+        with torch.cuda.device(flag.device):
+            st['host'].copy_(flag, non_blocking=True)
+            st['event'] = torch.cuda.Event()
+            st['event'].record()
+
+
 class EmbeddingFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, table, ids, padding_idx):

@@ -329,9 +329,13 @@ class TacotronLoss(Module):
         if hp.guided_attention_loss:
             losses['guided_att'] = v[3] if ga_on else 0
         if hp.reversal_classifier:
-            from ..dist import global_mean_scale      # data parallel: the reference's CE is a mean over the GLOBAL batch's valid characters
-            share = global_mean_scale(int(source_length.sum()), speaker_prediction.device)
-            losses['lang_class'] = ReversalClassifier.loss(source_length, speaker, speaker_prediction) * share[0] * \
+            losses['lang_class'] = ReversalClassifier.loss(source_length, speaker, speaker_prediction) * \
                 (hp.reversal_classifier_w / (hp.num_mels + 2))
+            if torch.is_grad_enabled() and speaker_prediction.requires_grad:
+                # data-parallel TRAINING step only (every rank holds a shard of ONE global batch and calls this exactly once per
+                # step): the reference's CE is a mean over the GLOBAL batch's valid characters.  Evaluation deals whole, unrelated
+                # batches to the ranks (train.evaluate) - no collective there: ranks make different numbers of calls.
+                from ..dist import global_mean_scale
+                losses['lang_class'] = losses['lang_class'] * global_mean_scale(source_length.sum(), speaker_prediction.device)[0]
             total = total + losses['lang_class']
         return total, losses

@@ -133,6 +133,7 @@ class FusedAdam(torch.optim.Adam):
         a.ptrs, a.chunk_tensor, a.chunk_off, a.chunk_len = ptr(t['ptrs']), ptr(t['ct']), ptr(t['co']), ptr(t['cl'])
         a.norm_partials, a.norm_out, a.nchunks, a.phase = ptr(t['partials']), ptr(norm), t['n'], phase
         a.max_norm = float(max_norm)
+        a.guard = ptr(self._guard)
         if group is not None:
             b1, b2 = group['betas']
             a.weight_decay, a.beta1, a.beta2, a.eps = group['weight_decay'], b1, b2, group['eps']
@@ -166,6 +167,10 @@ class FusedAdam(torch.optim.Adam):
         if not everything:
             return None
         dev = everything[0].device
+        # device-side guard: the update is skipped when this GPU's persistent-kernel error word is set or the gradient norm is not
+        # finite (mtts.h AdamArgs.guard) - no host synchronisation; kernels.poll_device_errors raises one step later
+        from .kernels import _err_flag
+        self._guard = _err_flag(dev)
         norm = self._tables.get('norm')
         if norm is None or norm.device != dev:
             norm = self._tables['norm'] = torch.zeros(2, dtype=torch.float32, device=dev)

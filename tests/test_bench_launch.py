@@ -35,3 +35,38 @@ def test_bench_rejects_mismatched_world_size():
     env.update(MTTS_BENCH_STUB='1', WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and 'WORLD_SIZE' in (r.stderr + r.stdout)
+
+
+# ---- SCALE dry run on ONE GPU -----------------------------------------------------------------------------------------------------
+import pytest
+
+
+def _run_real(argv, extra_env, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'MTTS_BENCH_STUB')}
+    env.update(extra_env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *argv], env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-1500:] + r.stderr[-2500:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_scale_dry_run_two_ranks_on_one_gpu_with_the_real_train_step():
+    """What the driver's SCALE run does (`python bench.py --gpus N --steps K --warmup W`, no launcher), with the REAL train step:
+    self-launch under torch.distributed.run, rendezvous on 127.0.0.1, per-rank model / shard / gradient buckets with the overlapped
+    all-reduce, fused clip + Adam, barrier + max-over-ranks timing, ONE JSON line from rank 0.  Both ranks share cuda:0
+    (MTTS_SINGLE_DEVICE=1), so the collective backend is gloo (RCCL refuses two ranks on one device) and the persistent kernels are
+    off (two processes cannot both own every CU); on the 8-GPU node the same code path runs over RCCL with one device per rank.
+    The per-rank step time must be consistent with the single-rank run of the same shard (two ranks time-share one GPU: between
+    0.5x and 6x of it)."""
+    argv = ['--steps', '2', '--warmup', '1', '--batch', '8', '--frames', '60', '--no-secondary', '--no-cpu-baseline']
+    env = dict(MTTS_SINGLE_DEVICE='1', MTTS_DIST_BACKEND='gloo', MTTS_PERSIST='0')
+    two = _run_real(['--gpus', '2', *argv], env)
+    assert two['n_gpus'] == 2 and two['steps'] == 2 and two['warmup'] == 1 and two['scaling'] == 'weak'
+    assert two['config']['global_batch'] == 16 and two['config']['parallelism'] == 'dp2'
+    assert two['unit'] == 'mel-frames/s' and two['value'] > 0 and 'roofline' in two
+    assert abs(two['value'] - 16 * 60 * 1e3 / two['ms_per_step']) <= 0.02 * two['value']          # whole-job frames / max-over-ranks time
+    one = _run_real(['--gpus', '1', *argv], dict(MTTS_PERSIST='0'))
+    assert one['n_gpus'] == 1 and one['config']['global_batch'] == 8
+    assert 0.5 * one['ms_per_step'] <= two['ms_per_step'] <= 6.0 * one['ms_per_step'], (one['ms_per_step'], two['ms_per_step'])

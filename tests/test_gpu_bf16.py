@@ -104,3 +104,12 @@ def test_bf16_path_matches_the_oracle_with_bf16_rounded_operands(B, T):
     against the fp32 fixtures is not."""
     from tests.test_gpu_more import run_train_step_case
     run_train_step_case('shared_training', B, 30, T, {}, check_grads=False, bf16=True)
+
+
+@pytest.mark.parametrize('preset,B,L,T', [('shared_training', 16, 30, 20), ('generated_switching', 40, 30, 10)])
+def test_bf16_gradients_match_the_oracle_with_bf16_rounded_operands(preset, B, L, T):
+    """bf16 train step: every parameter gradient against the autograd of the CPU oracle run with the same operand rounding
+    (relative L2 per tensor <= tests.test_gpu_more.BF16_GRAD_TOL) - replaces the cosine >= 0.98 bound against the fp32 fixtures,
+    which a wrong-but-plausible backward kernel passes."""
+    from tests.test_gpu_more import run_train_step_case
+    run_train_step_case(preset, B, L, T, {}, bf16=True)

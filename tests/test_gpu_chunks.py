@@ -49,6 +49,20 @@ def test_generated_training_train_step_at_real_widths():
     run_train_step_case('generated_training', 20, 30, 49, {})
 
 
+@pytest.mark.parametrize('preset,B', [('shared_training', 4), ('generated_switching', 5)])
+def test_benchmark_encoder_length_train_step_gradients_match_oracle(preset, B):
+    """L = 120, A = 128, Dm = 544 / 288: the attention-backward instance the benchmark launches 600 times per step
+    (`mtts_attn_step_bwd` picks its kernel from an LDS-size predicate over L and Dm, csrc/attention_bwd.hip) - outputs, loss and EVERY
+    parameter gradient against the oracle's autograd (reference modules/attention.py:39-86, modules/tacotron2.py:180-198)."""
+    run_train_step_case(preset, B, 120, 6, {})
+
+
+def test_batch_above_64_train_step_gradients_match_oracle():
+    """Batch 80 (five 16-row tiles, 16 per language group): above the 64-row limit of the round-3 persistent kernels - the forward
+    schedule of large batches and the backward's multi-tile paths, every gradient against the oracle."""
+    run_train_step_case('generated_switching', 80, 30, 7, {})
+
+
 def test_roofline_b240_shape_forward_matches_oracle():
     """The shape `roofline_b240` is quoted on - generated_switching, batch 240 (48 per language group, four 64-row MFMA tiles
     with a ragged last one), 120 characters - forward only over 48 frames: mel outputs and alignments against the CPU oracle."""

@@ -146,6 +146,7 @@ def test_train_step_gradients_match_oracle_at_real_widths(preset, B, L, T, over)
     run_train_step_case(preset, B, L, T, over)
 
 
+BF16_GRAD_TOL = 1e-2          # relative L2 per parameter tensor (see run_train_step_case)
 BF16_ORACLE_SITES = frozenset({'conv', 'bilstm_in', 'lstm', 'memory', 'loc', 'prenet', 'proj', 'linear'})
 
 
@@ -239,6 +240,32 @@ def run_train_step_case(preset, B, L, T, over, check_grads=True, ragged=None, te
         tol = {'encoder': 2e-3, 'pre': 2e-3, 'alignment': 2e-3, 'post': 2e-2}
         assert all(v[0] <= tol[k] for k, v in errs.items()), f'{preset} B={B} T={T} bf16: {errs}'
         assert (post.detach().cpu() - ref['post'].detach()).abs().max().item() > 0      # (not bit-identical: different summation order)
+        if not check_grads:
+            return
+        # bf16 GRADIENTS against the oracle's autograd through the same operand rounding (straight-through: the derivative of the
+        # rounding is 1).  What differs on the product side: its batched backward GEMMs round dY / W / X to bf16 as well (the
+        # per-step recurrence products stay fp32), i.e. one more 2^-9 relative perturbation per contraction operand, so the bound is
+        # a norm-wise one per tensor: relative L2 <= BF16_GRAD_TOL.  A wrong kernel (missing term, wrong mask, wrong scale) is off by
+        # O(1) in at least one tensor; the cosine >= 0.98 check this replaces allowed a 20 % error.
+        crit = TacotronLoss(hp.guided_attention_steps, hp.guided_attention_toleration, hp.guided_attention_gain)
+        _C.set_precision('bf16')
+        try:
+            loss, _ = crit(tl.cuda(), tgl.cuda(), pre, target.cuda(), post, target.cuda(), stop, stop_t.cuda(), align, to(spk), spk_pred, enc, None)
+            loss.backward()
+            torch.cuda.synchronize()
+        finally:
+            _C.set_precision('fp32')
+        assert abs(loss.item() - rloss.item()) <= 2e-3 * max(1.0, abs(rloss.item()))
+        worst = {}
+        for k, p in model.named_parameters():
+            r = sd[k].grad
+            assert r is not None and p.grad is not None, k
+            d = (p.grad.cpu() - r).double()
+            worst[k] = (d.norm() / r.double().norm().clamp_min(1e-12)).item()
+        top = sorted(worst.items(), key=lambda kv: -kv[1])[:6]
+        print('bf16 gradients vs bf16-operand oracle, worst relative L2:', [(k, round(v, 5)) for k, v in top])
+        bad = {k: v for k, v in worst.items() if v > BF16_GRAD_TOL}
+        assert not bad, f'{preset} B={B} T={T} bf16 gradients: {bad}'
         return
     crit = TacotronLoss(hp.guided_attention_steps, hp.guided_attention_toleration, hp.guided_attention_gain)
     loss, _ = crit(tl.cuda(), tgl.cuda(), pre, target.cuda(), post, target.cuda(), stop, stop_t.cuda(), align, to(spk), spk_pred, enc, None)
@@ -466,6 +493,61 @@ def test_data_parallel_train_steps_two_ranks_one_gpu(tmp_path):
     assert r0['losses'] != r1['losses']                         # different shards
     for a, b in zip(r0['params'], r1['params']):
         assert torch.equal(a, b)
+
+
+def _eval_collated(hp, G, n_batches=3):
+    """Collate-format validation batches (8-tuples of data.Collate) with RAGGED text lengths, so that the ranks hold different
+    numbers of valid characters."""
+    import bench
+    out = []
+    for i in range(n_batches):
+        b = bench.synthetic_batch(hp, 2 * G, 9, 12, torch.device('cpu'), seed=40 + i)
+        tl = b['text_length'].clone(); tl[-1] = 5 + i
+        b['text'][-1, int(tl[-1]):] = 0
+        out.append((b['text'], tl, b['target'], None, b['target_length'], b['stop'], b['speakers'], b['languages']))
+    return out
+
+
+def _ddp_eval_worker(rank, world, port, out, fixture):
+    import os
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      MTTS_PERSIST='0')       # both ranks share ONE GPU
+    import torch.distributed as dist
+    import train
+    from multilingual_text_to_speech_amd import dist as D
+    from multilingual_text_to_speech_amd.params import Params as hp
+    from multilingual_text_to_speech_amd.modules.tacotron2 import TacotronLoss
+    from tests.helpers import build_hip_model, load_golden
+    D.init(backend='gloo')
+    model = build_hip_model(load_golden(fixture)).train()
+    assert hp.reversal_classifier
+    crit = TacotronLoss(hp.guided_attention_steps, hp.guided_attention_toleration, hp.guided_attention_gain)
+    res = train.evaluate(hp, _eval_collated(hp, len(hp.languages)), model, crit, torch.device('cuda'), rank, world)
+    torch.save(res, f'{out}/ev{rank}.pt')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_evaluation_with_the_real_loss_and_an_odd_batch_count(tmp_path):
+    """train.evaluate under data parallelism with the REAL TacotronLoss and hp.reversal_classifier: three validation batches over
+    two ranks (2 + 1).  The classifier term must not issue a collective outside the sharded training step (the ranks make different
+    numbers of loss calls: a collective there pairs with the final all-reduce of the other rank - hang / garbage), both ranks return
+    the same means, and the classifier term (deterministic in eval mode: encoder + classifier only) equals the single-process value."""
+    import socket
+    import torch.multiprocessing as mp
+    import train
+    from multilingual_text_to_speech_amd.params import Params as hp
+    from multilingual_text_to_speech_amd.modules.tacotron2 import TacotronLoss
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_ddp_eval_worker, args=(2, port, str(tmp_path), 'generated_train'), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / 'ev0.pt'), torch.load(tmp_path / 'ev1.pt')
+    assert set(r0) == set(r1) == set(train.EVAL_TERMS) | set(train.EVAL_EXTRAS)
+    for k in r0:
+        assert r0[k] == r1[k] and r0[k] == r0[k], k
+    model = build_hip_model(load_golden('generated_train')).train()
+    crit = TacotronLoss(hp.guided_attention_steps, hp.guided_attention_toleration, hp.guided_attention_gain)
+    single = train.evaluate(hp, _eval_collated(hp, len(hp.languages)), model, crit, torch.device('cuda'))
+    assert abs(single['lang_class'] - r0['lang_class']) <= 1e-5 * max(1.0, abs(single['lang_class']))
 
 
 def _micro_batch_grads(model, crit, hp, rank, G):

@@ -63,3 +63,63 @@ def test_decoder_forward_forms_agree(tmp_path):
 def test_persistent_kernels_shape_edges_match_oracle(preset, B, L, T):
     from tests.test_gpu_more import run_train_step_case
     run_train_step_case(preset, B, L, T, {}, check_grads=False)
+
+
+# The same edges WITH gradients: the persistent kernels save h / c / activated gates / context / cumulative alignment / query for the
+# backward chains (csrc/decoder_bwd.hip); a ragged last row tile, a single sample and the maximal encoder length must hand the
+# backward exactly what the per-step schedule would (every parameter gradient against the oracle's autograd).
+@pytest.mark.parametrize('preset,B,L,T', [('shared_training', 1, 7, 10), ('shared_training', 33, 128, 6), ('shared_training', 63, 40, 5),
+                                          ('generated_switching', 40, 30, 8)])
+def test_persistent_kernels_shape_edges_gradients_match_oracle(preset, B, L, T):
+    from tests.test_gpu_more import run_train_step_case
+    run_train_step_case(preset, B, L, T, {})
+
+
+def test_two_persistent_decodes_in_flight_from_two_streams():
+    """A persistent kernel needs every workgroup of its grid resident; two of them dispatched at once from two streams could each hold
+    a part of the chip and starve the other until the bounded spins give up.  The library orders a persistent launch behind the
+    device's previous one when that went to another stream (csrc/persist.hip: ps_serialize): decodes issued concurrently from two
+    host threads on two streams must all equal the single-stream result, with no device error raised."""
+    import threading
+    from multilingual_text_to_speech_amd import kernels
+    from multilingual_text_to_speech_amd.params import presets, Params as hp
+    from multilingual_text_to_speech_amd.modules.tacotron2 import Tacotron
+    from tests.test_gpu_more import _random_batch
+    presets.apply('shared_training')
+    torch.manual_seed(0)
+    model = Tacotron().cuda().eval()
+    B, L, T = 24, 40, 90
+    text, tl, target, tgl, spk, lang = _random_batch(hp, B, L, T)
+    args = (text.cuda(), tl, target.cuda(), tgl, None, lang.cuda(), 1.0)
+    from multilingual_text_to_speech_amd.masks import provider
+    g = torch.Generator().manual_seed(3)
+    draws = {f'dec.prenet.{i}': (torch.rand(T, B, hp.prenet_dimension, generator=g) >= hp.dropout).to(torch.uint8).cuda() for i in range(2)}
+    provider.injected = {**draws, 'teacher': [True] * T}           # identical prenet dropout draws in every call (thread-safe: read only)
+    try:
+        with torch.no_grad():
+            base = model(*args)[0].clone()
+        torch.cuda.synchronize()
+        kernels.check_device_errors()
+        outs, errs = {}, []
+
+        def worker(i):
+            try:
+                s = torch.cuda.Stream()
+                with torch.cuda.stream(s), torch.no_grad():
+                    outs[i] = [model(*args)[0].clone() for _ in range(3)]
+                s.synchronize()
+            except Exception as exc:              # noqa: BLE001 - reported below
+                errs.append(repr(exc))
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        torch.cuda.synchronize()
+    finally:
+        provider.injected = None
+    assert not errs, errs
+    kernels.check_device_errors()
+    for i in range(2):
+        for o in outs[i]:
+            assert torch.equal(o, base)

@@ -167,14 +167,40 @@ def make_loader(hp, ds, train, rank, world, workers):
 
 
 EVAL_TERMS = ('mel_pre', 'mel_pos', 'stop_token', 'guided_att', 'lang_class')      # the loss dictionary of TacotronLoss.forward
+EVAL_EXTRAS = ('free_running_mse', 'classifier_accuracy')                              # reported beside the loss, never summed into it
 
 
-def evaluate(hp, data, model, crit, device, rank=0, world=1):
-    """Validation loss with teacher forcing (train.py:100-126,155-160): mean of the per-batch loss terms.  The reference also
-    reports mel-cepstral distortion of a free-running pass and alignment plots; both need its audio stack (absent here).
+def _free_running_mse(hp, post0, stop0, target, target_length):
+    """Mean squared error of the FREE-RUNNING prediction against the target, per utterance over the frames both have: the generated
+    length follows the reference's rule (train.py:137-139: first frame with sigmoid(stop) > 0.5, plus hp.stop_frames, capped).  A
+    stand-in for the reference's mel-cepstral distortion (train.py:134-145), whose MFCC / DTW need librosa + fastdtw (absent here)."""
+    probs = torch.sigmoid(stop0)
+    B, T = probs.shape
+    hit = probs > 0.5
+    first = torch.where(hit.any(1), hit.float().argmax(1), torch.full((B,), T, device=probs.device))
+    n_gen = torch.clamp(first + getattr(hp, 'stop_frames', 5), max=T)
+    n = torch.minimum(n_gen, target_length.to(probs.device)).clamp_min(1)
+    m = (torch.arange(T, device=probs.device)[None, :] < n[:, None]).to(post0.dtype)            # [B, T]
+    d2 = ((post0 - target) ** 2).mean(1) * m                                                       # mean over mel channels
+    return float((d2.sum(1) / n).mean())
+
+
+def _classifier_accuracy(hp, text_length, speakers, spk_pred):
+    """Share of valid characters whose adversarial-classifier prediction is the utterance's speaker (train.py:147-156)."""
+    mask = (torch.arange(spk_pred.shape[1], device=spk_pred.device)[None, :] < text_length.to(spk_pred.device)[:, None])
+    match = (spk_pred.argmax(-1) == speakers.to(spk_pred.device)[:, None]) & mask
+    return float(match.sum()) / max(float(mask.sum()), 1.0)
+
+
+def evaluate(hp, data, model, crit, device, rank=0, world=1, free_running=True):
+    """Validation (train.py:100-160): per batch the model runs TWICE like the reference's (`:124-125`) - teacher forced (the loss terms)
+    and free running (teacher forcing 0.0: the general decoder schedule on the model's own frames) - and the result is the mean of
+    the per-batch loss terms plus, beside them, the free-running reconstruction error and the adversarial classifier's accuracy
+    (EVAL_EXTRAS; the reference's MCD and alignment plots need its audio stack, absent here).
     Data parallel: the batches are the reference's full (unsharded) validation batches; rank r takes batches r, r + world, ...
     and the per-term sums and the batch count are all-reduced, so every rank works (no rank idles in a barrier while rank 0
-    evaluates - a long validation pass would otherwise run into the collective watchdog) and all ranks return the same means."""
+    evaluates - a long validation pass would otherwise run into the collective watchdog) and all ranks return the same means.
+    No collective runs inside the loop (the ranks see different numbers of batches)."""
     from multilingual_text_to_speech_amd import data as DT
     model.eval()
     sums, n = {}, 0
@@ -187,12 +213,19 @@ def evaluate(hp, data, model, crit, device, rank=0, world=1):
                                                      b['languages'], 1.0)
             _, parts = crit(b['text_length'].to(device), b['target_length'].to(device), pre, b['target'], post, b['target'], stop,
                             b['stop'], align, b['speakers'], spk, enc, None)
+            parts = dict(parts)
+            if free_running:
+                post0, _, stop0, _, _, _ = model(b['text'], b['text_length'], b['target'], b['target_length'], b['speakers'],
+                                                 b['languages'], 0.0)
+                parts['free_running_mse'] = _free_running_mse(hp, post0, stop0, b['target'], b['target_length'])
+            if spk is not None and b['speakers'] is not None:
+                parts['classifier_accuracy'] = _classifier_accuracy(hp, b['text_length'], b['speakers'], spk)
             for k, v in parts.items():
                 sums[k] = sums.get(k, 0.0) + float(v)
             n += 1
     model.train()
     if world > 1:
-        keys = sorted(EVAL_TERMS)
+        keys = sorted(EVAL_TERMS + EVAL_EXTRAS)
         t = torch.tensor([sums.get(k, 0.0) for k in keys] + [float(n)], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t)
         n = int(t[-1].item())
@@ -229,8 +262,9 @@ def train_on_dataset(args, hp, datasets, model, opt, crit, buckets, rank, world,
         # validation over the full (unsharded) batches of the reference's single-process evaluate(), dealt round-robin to the ranks
         eval_losses = evaluate(hp, eval_data, model, crit, device, rank, world) if eval_data is not None else {}
         if rank == 0:
-            eval_loss = sum(eval_losses.values()) if eval_losses else float(loss.item())
-            print(f'epoch {epoch}: train loss {loss.item():.4f}  eval loss {eval_loss:.4f}  '
+            eval_loss = sum(v for k, v in eval_losses.items() if k in EVAL_TERMS) if eval_losses else float(loss.item())
+            extras = '  '.join(f'{k} {eval_losses[k]:.4f}' for k in EVAL_EXTRAS if k in eval_losses)
+            print(f'epoch {epoch}: train loss {loss.item():.4f}  eval loss {eval_loss:.4f}  {extras}  '
                   f'{frames * world / (time.time() - t0):.0f} frames/s', flush=True)
             if (epoch + 1) % hp.checkpoint_each_epochs == 0:
                 DT.save_checkpoint(os.path.join(ckpt_dir, f'{hp.version}_loss-{epoch}-{eval_loss:2.3f}'), epoch, model, opt, sched, crit)
