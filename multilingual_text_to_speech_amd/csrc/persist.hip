@@ -188,14 +188,32 @@ __device__ __forceinline__ bool ps_barrier(const PsSync& s, unsigned epoch) {
 //   from the exchange buffer (sc1 loads, DEPTH blocks in flight), takes its weight fragments from LDS and leaves its
 //   [16 RT rows x 16 columns] partial sums in red[w][row][col].
 // ---------------------------------------------------------------------------------------------------------------------------
-// acc += this wave's share of the k-blocks [kb_lo, kb_hi) (the eight waves split the range; at most NBW blocks per wave)
-template <int NBW, int RT, int DEPTH>
-__device__ __forceinline__ void ps_gates_acc(__amdgpu_buffer_rsrc_t xr, int nkb, int kb_lo, int kb_hi, const float4* __restrict__ wl, f32x4 (&acc)[RT]) {
+// request the k-blocks [J0, J1) (J1 <= DEPTH) of this wave's share of [kb_lo, kb_hi) (the fragments of all RT row tiles) into xa
+template <int NBW, int RT, int DEPTH, int J0 = 0, int J1 = DEPTH>
+__device__ __forceinline__ void ps_gates_prefetch(__amdgpu_buffer_rsrc_t xr, int nkb, int kb_lo, int kb_hi, float4 (&xa)[DEPTH][RT][2]) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nrange = kb_hi - kb_lo;
     const int k0 = kb_lo + ((nrange * wave) >> 3), k1 = kb_lo + ((nrange * (wave + 1)) >> 3);
-    float4 xa[DEPTH][RT][2];
+#pragma unroll
+    for (int j = J0; j < J1 && j < NBW; ++j)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+                xa[j][rt][hf] = ps_ld16_sc1(xr, (k0 + j < k1) ? (unsigned)((((rt * nkb + k0 + j) * 2 + hf) * 1024) + lane * 16) : 0xfffffff0u);
+}
+
+// acc += this wave's share of the k-blocks [kb_lo, kb_hi) (the eight waves split the range; at most NBW blocks per wave).
+// preloaded: the caller has already run ps_gates_prefetch<.., 0, NPRE> for this range into xa (loads issued earlier, in the shadow of
+// other work)
+template <int NBW, int RT, int DEPTH, int NPRE = DEPTH>
+__device__ __forceinline__ void ps_gates_acc(__amdgpu_buffer_rsrc_t xr, int nkb, int kb_lo, int kb_hi, const float4* __restrict__ wl, f32x4 (&acc)[RT],
+                                             float4 (&xa)[DEPTH][RT][2], bool preloaded) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nrange = kb_hi - kb_lo;
+    const int k0 = kb_lo + ((nrange * wave) >> 3), k1 = kb_lo + ((nrange * (wave + 1)) >> 3);
     // fragment (rt, kb): byte offset ((rt * nkb + kb) * 2 + hf) * 1024 + lane * 16; blocks past k1 read out of range (= 0)
     auto issue = [&](int j, int slot) {
         const int kb = k0 + j;
@@ -208,8 +226,8 @@ __device__ __forceinline__ void ps_gates_acc(__amdgpu_buffer_rsrc_t xr, int nkb,
                 xa[slot][rt][hf] = ps_ld16_sc1(xr, off);
             }
     };
-#pragma unroll
-    for (int j = 0; j < DEPTH && j < NBW; ++j) issue(j, j);
+    if (!preloaded) ps_gates_prefetch<NBW, RT, DEPTH, 0, NPRE>(xr, nkb, kb_lo, kb_hi, xa);
+    if (NPRE < DEPTH) ps_gates_prefetch<NBW, RT, DEPTH, NPRE, DEPTH>(xr, nkb, kb_lo, kb_hi, xa);
     __builtin_amdgcn_sched_barrier(0);          // keep the whole burst ahead of the first use (hipcc would sink loads next to their uses)
     // (MFMA and split VALU of one SIMD do not overlap on gfx950 with 16x16x32 tiles - measured with software-pipelined and with
     //  hand-interleaved streams: their times add, 8.2k + 5.4k cycles per phase at K = 1568, B = 64 - so the loop stays simple.)
@@ -247,9 +265,10 @@ __device__ __forceinline__ void ps_gates_store(const f32x4 (&acc)[RT], float* __
 template <int NBW, int RT, int DEPTH>
 __device__ __forceinline__ void ps_gates(__amdgpu_buffer_rsrc_t xr, int nkb, const float4* __restrict__ wl, float* __restrict__ red) {
     f32x4 acc[RT];
+    float4 xa[DEPTH][RT][2];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    ps_gates_acc<NBW, RT, DEPTH>(xr, nkb, 0, nkb, wl, acc);
+    ps_gates_acc<NBW, RT, DEPTH>(xr, nkb, 0, nkb, wl, acc, xa, false);
     ps_gates_store<RT>(acc, red);
 }
 
@@ -258,17 +277,26 @@ __device__ __forceinline__ void ps_gates_bf16(__amdgpu_buffer_rsrc_t xr, int nkb
 
 // bf16 form: the exchange holds bf16 fragments, the LDS weight slice is bf16 ([nkb][64 lanes] x 16 B), one MFMA per product
 template <int NBW, int RT>
-__device__ __forceinline__ void ps_gates_bf16_acc(__amdgpu_buffer_rsrc_t xr, int nkb, int kb_lo, int kb_hi, const uint4* __restrict__ wlb, f32x4 (&acc)[RT]) {
+__device__ __forceinline__ void ps_gates_bf16_prefetch(__amdgpu_buffer_rsrc_t xr, int nkb, int kb_lo, int kb_hi, u32x4 (&xa)[NBW][RT]) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nrange = kb_hi - kb_lo;
     const int k0 = kb_lo + ((nrange * wave) >> 3), k1 = kb_lo + ((nrange * (wave + 1)) >> 3);
-    u32x4 xa[NBW][RT];
 #pragma unroll
     for (int j = 0; j < NBW; ++j)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
             xa[j][rt] = __builtin_amdgcn_raw_buffer_load_b128(xr, (k0 + j < k1) ? (unsigned)(((rt * nkb + k0 + j) * 1024) + lane * 16) : 0xfffffff0u, 0, 16);
+}
+
+template <int NBW, int RT>
+__device__ __forceinline__ void ps_gates_bf16_acc(__amdgpu_buffer_rsrc_t xr, int nkb, int kb_lo, int kb_hi, const uint4* __restrict__ wlb, f32x4 (&acc)[RT],
+                                                  u32x4 (&xa)[NBW][RT], bool preloaded) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nrange = kb_hi - kb_lo;
+    const int k0 = kb_lo + ((nrange * wave) >> 3);
+    if (!preloaded) ps_gates_bf16_prefetch<NBW, RT>(xr, nkb, kb_lo, kb_hi, xa);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < NBW; ++j) {
@@ -285,9 +313,10 @@ __device__ __forceinline__ void ps_gates_bf16_acc(__amdgpu_buffer_rsrc_t xr, int
 template <int NBW, int RT>
 __device__ __forceinline__ void ps_gates_bf16(__amdgpu_buffer_rsrc_t xr, int nkb, const uint4* __restrict__ wlb, float* __restrict__ red) {
     f32x4 acc[RT];
+    u32x4 xa[NBW][RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    ps_gates_bf16_acc<NBW, RT>(xr, nkb, 0, nkb, wlb, acc);
+    ps_gates_bf16_acc<NBW, RT>(xr, nkb, 0, nkb, wlb, acc, xa, false);
     ps_gates_store<RT>(acc, red);
 }
 
@@ -659,6 +688,8 @@ struct PsDec {
     unsigned long long* eg;     // [64][4][128] partial-energy granules {tag, value}
     PsSync sync;
     int poll_h;                 // 1: the sample role polls its h row (pre-filled with PS_SENTINEL by the host) instead of waiting for the barrier
+    int early_h;                // 1: the h-part fragments of the next step's gates are requested inside the attention step (after the energy exchange,
+                                //    once the h barrier is seen complete) instead of behind the context barrier's arrive
 };
 
 constexpr unsigned PS_SENTINEL = 0xffffffffu;      // a NaN pattern no arithmetic produces
@@ -679,6 +710,7 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     float* cumw = Mt_s + PD_LMAX * 32;                                                  // [PD_LMAX + 64] cumulative alignment with zero halo
     uint4* Upl = reinterpret_cast<uint4*>(cumw + PD_LMAX + 64);                         // [2 col tiles][3 planes][64 lanes]
     float* vb = reinterpret_cast<float*>(Upl + 2 * 3 * 64);                             // v[32], bias[32]
+    volatile unsigned* eflag = reinterpret_cast<volatile unsigned*>(vb + 64);           // [4] workgroup-uniform decision of thread 0 (early h-part loads)
     // phase-2 scratch inside `red`
     float* hs = red;                                   // [H] query operand: the sample's h row
     float* qs = hs + 1024;                             // [32]
@@ -686,7 +718,7 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     float* wsm = es + 4 * PD_LMAX;                     // [PD_LMAX] alignment weights
     float* ctxp = wsm + PD_LMAX;                       // [ng][Dq] context partial sums
 #ifdef PS_PROF
-    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(vb + 64);
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(vb + 68);
 #endif
 #define PD_STAMP(k) PS_STAMP(stamps, 10 * (t - p.t0) + (k), tid == 0 && (t - p.t0) < 30)
 
@@ -743,14 +775,25 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     // runs in the shadow of the barrier that publishes ctx_t; only the ctx-part sits between that barrier and the cell.
     const int kb_ctx = Dm >> 5;
     f32x4 acc[RT];
-    auto gates_part = [&](int tt, int lo, int hi, auto nbw_tag) {
-        constexpr int NBWP = decltype(nbw_tag)::value;
-        if (PREC) ps_gates_bf16_acc<NBWP, RT>(xregion(tt & 1), nkb, lo, hi, reinterpret_cast<const uint4*>(wl), acc);
-        else ps_gates_acc<NBWP, RT, (NBWP < 3 ? NBWP : 3)>(xregion(tt & 1), nkb, lo, hi, wl, acc);
+    float4 xf[3][RT][2];         // fragment registers of the gate products (fp32 exchange: 3 k-blocks in flight; bf16: all 4 of a wave's share)
+    u32x4 xb[4][RT];
+    // ctx-part (k-blocks [0, kb_ctx), at most 3 per wave) / h-part (k-blocks [kb_ctx, nkb), 4 per wave) of the gates of step tt
+    auto gates_ctx = [&](int tt) {
+        if (PREC) { u32x4 x3[3][RT]; ps_gates_bf16_acc<3, RT>(xregion(tt & 1), nkb, 0, kb_ctx, reinterpret_cast<const uint4*>(wl), acc, x3, false); }
+        else ps_gates_acc<3, RT, 3>(xregion(tt & 1), nkb, 0, kb_ctx, wl, acc, xf, false);
+    };
+    constexpr int NPRE = RT >= 4 ? 2 : 3;      // k-blocks requested early (four row tiles: two, the register file has no room for a third)
+    auto gates_h_prefetch = [&](int tt) {
+        if (PREC) ps_gates_bf16_prefetch<4, RT>(xregion(tt & 1), nkb, kb_ctx, nkb, xb);
+        else ps_gates_prefetch<4, RT, 3, 0, NPRE>(xregion(tt & 1), nkb, kb_ctx, nkb, xf);
+    };
+    auto gates_h = [&](int tt, bool preloaded) {
+        if (PREC) ps_gates_bf16_acc<4, RT>(xregion(tt & 1), nkb, kb_ctx, nkb, reinterpret_cast<const uint4*>(wl), acc, xb, preloaded);
+        else ps_gates_acc<4, RT, 3, NPRE>(xregion(tt & 1), nkb, kb_ctx, nkb, wl, acc, xf, preloaded);
     };
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    gates_part(p.t0, kb_ctx, nkb, std::integral_constant<int, 4>{});
+    gates_h(p.t0, false);
 
     for (int t = p.t0; t < p.t1; ++t) {
         // ================= phase 1: attention LSTM (column role) =================
@@ -758,7 +801,7 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const size_t mo = ((size_t)t * B + rowc) * H + u;
         const unsigned hm = p.hmask ? (unsigned)p.hmask[mo] : 1u, cm = p.cmask ? (unsigned)p.cmask[mo] : 1u;
         PD_STAMP(0);
-        gates_part(t, 0, kb_ctx, std::integral_constant<int, 3>{});
+        gates_ctx(t);
         ps_gates_store<RT>(acc, red);
         PD_STAMP(1);
         __syncthreads();
@@ -775,16 +818,17 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         PD_STAMP(2);
         ps_bar_arrive(p.sync, ++epoch);
         float4 wq4[16]; float4 mem4[PD_NCM];
-        auto pd_prefetch = [&]() {
-        // operands of phase 2 that do not depend on h_{t+1}: requested behind the arrive, landing while the barrier completes.
-        // query weights (streamed from L2 every step: neither LDS nor the register file has 128 KiB to spare beside phase 1):
+        // operands of phase 2 that do not depend on h_{t+1}.  Query weights: requested behind the arrive, landing while the barrier
+        // completes (streamed from L2 every step: neither LDS nor the register file has 128 KiB to spare beside phase 1):
         // lane (a = tid >> 4, l16 = tid & 15) takes k = 64 i + 4 l16 .. + 4, i.e. 256 contiguous bytes per channel and load
         {
             const float* wq = p.w_query + (size_t)(32 * sj + (tid >> 4)) * H + 4 * (tid & 15);
 #pragma unroll
             for (int i = 0; i < 16; ++i) wq4[i] = *reinterpret_cast<const float4*>(wq + 64 * i);
         }
-        {
+        // memory columns of the context: requested after the query (they are needed three stages later; keeping them out of the query's
+        // register budget leaves room for the early h-part fragments)
+        auto pd_prefetch_mem = [&]() {
             const int c4 = tid % nc4, lg = tid / nc4;
             const float* mem = p.memory + (size_t)sbc * L * Dm + d0 + 4 * c4;
 #pragma unroll
@@ -792,9 +836,7 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 const int l = min(lg + i * ng, L - 1);
                 mem4[i] = *reinterpret_cast<const float4*>(mem + (size_t)l * Dm);
             }
-        }
         };
-        pd_prefetch();
         if (cellthr) {
             const size_t o = ((size_t)(t + 1) * B + row) * H + u;
             p.c[o] = c_state;
@@ -810,6 +852,7 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         // poll -> fetch).  The barrier itself is then waited for after the attention step, where it has long completed.
         if (!p.poll_h && !ps_bar_wait(p.sync, epoch)) return;
         PD_STAMP(3);
+        bool early = false;          // h-part fragments of step t + 1 already requested (workgroup-uniform)
 
         // ================= phase 2: attention (sample role) =================
         if (has_sample) {
@@ -846,6 +889,7 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                     if (p.q_all) p.q_all[((size_t)t * B + sb) * A + 32 * sj + (tid >> 4)] = acc;
                 }
             }
+            pd_prefetch_mem();
             __syncthreads();
             PD_STAMP(4);
             // ---- location features (MFMA, exact split) + partial energies: wave w <-> positions [16 w, 16 w + 16)
@@ -899,8 +943,14 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                     es[j2 * PD_LMAX + l] = __uint_as_float((unsigned)x);
                 }
             }
+            // Early h-part loads: by now the grid barrier of the h hand-off has normally completed (it trails the polled row by about
+            // one energy stage); thread 0 looks ONCE, without waiting.  If it has, every wave requests its first three h-part k-blocks
+            // of the next step's gates here - they travel while the softmax and the context run - and the barrier's wait is skipped.
+            if (tid == 0) eflag[0] = (p.early_h && t + 1 < p.t1 && (!p.poll_h || __hip_atomic_load(p.sync.cnt, PS_RLX, PS_AGENT) >= epoch * 8u)) ? 1u : 0u;
             __syncthreads();
             PD_STAMP(6);
+            early = eflag[0] != 0u;
+            if (early) gates_h_prefetch(t + 1);
             // ---- masked softmax over the positions (wave 0), cumulative alignment
             if (wave == 0) {
                 float e0[2], mx = -INFINITY;
@@ -949,11 +999,11 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             }
         }
         PD_STAMP(8);
-        if (p.poll_h && !ps_bar_wait(p.sync, epoch)) return;       // the h barrier of this step (complete long ago)
+        if (p.poll_h && !early && !ps_bar_wait(p.sync, epoch)) return;       // the h barrier of this step (complete long ago; `early`: seen complete)
         ps_bar_arrive(p.sync, ++epoch);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (t + 1 < p.t1) gates_part(t + 1, kb_ctx, nkb, std::integral_constant<int, 4>{});      // h_{t+1} landed one barrier ago
+        if (t + 1 < p.t1) gates_h(t + 1, early);      // h_{t+1} landed one barrier ago
         if (!ps_bar_wait(p.sync, epoch)) return;
         PD_STAMP(9);
     }
@@ -1056,6 +1106,7 @@ MTTS_API long mtts_decoder_persist_ws_bytes(int B, int L, int H, int Dm, int A) 
 
 unsigned long long* g_ps_prof = nullptr;      // timeline buffer of the micro-benchmark harness (NULL in the library)
 bool g_pdec_poll_off = false;                 // harness switch: barrier-only hand-off of h (bit-equality check of the two forms)
+bool g_pdec_early_off = false;                // harness switch: h-part fragments requested behind the context barrier's arrive only
 
 // ---- generator LSTM: kernel instance for a shape (fp32: the dataflow kernel pgen7; bf16: one barrier per step, bf16 weights in LDS)
 namespace {
@@ -1073,7 +1124,7 @@ PsInst pgen_instance(int B, int H, int precision) {
     return k;
 }
 size_t pdec_lds(int H, int Dm, int precision) {
-    size_t lds = (size_t)((Dm + H) / 32) * (precision ? 1024 : 2048) + 8 * 64 * 16 * 4 + PD_LMAX * 32 * 4 + (PD_LMAX + 64) * 4 + 2 * 3 * 64 * 16 + 64 * 4;
+    size_t lds = (size_t)((Dm + H) / 32) * (precision ? 1024 : 2048) + 8 * 64 * 16 * 4 + PD_LMAX * 32 * 4 + (PD_LMAX + 64) * 4 + 2 * 3 * 64 * 16 + 64 * 4 + 16;
 #ifdef PS_PROF
     lds += 300 * 8;
 #endif
@@ -1170,6 +1221,8 @@ int pdec_launch(const DecoderArgs& a, int t0, int t1, hipStream_t s) {
     MTTS_CHECK_HIP(hipMemsetAsync(p.eg, 0, (size_t)64 * 4 * PD_LMAX * 8, s));
     static const bool poll_on = [] { const char* e = getenv("MTTS_PDEC_POLL"); return !(e && e[0] == '0'); }();
     p.poll_h = (poll_on && !g_pdec_poll_off) ? 1 : 0;
+    static const bool early_on = [] { const char* e = getenv("MTTS_PDEC_EARLY"); return !(e && e[0] == '0'); }();
+    p.early_h = (early_on && !g_pdec_early_off) ? 1 : 0;
     if (p.poll_h)       // h rows of the steps this launch produces: sentinel until their owner's store lands
         MTTS_CHECK_HIP(hipMemsetAsync(a.h_att + (size_t)(t0 + 1) * a.B * a.H, 0xff, (size_t)(t1 - t0) * a.B * a.H * sizeof(float), s));
     const size_t lds = pdec_lds(a.H, a.Dm, a.precision);

@@ -148,7 +148,9 @@ int main(int argc, char** argv) {
         a.U = to_dev(host_rand((size_t)A * 31, 0.3f)); a.att_bias = to_dev(host_rand(A, 0.1f)); a.w_energy = to_dev(host_rand(A, 0.5f));
         std::vector<int> lens(B, L); int* dl; (void)hipMalloc(&dl, B * 4); (void)hipMemcpy(dl, lens.data(), B * 4, hipMemcpyHostToDevice); a.lengths = dl;
         a.ctx = dev_zero((size_t)(T + 1) * B * Dm); a.cum = dev_zero((size_t)(T + 1) * B * L); a.align = dev_zero((size_t)T * B * L); a.q_all = dev_zero((size_t)T * B * A);
-        // ---- the sentinel-polled hand-off of h must reproduce the barrier-only form bit for bit
+        // ---- every hand-off form must reproduce the barrier-only form bit for bit: sentinel-polled h row, early h-part loads, both
+        struct Form { const char* name; bool poll, early; };
+        const Form forms[] = {{"barrier        ", false, false}, {"polled h       ", true, false}, {"barrier + early", false, true}, {"polled + early ", true, true}};
         {
             const int Tq = T < 40 ? T : 40;
             struct Buf { const char* name; float* d; size_t n; };
@@ -156,34 +158,39 @@ int main(int argc, char** argv) {
                                 {"ctx", a.ctx, (size_t)(Tq + 1) * B * Dm}, {"cum", a.cum, (size_t)(Tq + 1) * B * L}, {"align", a.align, (size_t)Tq * B * L},
                                 {"q", a.q_all, (size_t)Tq * B * A}};
             std::vector<std::vector<float>> ref;
-            for (int pass = 0; pass < 2; ++pass) {
+            for (int pass = 0; pass < 4; ++pass) {
                 for (const Buf& b : bufs) (void)hipMemset(b.d, 0, b.n * 4);
-                g_pdec_poll_off = pass == 0;
+                g_pdec_poll_off = !forms[pass].poll; g_pdec_early_off = !forms[pass].early;
                 if (pdec_launch(a, 0, Tq, 0)) { printf("pdec_launch failed: %s\n", g_mtts_err); return 1; }
                 (void)hipDeviceSynchronize();
-                printf("pdec (%s) correctness run: status %d\n", pass ? "polled h" : "barrier", mtts_decoder_persist_status(a.persist_ws, 0));
+                printf("pdec (%s) correctness run: status %d\n", forms[pass].name, mtts_decoder_persist_status(a.persist_ws, 0));
+                size_t total_bad = 0;
                 for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); ++i) {
                     std::vector<float> h(bufs[i].n);
                     (void)hipMemcpy(h.data(), bufs[i].d, bufs[i].n * 4, hipMemcpyDeviceToHost);
-                    if (pass == 0) { ref.push_back(h); continue; }
-                    size_t bad = 0, first = 0; double asum = 0;
-                    for (size_t k = 0; k < h.size(); ++k) {
-                        asum += fabs((double)h[k]);
-                        if (memcmp(&h[k], &ref[i][k], 4) != 0 && bad++ == 0) first = k;
+                    if (pass == 0) {
+                        double asum = 0; size_t nan = 0;
+                        for (float v : h) { asum += fabs((double)v); nan += v != v; }
+                        printf("  %-6s %9zu floats, mean |x| %.4f, %zu NaN\n", bufs[i].name, h.size(), asum / h.size(), nan);
+                        ref.push_back(h); continue;
                     }
-                    printf("  %-6s %9zu floats, mean |x| %.4f: %zu differ from the barrier form%s", bufs[i].name, h.size(), asum / h.size(), bad, bad ? "" : "  OK\n");
-                    if (bad) printf(" (first at %zu: %.9g vs %.9g)  MISMATCH\n", first, h[first], ref[i][first]);
+                    size_t bad = 0, first = 0;
+                    for (size_t k = 0; k < h.size(); ++k)
+                        if (memcmp(&h[k], &ref[i][k], 4) != 0 && bad++ == 0) first = k;
+                    if (bad) printf("  %-6s %zu differ from the barrier form (first at %zu: %.9g vs %.9g)  MISMATCH\n", bufs[i].name, bad, first, h[first], ref[i][first]);
+                    total_bad += bad;
                 }
+                if (pass) printf("  -> %zu values differ from the barrier form  %s\n", total_bad, total_bad ? "MISMATCH" : "OK");
             }
         }
-        for (int variant = 0; variant < 2; ++variant) {
-            g_pdec_poll_off = variant == 0;
+        for (int variant = 0; variant < 4; ++variant) {
+            g_pdec_poll_off = !forms[variant].poll; g_pdec_early_off = !forms[variant].early;
             for (int rep = 0; rep < 3; ++rep) {
                 (void)hipEventRecord(e0, 0);
                 if (pdec_launch(a, 0, T, 0)) { printf("pdec_launch failed: %s\n", g_mtts_err); return 1; }
                 (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
                 float ms; (void)hipEventElapsedTime(&ms, e0, e1);
-                printf("pdec (%s) B=%d T=%d: %.3f ms = %.2f us per step (status %d)\n", variant ? "polled h" : "barrier ", B, T, ms, ms * 1e3 / T, mtts_decoder_persist_status(a.persist_ws, 0));
+                printf("pdec (%s) B=%d T=%d: %.3f ms = %.2f us per step (status %d)\n", forms[variant].name, B, T, ms, ms * 1e3 / T, mtts_decoder_persist_status(a.persist_ws, 0));
             }
         }
 #ifdef PS_PROF
