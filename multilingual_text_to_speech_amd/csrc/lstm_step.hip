@@ -351,6 +351,200 @@ __global__ __launch_bounds__(256) void lstm_cell_q_kernel(LsCell p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// F: the whole LSTM step of a LARGE batch (B > 64) in ONE launch - gate GEMM over the full K, cell, query partials.
+// With more than 64 rows there is enough work per launch without splitting K, and the K-split form pays for it: at batch 240 the
+// partial slabs of the two decoder LSTMs are 150 MB of write + read traffic per step (456 MB measured per decoder step against 122 MB
+// algorithmic, profiles/r04_*) and the cell needs a second launch.  Here a workgroup owns 16 LSTM units (64 unit-major gate columns =
+// four 16-column groups of the packed weight) x 32 NRT rows; wave w = (column group w & 3, row half w >> 2) walks the whole K:
+//   * weight fragments straight from the packed copy (L2: the RG row groups of a unit group are placed on ONE XCD, so every weight
+//     block crosses the fabric once per step), activation fragments straight from the row-major [B, K] operands (the four waves of a
+//     row half read the same lines: L1 hits), DEPTH k-blocks in flight;
+//   * products: precision 0 on v_mfma_f32_16x16x4_f32 - exact fp32 products, no operand split (at this size the 3-way bf16 split is
+//     VALU-bound, the fp32 matrix rate is not the limit of the step: 2.6 GFLOP = 16 us for the attention LSTM at batch 240);
+//     precision 1: activations rounded to bf16 (RNE) on the fly, bf16-packed weights, one v_mfma_f32_16x16x32_bf16 per fragment pair;
+//   * epilogue: the four gates of a unit sit in four neighbouring columns of the wave's own tile -> cell of lstm_cell_q_body through a
+//     wave-private LDS patch (no block barrier), h tile -> LDS -> query partials q_part[unit group][B][A] on fp32 MFMA (same slabs
+//     as the K-split path: the attention kernel sums H / 16 of them).
+// ---------------------------------------------------------------------------------------------------------------------------
+struct LsFused {
+    const float* x0; const float* x1; const float* x2;
+    int K0, K1, K2, ld0, ld1, ld2;
+    const void* wp; int nkb;
+    LsCell c;             // part / KS unused
+};
+
+template <int PREC, int NRT, int DEPTH>
+__global__ __launch_bounds__(LS_THREADS, 4) void lstm_fused_kernel(LsFused p) {
+    step_prio();
+    constexpr int RPW = 32 * NRT;                           // rows per workgroup
+    __shared__ __attribute__((aligned(16))) float red[8][16 * NRT][16];
+    __shared__ float hs[RPW][17];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, q4 = lane >> 4;
+    const int B = p.c.B, H = p.c.H, N = 4 * H, nug = H >> 4, RG = (int)gridDim.x / nug;
+    int ug, rg;
+    if ((nug & 7) == 0) { const int id = blockIdx.x, slot = id >> 3; ug = (id & 7) * (nug >> 3) + slot / RG; rg = slot % RG; }      // row groups of a unit group share an XCD
+    else { ug = (int)blockIdx.x / RG; rg = (int)blockIdx.x % RG; }
+    const int ct = wave & 3, rh = wave >> 2;
+    const int row0 = rg * RPW + rh * (16 * NRT);
+    const int cgrp = ug * 4 + ct;
+
+    // ---- operand streams
+    int roff[NRT];                                          // clamped row of this lane in every row tile
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) roff[rt] = min(row0 + 16 * rt + i16, B - 1);
+    float4 xa[DEPTH][NRT][2];
+    float4 wa[DEPTH][PREC ? 1 : 2];
+    auto issue = [&](int kb, int slot) {
+        int kg = 32 * kb;
+        const float* xs; int ld;
+        if (kg < p.K0) { xs = p.x0; ld = p.ld0; }
+        else if (kg < p.K0 + p.K1) { xs = p.x1; ld = p.ld1; kg -= p.K0; }
+        else { xs = p.x2; ld = p.ld2; kg -= p.K0 + p.K1; }
+        xs += kg + 8 * q4;
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) {
+            const float* xr = xs + (long)roff[rt] * ld;
+            xa[slot][rt][0] = *reinterpret_cast<const float4*>(xr);
+            xa[slot][rt][1] = *reinterpret_cast<const float4*>(xr + 4);
+        }
+        if (PREC) {
+            wa[slot][0] = reinterpret_cast<const float4*>(p.wp)[((long)cgrp * p.nkb + kb) * 64 + lane];
+        } else {
+            const float4* ws = reinterpret_cast<const float4*>(p.wp) + ((long)cgrp * p.nkb + kb) * 128 + lane;
+            wa[slot][0] = ws[0]; wa[slot][1] = ws[64];
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) if (d < p.nkb) issue(d, d);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- cell / query operands (independent of the products: requested behind the first blocks, landed long before the epilogue)
+    const LsCell& c = p.c;
+    float4 pre4[NRT]; float cp[NRT], hp[NRT]; int hm[NRT], cm[NRT];
+#pragma unroll
+    for (int n = 0; n < NRT; ++n) {
+        const int pi = lane + 64 * n, rl = pi >> 2, uu = pi & 3;
+        const int row = min(row0 + rl, B - 1), u = 16 * ug + 4 * ct + uu;
+        const long hi = (long)row * H + u;
+        pre4[n] = c.pre ? *reinterpret_cast<const float4*>(c.pre + (long)row * c.ldpre + 4 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+        cp[n] = c.c_prev[hi];
+        hp[n] = c.h_prev ? c.h_prev[hi] : 0.f;
+        hm[n] = c.hmask ? (int)c.hmask[hi] : 1;
+        cm[n] = c.cmask ? (int)c.cmask[hi] : 1;
+    }
+    constexpr int NQ = 2;                                   // query channel tiles per wave: A <= 8 waves x 2 x 16 = 256
+    const int nct = c.qpart ? c.A >> 4 : 0;
+    float4 wq4[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+        const int cta = wave + 8 * k;
+        wq4[k] = (cta < nct) ? *reinterpret_cast<const float4*>(c.wq + (long)(16 * cta + i16) * H + 16 * ug + 4 * q4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- products over the whole K
+    f32x4 acc[NRT][2];
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) { acc[rt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[rt][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int kb0 = 0; kb0 < p.nkb; kb0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int kb = kb0 + d;
+            if (kb < p.nkb) {
+                if (PREC) {
+                    Frag8 wb;
+                    wb.u[0] = __float_as_uint(wa[d][0].x); wb.u[1] = __float_as_uint(wa[d][0].y);
+                    wb.u[2] = __float_as_uint(wa[d][0].z); wb.u[3] = __float_as_uint(wa[d][0].w);
+#pragma unroll
+                    for (int rt = 0; rt < NRT; ++rt) {
+                        const float4 lo = xa[d][rt][0], hi4 = xa[d][rt][1];
+                        Frag8 a;
+                        a.u[0] = bf16_rne(lo.x) | (bf16_rne(lo.y) << 16); a.u[1] = bf16_rne(lo.z) | (bf16_rne(lo.w) << 16);
+                        a.u[2] = bf16_rne(hi4.x) | (bf16_rne(hi4.y) << 16); a.u[3] = bf16_rne(hi4.z) | (bf16_rne(hi4.w) << 16);
+                        acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, wb.v, acc[rt][0], 0, 0, 0);
+                    }
+                } else {
+                    // k of (hf, e) = 32 kb + 8 q4 + 4 hf + e on both operands; two accumulators per row tile alternate
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const float wv[4] = {wa[d][PREC ? 0 : hf].x, wa[d][PREC ? 0 : hf].y, wa[d][PREC ? 0 : hf].z, wa[d][PREC ? 0 : hf].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int rt = 0; rt < NRT; ++rt) {
+                                const float4 xv = xa[d][rt][hf];
+                                const float xe = e == 0 ? xv.x : e == 1 ? xv.y : e == 2 ? xv.z : xv.w;
+                                acc[rt][e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xe, wv[e], acc[rt][e & 1], 0, 0, 0);
+                            }
+                    }
+                }
+                if (kb + DEPTH < p.nkb) { issue(kb + DEPTH, d); __builtin_amdgcn_sched_barrier(0); }
+            }
+        }
+    }
+
+    // ---- cell: tile -> wave-private LDS patch -> (row, unit) per lane
+    float (*rw)[16] = red[wave];
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rw[16 * rt + 4 * q4 + r][i16] = acc[rt][0][r] + acc[rt][1][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int n = 0; n < NRT; ++n) {
+        const int pi = lane + 64 * n, rl = pi >> 2, uu = pi & 3;
+        const int row = row0 + rl, u = 16 * ug + 4 * ct + uu;
+        const bool valid = row < B;
+        float4 g4 = *reinterpret_cast<const float4*>(&rw[rl][4 * uu]);
+        if (c.bias_u) { const float4 b4 = *reinterpret_cast<const float4*>(c.bias_u + 4 * u); g4.x += b4.x; g4.y += b4.y; g4.z += b4.z; g4.w += b4.w; }
+        g4.x += pre4[n].x; g4.y += pre4[n].y; g4.z += pre4[n].z; g4.w += pre4[n].w;
+        const float ig = sigmoidf_(g4.x), fg = sigmoidf_(g4.y), gg = tanhf_(g4.z), og = sigmoidf_(g4.w);
+        const float cn = fg * cp[n] + ig * gg;
+        const float hn = og * tanhf_(cn);
+        float ho, co = cn;
+        if (c.zone == 1) { ho = hm[n] ? hn : hp[n]; co = cm[n] ? cn : cp[n]; }
+        else if (c.zone == 2) { ho = c.zh * hp[n] + (1.f - c.zh) * hn; co = c.zc * cp[n] + (1.f - c.zc) * cn; }
+        else ho = c.hmask ? (hm[n] ? hn * c.hscale : 0.f) : hn;
+        if (valid) {
+            const long hi = (long)row * H + u;
+            c.h_out[hi] = ho;
+            c.c_out[hi] = co;
+            if (c.gates_out) {
+                float* go = c.gates_out + (long)row * N + u;
+                go[0] = ig; go[H] = fg; go[2 * H] = gg; go[3 * H] = og;
+            }
+        }
+        hs[rh * (16 * NRT) + rl][4 * ct + uu] = valid ? ho : 0.f;
+    }
+    if (!c.qpart) return;
+    __syncthreads();
+    // ---- q_part[ug][rows of this workgroup][A] = h_tile [RPW x 16] W_q[:, 16 ug .. +16]^T (exact fp32 MFMA), wave <-> channel tiles
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+        const int cta = wave + 8 * k;
+        if (cta >= nct) break;
+        const float bv[4] = {wq4[k].x, wq4[k].y, wq4[k].z, wq4[k].w};
+#pragma unroll
+        for (int rtq = 0; rtq < RPW / 16; ++rtq) {
+            const float av[4] = {hs[16 * rtq + i16][4 * q4 + 0], hs[16 * rtq + i16][4 * q4 + 1], hs[16 * rtq + i16][4 * q4 + 2], hs[16 * rtq + i16][4 * q4 + 3]};
+            f32x4 qa = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) qa = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bv[s2], qa, 0, 0, 0);
+            float* out = c.qpart + ((long)ug * B) * c.A + 16 * cta + i16;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int orow = rg * RPW + 16 * rtq + 4 * q4 + rr;
+                if (orow < B) out[(long)orow * c.A] = qa[rr];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // Two-layer prenet of ONE free-running step in one launch (reference Prenet.forward modules/tacotron2.py:37-46 called at :181):
 //   y1 = dropout(relu(x W1^T + b1)),  y2 = dropout(relu(y1 W2^T + b2));  dropout always on (keep flags are inputs).
 // Workgroup = 16 batch rows; wave w owns output columns {16 w .. } of both layers; y1 stays in LDS.  Exact fp32 MFMA.
@@ -568,9 +762,31 @@ static int ls_set_attrs() {
     return 0;
 }
 
+// batches of more than 64 rows take the fused kernel (lstm_fused_kernel): 64-row workgroups above 128 rows, 32-row ones up to 128
+static bool ls_fused_ok(const LstmStepArgs& a) {
+    return a.B > 64 && (a.H & 15) == 0 && (!a.qpart || a.A <= 256);
+}
+
 int lstm_step_launch(const LstmStepArgs& a, hipStream_t s) {
     LsGates g; LsCell c;
     MTTS_TRY(ls_marshal(a, g, c));
+    if (ls_fused_ok(a)) {
+        LsFused f; memset(&f, 0, sizeof(f));
+        f.x0 = g.x0; f.x1 = g.x1; f.x2 = g.x2; f.K0 = g.K0; f.K1 = g.K1; f.K2 = g.K2; f.ld0 = g.ld0; f.ld1 = g.ld1; f.ld2 = g.ld2;
+        f.wp = g.wp; f.nkb = g.nkb; f.c = c;
+        const int nug = a.H / 16;
+        if (a.B > 128) {
+            const dim3 grid(nug * ((a.B + 63) / 64));
+            if (a.precision) hipLaunchKernelGGL((lstm_fused_kernel<1, 2, 3>), grid, dim3(LS_THREADS), 0, s, f);
+            else hipLaunchKernelGGL((lstm_fused_kernel<0, 2, 3>), grid, dim3(LS_THREADS), 0, s, f);
+        } else {
+            const dim3 grid(nug * ((a.B + 31) / 32));
+            if (a.precision) hipLaunchKernelGGL((lstm_fused_kernel<1, 1, 4>), grid, dim3(LS_THREADS), 0, s, f);
+            else hipLaunchKernelGGL((lstm_fused_kernel<0, 1, 4>), grid, dim3(LS_THREADS), 0, s, f);
+        }
+        MTTS_CHECK_LAUNCH("lstm_fused_kernel");
+        return 0;
+    }
     MTTS_TRY(ls_set_attrs());
     const int ntile = (4 * a.H) / LS_COLS;
     const dim3 grid(ntile * g.KS), blk(LS_THREADS);

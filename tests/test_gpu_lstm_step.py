@@ -145,3 +145,33 @@ def test_fp32_split_products_are_fp32_accurate():
     err = ((z - ref).abs() / scale).max().item()
     err_torch = (((x @ w.t()).double() - ref).abs() / scale).max().item()
     assert err <= 1.25 * err_torch + 2.0 ** -24, (err, err_torch)
+
+
+# ---- batches above 64 rows: the fused kernel (lstm_fused_kernel: full-K gate products, cell and query partials in ONE launch) ----------
+@pytest.mark.parametrize('B', [96, 128, 129, 200, 256])
+def test_fused_large_batch_step_matches_lstm_cell(B):
+    """32-row workgroups (B <= 128) and 64-row workgroups (B > 128), ragged last row group, the training operands [context | h] and
+    the three-segment operands of the free-running schedule ([prenet | context | h], [h_att | context | h_gen])."""
+    run_step(B, 1024, [288, 1024], 128, 0, seed=B)
+    run_step(B, 1024, [256, 288, 1024], 128, 0, seed=B + 1)
+    run_step(B, 1024, [1024, 288, 1024], 128, 0, seed=B + 2, with_pre=False)
+
+
+@pytest.mark.parametrize('B,H,Ks,A', [(70, 128, [128], 128), (100, 64, [96, 64], 48), (130, 256, [64, 256], 256), (65, 32, [32], 16)])
+def test_fused_large_batch_step_small_widths(B, H, Ks, A):
+    """H / 16 not a multiple of 8 (plain workgroup order instead of the XCD-aware one), A up to 256 (two query tiles per wave),
+    a single k-block, without the hoisted addend / the query."""
+    run_step(B, H, Ks, A, 0, seed=B)
+    run_step(B, H, Ks, A, 0, seed=B + 1, with_pre=False, with_q=False)
+
+
+@pytest.mark.parametrize('zone', [1, 2])
+def test_fused_large_batch_step_zoneout(zone):
+    run_step(100, 256, [64, 256], 64, 0, zone=zone, seed=13)
+    run_step(150, 256, [64, 256], 64, 0, zone=zone, seed=14)
+
+
+@pytest.mark.parametrize('B', [100, 128, 200])
+def test_fused_large_batch_step_bf16_operands(B):
+    run_step(B, 1024, [288, 1024], 128, 1, seed=B)
+    run_step(B, 1024, [256, 288, 1024], 128, 1, seed=B + 1, with_pre=False)
