@@ -376,8 +376,11 @@ struct LsFused {
 template <int PREC, int NRT, int DEPTH>
 __global__ __launch_bounds__(LS_THREADS, 4) void lstm_fused_kernel(LsFused p) {
     step_prio();
+    static_assert(DEPTH == 4 || DEPTH == 2, "the LDS double buffer follows the parity of the slot index");
     constexpr int RPW = 32 * NRT;                           // rows per workgroup
+    constexpr int XLD = PREC ? 20 : 36;                     // LDS row of a staged k-block in 4-byte words: 32 bf16 / 32 floats + pad
     __shared__ __attribute__((aligned(16))) float red[8][16 * NRT][16];
+    __shared__ __attribute__((aligned(16))) float xs[2][RPW][XLD];
     __shared__ float hs[RPW][17];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -390,34 +393,48 @@ __global__ __launch_bounds__(LS_THREADS, 4) void lstm_fused_kernel(LsFused p) {
     const int row0 = rg * RPW + rh * (16 * NRT);
     const int cgrp = ug * 4 + ct;
 
-    // ---- operand streams
-    int roff[NRT];                                          // clamped row of this lane in every row tile
-#pragma unroll
-    for (int rt = 0; rt < NRT; ++rt) roff[rt] = min(row0 + 16 * rt + i16, B - 1);
-    float4 xa[DEPTH][NRT][2];
+    // ---- operand streams.  Activations: the workgroup's [RPW rows x 32 k] block is fetched ONCE, 8 lanes per row (whole 128-byte
+    // lines; a wave reading MFMA fragments straight from the row-major operand gathers 16 rows per instruction, four waves repeat
+    // every line, and the h operand's 4 KiB row stride lands the 16 rows on one L2 channel: 44 us per launch for the loads alone at
+    // batch 240, scripts/mb/mb_lstm_fused.hip) and staged through a double-buffered LDS block; weights: fragments from the packed copy.
+    const int srow = (tid >> 3) & (RPW - 1), sch = tid & 7; // staging role: row of the block, 16-byte chunk (32-row workgroups: both
+                                                            // halves of the workgroup fetch and store the same values - no condition)
+    const int grow = min(rg * RPW + srow, B - 1);
+    float4 xg[DEPTH];
     float4 wa[DEPTH][PREC ? 1 : 2];
     auto issue = [&](int kb, int slot) {
         int kg = 32 * kb;
-        const float* xs; int ld;
-        if (kg < p.K0) { xs = p.x0; ld = p.ld0; }
-        else if (kg < p.K0 + p.K1) { xs = p.x1; ld = p.ld1; kg -= p.K0; }
-        else { xs = p.x2; ld = p.ld2; kg -= p.K0 + p.K1; }
-        xs += kg + 8 * q4;
-#pragma unroll
-        for (int rt = 0; rt < NRT; ++rt) {
-            const float* xr = xs + (long)roff[rt] * ld;
-            xa[slot][rt][0] = *reinterpret_cast<const float4*>(xr);
-            xa[slot][rt][1] = *reinterpret_cast<const float4*>(xr + 4);
-        }
+        const float* xsrc; int ld;
+        if (kg < p.K0) { xsrc = p.x0; ld = p.ld0; }
+        else if (kg < p.K0 + p.K1) { xsrc = p.x1; ld = p.ld1; kg -= p.K0; }
+        else { xsrc = p.x2; ld = p.ld2; kg -= p.K0 + p.K1; }
+#ifndef LF_NO_X          // (scripts/mb/mb_lstm_fused.hip: stream knock-outs of the timing harness)
+        xg[slot] = *reinterpret_cast<const float4*>(xsrc + (long)grow * ld + kg + 4 * sch);
+#endif
+#ifdef LF_NO_W
+        return;
+#endif
         if (PREC) {
             wa[slot][0] = reinterpret_cast<const float4*>(p.wp)[((long)cgrp * p.nkb + kb) * 64 + lane];
         } else {
             const float4* ws = reinterpret_cast<const float4*>(p.wp) + ((long)cgrp * p.nkb + kb) * 128 + lane;
-            wa[slot][0] = ws[0]; wa[slot][1] = ws[64];
+            wa[slot][0] = ws[0]; wa[slot][PREC ? 0 : 1] = ws[64];
         }
     };
+    auto stage = [&](int slot, int buf) {                   // this thread's 16 bytes of the block in `slot` -> LDS
+        const float4 v = xg[slot];
+        if (PREC) *reinterpret_cast<uint2*>(&xs[buf][srow][2 * sch]) = make_uint2(bf16_rne(v.x) | (bf16_rne(v.y) << 16), bf16_rne(v.z) | (bf16_rne(v.w) << 16));
+        else *reinterpret_cast<float4*>(&xs[buf][srow][4 * sch]) = make_float4(v.x, v.y, v.z, v.w);
+    };
+    // Every load of the stream is UNCONDITIONAL (blocks past the end re-read the last block and are never multiplied): with loads or
+    // their uses under a condition the compiler's wait-count bookkeeping gives up and waits for vmcnt(0) before every block.
+    const int last = p.nkb - 1;
+#if defined(LF_NO_X) || defined(LF_NO_W)
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) if (d < p.nkb) issue(d, d);
+    for (int d = 0; d < DEPTH; ++d) { xg[d] = make_float4(1.f, 2.f, 3.f, 4.f); wa[d][0] = make_float4(1.f, 2.f, 3.f, 4.f); wa[d][PREC ? 0 : 1] = make_float4(1.f, 2.f, 3.f, 4.f); }
+#endif
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) issue(min(d, last), d);
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- cell / query operands (independent of the products: requested behind the first blocks, landed long before the epilogue)
@@ -448,43 +465,69 @@ __global__ __launch_bounds__(LS_THREADS, 4) void lstm_fused_kernel(LsFused p) {
     f32x4 acc[NRT][2];
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt) { acc[rt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[rt][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    for (int kb0 = 0; kb0 < p.nkb; kb0 += DEPTH) {
+    auto use = [&](int d, int buf) {                        // block in weight slot d x the staged activation block in xs[buf]
+#ifdef LF_NO_MFMA
 #pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-            const int kb = kb0 + d;
-            if (kb < p.nkb) {
-                if (PREC) {
-                    Frag8 wb;
-                    wb.u[0] = __float_as_uint(wa[d][0].x); wb.u[1] = __float_as_uint(wa[d][0].y);
-                    wb.u[2] = __float_as_uint(wa[d][0].z); wb.u[3] = __float_as_uint(wa[d][0].w);
+        for (int rt = 0; rt < NRT; ++rt) acc[rt][0][0] += xs[buf][rh * (16 * NRT) + 16 * rt + i16][q4] + wa[d][0].y + wa[d][PREC ? 0 : 1].z;
+        return;
+#endif
+        if (PREC) {
+            Frag8 wb;
+            wb.u[0] = __float_as_uint(wa[d][0].x); wb.u[1] = __float_as_uint(wa[d][0].y);
+            wb.u[2] = __float_as_uint(wa[d][0].z); wb.u[3] = __float_as_uint(wa[d][0].w);
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt) {
+                const uint4 av = *reinterpret_cast<const uint4*>(&xs[buf][rh * (16 * NRT) + 16 * rt + i16][4 * q4]);      // 8 bf16: k = 8 q4 .. + 7
+                Frag8 a; a.u[0] = av.x; a.u[1] = av.y; a.u[2] = av.z; a.u[3] = av.w;
+                acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, wb.v, acc[rt][0], 0, 0, 0);
+            }
+        } else {
+            // k of (hf, e) = 32 kb + 8 q4 + 4 hf + e on both operands; two accumulators per row tile alternate
+            float4 xv[NRT][2];
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) xv[rt][hf] = *reinterpret_cast<const float4*>(&xs[buf][rh * (16 * NRT) + 16 * rt + i16][8 * q4 + 4 * hf]);
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const float wv[4] = {wa[d][PREC ? 0 : hf].x, wa[d][PREC ? 0 : hf].y, wa[d][PREC ? 0 : hf].z, wa[d][PREC ? 0 : hf].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int rt = 0; rt < NRT; ++rt) {
-                        const float4 lo = xa[d][rt][0], hi4 = xa[d][rt][1];
-                        Frag8 a;
-                        a.u[0] = bf16_rne(lo.x) | (bf16_rne(lo.y) << 16); a.u[1] = bf16_rne(lo.z) | (bf16_rne(lo.w) << 16);
-                        a.u[2] = bf16_rne(hi4.x) | (bf16_rne(hi4.y) << 16); a.u[3] = bf16_rne(hi4.z) | (bf16_rne(hi4.w) << 16);
-                        acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, wb.v, acc[rt][0], 0, 0, 0);
+                        const float xe = e == 0 ? xv[rt][hf].x : e == 1 ? xv[rt][hf].y : e == 2 ? xv[rt][hf].z : xv[rt][hf].w;
+                        acc[rt][e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xe, wv[e], acc[rt][e & 1], 0, 0, 0);
                     }
-                } else {
-                    // k of (hf, e) = 32 kb + 8 q4 + 4 hf + e on both operands; two accumulators per row tile alternate
-#pragma unroll
-                    for (int hf = 0; hf < 2; ++hf) {
-                        const float wv[4] = {wa[d][PREC ? 0 : hf].x, wa[d][PREC ? 0 : hf].y, wa[d][PREC ? 0 : hf].z, wa[d][PREC ? 0 : hf].w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-#pragma unroll
-                            for (int rt = 0; rt < NRT; ++rt) {
-                                const float4 xv = xa[d][rt][hf];
-                                const float xe = e == 0 ? xv.x : e == 1 ? xv.y : e == 2 ? xv.z : xv.w;
-                                acc[rt][e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xe, wv[e], acc[rt][e & 1], 0, 0, 0);
-                            }
-                    }
-                }
-                if (kb + DEPTH < p.nkb) { issue(kb + DEPTH, d); __builtin_amdgcn_sched_barrier(0); }
             }
         }
+    };
+    // block kb lives in global slot kb % DEPTH and in LDS buffer kb & 1 (DEPTH even: both are static in the unrolled body).
+    // Per block ONE barrier: it publishes the next block's LDS copy and retires this block's reads before that buffer is rewritten.
+    stage(0, 0);
+    __syncthreads();
+    const int nfull = (p.nkb / DEPTH) * DEPTH;
+    for (int kb0 = 0; kb0 < nfull; kb0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            stage((d + 1) % DEPTH, (d + 1) & 1);            // block kb0 + d + 1 (requested DEPTH - 1 blocks ago)
+            use(d, d & 1);
+            issue(min(kb0 + d + DEPTH, last), d);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+        }
     }
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (d < p.nkb - nfull) {                            // slots 0 .. hold the blocks nfull .. (uniform condition)
+            if (d + 1 < DEPTH) stage(d + 1, (d + 1) & 1);
+            use(d, d & 1);
+            __syncthreads();
+        }
 
+#ifdef LF_NO_EPI
+    if (row0 + i16 < B) c.h_out[(long)(row0 + i16) * H + 16 * ug + 4 * ct + q4] = acc[0][0][0] + acc[0][1][1] + acc[NRT - 1][0][2] + acc[NRT - 1][1][3];
+    return;
+#endif
     // ---- cell: tile -> wave-private LDS patch -> (row, unit) per lane
     float (*rw)[16] = red[wave];
 #pragma unroll
@@ -777,8 +820,8 @@ int lstm_step_launch(const LstmStepArgs& a, hipStream_t s) {
         const int nug = a.H / 16;
         if (a.B > 128) {
             const dim3 grid(nug * ((a.B + 63) / 64));
-            if (a.precision) hipLaunchKernelGGL((lstm_fused_kernel<1, 2, 3>), grid, dim3(LS_THREADS), 0, s, f);
-            else hipLaunchKernelGGL((lstm_fused_kernel<0, 2, 3>), grid, dim3(LS_THREADS), 0, s, f);
+            if (a.precision) hipLaunchKernelGGL((lstm_fused_kernel<1, 2, 4>), grid, dim3(LS_THREADS), 0, s, f);
+            else hipLaunchKernelGGL((lstm_fused_kernel<0, 2, 4>), grid, dim3(LS_THREADS), 0, s, f);
         } else {
             const dim3 grid(nug * ((a.B + 31) / 32));
             if (a.precision) hipLaunchKernelGGL((lstm_fused_kernel<1, 1, 4>), grid, dim3(LS_THREADS), 0, s, f);

@@ -141,7 +141,10 @@ __device__ __forceinline__ void bwd_prefetch(const SkinnyArgs& p, int row, int u
     f.valid = valid;
     const int r = valid ? row : 0, uu = valid ? u : 0;
     const long hi = (long)r * p.H + uu;
-    float e = p.dh_a ? p.dh_a[(long)r * p.ld_dh_a + uu] : 0.f;
+    f.len = p.lengths ? p.lengths[r] : 0x7fffffff;
+    // packed-sequence semantics (reference modules/encoder.py:41-44: pad_packed_sequence): the output at a padded position is a
+    // constant zero, so the upstream gradient of a carried step is dropped - only the recurrent / carried parts pass through
+    float e = (p.dh_a && p.t < f.len) ? p.dh_a[(long)r * p.ld_dh_a + uu] : 0.f;
     if (p.dh_b) e += p.dh_b[hi];
     float parts[MAX_PART];
 #pragma unroll
@@ -156,7 +159,6 @@ __device__ __forceinline__ void bwd_prefetch(const SkinnyArgs& p, int row, int u
     f.cp = p.c_prev[hi];
     f.hm = p.hmask ? (int)p.hmask[hi] : 1;
     f.cm = p.cmask ? (int)p.cmask[hi] : 1;
-    f.len = p.lengths ? p.lengths[r] : 0x7fffffff;
 }
 
 template <int MT>

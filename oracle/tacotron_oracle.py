@@ -43,11 +43,66 @@ def _r(x, site):
     return x.to(torch.bfloat16).to(torch.float32) if site in BF16_SITES else x
 
 
+# Backward of the bf16-operand mode.  The product's BATCHED backward GEMMs round their operands as well (dY, and the W / X they multiply it
+# with); its per-step recurrence products (decoder LSTM input gradients, attention) stay fp32.  `BF16_BWD_SITES` lists the sites whose
+# input AND weight gradient come from rounded operands; for the sites in `BF16_BWD_WGRAD_ONLY` (the decoder LSTMs: weight gradients are
+# batched GEMMs, input gradients per-step fp32 products) only the weight gradient does.  Empty (default): plain autograd through the
+# forward rounding (straight-through).  Test infrastructure only, like everything in this file.
+BF16_BWD_SITES = frozenset()
+BF16_BWD_WGRAD_ONLY = frozenset()
+
+
+def _rb(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+class _RoundedLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, wgrad_only):
+        xr, wr = _rb(x), _rb(w)
+        ctx.save_for_backward(xr, wr)
+        ctx.wgrad_only = wgrad_only
+        return F.linear(xr, wr)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xr, wr = ctx.saved_tensors
+        dyr = _rb(dy)
+        dx = (dy if ctx.wgrad_only else dyr) @ wr
+        dw = dyr.reshape(-1, dyr.shape[-1]).t() @ xr.reshape(-1, xr.shape[-1])
+        return dx, dw, None
+
+
+class _RoundedConv1d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, dilation, groups):
+        xr, wr = _rb(x), _rb(w)
+        ctx.save_for_backward(xr, wr)
+        ctx.cfg = (dilation, groups)
+        return F.conv1d(xr, wr, None, 1, 0, dilation, groups)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xr, wr = ctx.saved_tensors
+        dilation, groups = ctx.cfg
+        dyr = _rb(dy)
+        dx = torch.nn.grad.conv1d_input(xr.shape, wr, dyr, 1, 0, dilation, groups)
+        dw = torch.nn.grad.conv1d_weight(xr, wr.shape, dyr, 1, 0, dilation, groups)
+        return dx, dw, None, None
+
+
 def _lin(site, x, w, b=None):
+    if site in BF16_SITES and (site in BF16_BWD_SITES or site in BF16_BWD_WGRAD_ONLY):
+        y = _RoundedLinear.apply(x, w, site in BF16_BWD_WGRAD_ONLY)
+        return y if b is None else y + b
     return F.linear(_r(x, site), _r(w, site), b)
 
 
 def _conv(site, x, w, *args):
+    if site in BF16_SITES and site in BF16_BWD_SITES:
+        bias, stride, padding, dilation, groups = args
+        assert bias is None and stride == 1 and padding == 0
+        return _RoundedConv1d.apply(x, w, dilation, groups)
     return F.conv1d(_r(x, site), _r(w, site), *args)
 
 
@@ -133,12 +188,14 @@ def generated_conv_block(sd, prefix, e, x, in_ch, out_ch, kernel, activation, ma
     (modules/generated.py:34-42) and BatchNorm1dGenerated (modules/generated.py:71-96, eps 1e-8)."""
     x = _same_pad(x, kernel, dilation)
     cp = prefix + '._convolution'
-    eb = F.linear(e, sd[cp + '._bottleneck.weight'], sd[cp + '._bottleneck.bias'])
+    # bf16-operand mode: the bottleneck Linears and the BN affine Linear are library GEMMs (site 'linear'), the kernel generator
+    # itself (mtts_gen_params_fwd) is an fp32 kernel - not rounded -, the grouped convolution is a GEMM (site 'conv')
+    eb = _lin('linear', e, sd[cp + '._bottleneck.weight'], sd[cp + '._bottleneck.bias'])
     w = F.linear(eb, sd[cp + '._kernel.weight'], sd[cp + '._kernel.bias']).view(out_ch, in_ch // groups, kernel)
-    x = F.conv1d(x, w, None, 1, 0, dilation, groups)
+    x = _conv('conv', x, w, None, 1, 0, dilation, groups)
     rp = prefix + '._regularizer'
-    er = F.linear(e, sd[rp + '._bottleneck.weight'], sd[rp + '._bottleneck.bias'])
-    affine = F.linear(er, sd[rp + '._affine.weight'], sd[rp + '._affine.bias'])
+    er = _lin('linear', e, sd[rp + '._bottleneck.weight'], sd[rp + '._bottleneck.bias'])
+    affine = _lin('linear', er, sd[rp + '._affine.weight'], sd[rp + '._affine.bias'])
     nf = out_ch // groups
     scale = affine[:, :nf].contiguous().view(-1)
     bias = affine[:, nf:].contiguous().view(-1)

@@ -146,11 +146,15 @@ def test_train_step_gradients_match_oracle_at_real_widths(preset, B, L, T, over)
     run_train_step_case(preset, B, L, T, over)
 
 
-BF16_GRAD_TOL = 1e-2          # relative L2 per parameter tensor (see run_train_step_case)
+# bf16 gradients against the same-rounding oracle: relative L2 per parameter tensor.  The error is NOT made in the backward: the post-net
+# output of the two runs already differs by ~1 % (tolerance 2e-2 above: rounding flips amplified by five batch norms), so d(loss)/d(post)
+# and with it EVERY gradient carries that relative difference in a random direction (observed: norm ratio 1.000 +- 0.003,
+# 1 - cosine 1.1e-4 for every tensor = 1.5e-2 relative L2).  3e-2 bounds it; a wrong kernel is off by O(1) in some tensor.
+BF16_GRAD_TOL = 3e-2
 BF16_ORACLE_SITES = frozenset({'conv', 'bilstm_in', 'lstm', 'memory', 'loc', 'prenet', 'proj', 'linear'})
 
 
-def run_train_step_case(preset, B, L, T, over, check_grads=True, ragged=None, teacher=None, bf16=False):
+def run_train_step_case(preset, B, L, T, over, check_grads=True, ragged=None, teacher=None, bf16=False, seed=9):
     """One train-mode step of the product on the GPU against the CPU oracle with identical dropout draws: outputs, loss and
     (check_grads) the gradient of every parameter.  Shared by the chunk-boundary tests in test_gpu_chunks.py."""
     from multilingual_text_to_speech_amd.params import presets, Params as hp
@@ -159,7 +163,7 @@ def run_train_step_case(preset, B, L, T, over, check_grads=True, ragged=None, te
     presets.apply(preset, speaker_number=7, **over)
     torch.manual_seed(1)
     model = Tacotron().train()
-    text, tl, target, tgl, spk, lang = _random_batch(hp, B, L, T, seed=9, ragged=(L >= 4) if ragged is None else ragged)
+    text, tl, target, tgl, spk, lang = _random_batch(hp, B, L, T, seed=seed, ragged=(L >= 4) if ragged is None else ragged)
     stop_t = torch.zeros(B, T)
     for b in range(B):
         stop_t[b, max(int(tgl[b]) - hp.stop_frames, 0):] = 1.0
@@ -206,14 +210,17 @@ def run_train_step_case(preset, B, L, T, over, check_grads=True, ragged=None, te
             om[k] = mult(v, hp.dropout).permute(0, 2, 1)
     torch.set_flush_denormal(True)               # CPU speed only: identical output (SURVEY 8c recipe 5)
     O.BF16_SITES = BF16_ORACLE_SITES if bf16 else frozenset()      # bf16 path: the oracle rounds the same contraction operands
+    if bf16 and check_grads:      # ... and its backward rounds what the product's batched backward GEMMs round (see oracle._RoundedLinear)
+        O.BF16_BWD_SITES = BF16_ORACLE_SITES - {'lstm', 'loc'}
+        O.BF16_BWD_WGRAD_ONLY = frozenset({'lstm'})
     try:
         with torch.set_grad_enabled(check_grads):
             ref = O.tacotron_forward(sd, cfg, text, tl, target, tgl, spk, lang, torch.tensor(teacher), om, True)
             rloss, _ = O.tacotron_loss(cfg, ref, tl, tgl, target, stop_t, spk, hp.guided_attention_toleration)
+        if check_grads:
+            rloss.backward()
     finally:
-        O.BF16_SITES = frozenset()
-    if check_grads:
-        rloss.backward()
+        O.BF16_SITES = O.BF16_BWD_SITES = O.BF16_BWD_WGRAD_ONLY = frozenset()
 
     # ---- HIP
     model.cuda()
@@ -238,6 +245,10 @@ def run_train_step_case(preset, B, L, T, over, check_grads=True, ragged=None, te
         # encoder output, decoder mels and alignments: 2e-3.  The post-net output sits behind five more conv + batch-norm (batch
         # statistics) + tanh layers of a random-init model, which amplify the decoder's residual ~10x (observed 5.7e-3): 2e-2.
         tol = {'encoder': 2e-3, 'pre': 2e-3, 'alignment': 2e-3, 'post': 2e-2}
+        if hp.encoder_type == 'generated':
+            # 14 generated conv blocks, each with a batch norm over (B / G) * L rows: a flipped operand rounding is amplified layer by
+            # layer like behind the post-net (observed 4.8e-3 on the encoder output, 2.2e-3 on the decoder mels at B = 40, L = 30)
+            tol.update(encoder=8e-3, pre=4e-3)
         assert all(v[0] <= tol[k] for k, v in errs.items()), f'{preset} B={B} T={T} bf16: {errs}'
         assert (post.detach().cpu() - ref['post'].detach()).abs().max().item() > 0      # (not bit-identical: different summation order)
         if not check_grads:
@@ -256,15 +267,21 @@ def run_train_step_case(preset, B, L, T, over, check_grads=True, ragged=None, te
         finally:
             _C.set_precision('fp32')
         assert abs(loss.item() - rloss.item()) <= 2e-3 * max(1.0, abs(rloss.item()))
-        worst = {}
+        worst, shape = {}, {}
         for k, p in model.named_parameters():
             r = sd[k].grad
             assert r is not None and p.grad is not None, k
-            d = (p.grad.cpu() - r).double()
-            worst[k] = (d.norm() / r.double().norm().clamp_min(1e-12)).item()
+            g64, r64 = p.grad.cpu().double().flatten(), r.double().flatten()
+            worst[k] = ((g64 - r64).norm() / r64.norm().clamp_min(1e-12)).item()
+            shape[k] = (round((g64.norm() / r64.norm().clamp_min(1e-12)).item(), 5),
+                        round(1.0 - (torch.dot(g64, r64) / (g64.norm() * r64.norm()).clamp_min(1e-30)).item(), 7))
         top = sorted(worst.items(), key=lambda kv: -kv[1])[:6]
-        print('bf16 gradients vs bf16-operand oracle, worst relative L2:', [(k, round(v, 5)) for k, v in top])
-        bad = {k: v for k, v in worst.items() if v > BF16_GRAD_TOL}
+        print('bf16 gradients vs bf16-operand oracle, worst relative L2 (norm ratio, 1 - cosine):', [(k, round(v, 5), shape[k]) for k, v in top])
+        # generated encoder: the gradients of the parameter GENERATORS (tens of values that steer whole convolution kernels through
+        # 14 batch-normed layers) see the forward's 5e-3 encoder difference amplified: observed up to 6.6e-2 (norm ratio 1.03,
+        # 1 - cosine 1.8e-3) on a bottleneck bias at B = 40 - bounded at 1.5e-1, still an order below a wrong kernel's O(1)
+        gtol, ntol, ctol = (1.5e-1, 8e-2, 1e-2) if hp.encoder_type == 'generated' else (BF16_GRAD_TOL, 2e-2, 5e-4)
+        bad = {k: (v, shape[k]) for k, v in worst.items() if v > gtol or abs(shape[k][0] - 1.0) > ntol or shape[k][1] > ctol}
         assert not bad, f'{preset} B={B} T={T} bf16 gradients: {bad}'
         return
     crit = TacotronLoss(hp.guided_attention_steps, hp.guided_attention_toleration, hp.guided_attention_gain)
@@ -278,12 +295,15 @@ def run_train_step_case(preset, B, L, T, over, check_grads=True, ragged=None, te
     assert abs(loss.item() - rloss.item()) <= 1e-4 * max(1.0, abs(rloss.item()))
     if not check_grads:
         return
+    bad = []
     for k, p in model.named_parameters():
         r = sd[k].grad
         assert r is not None and p.grad is not None, k
         err = (p.grad.cpu() - r).abs().max().item()
         tol = 1e-3 * r.abs().max().item() + 2e-5
-        assert err <= tol, f'{preset}/{k}: max |delta| {err:.3e} > {tol:.3e}'
+        if err > tol:
+            bad.append(f'{k}: max |delta| {err:.3e} > {tol:.3e}')
+    assert not bad, f'{preset} B={B} L={L} T={T}: {len(bad)} gradients off: ' + '; '.join(bad[:12])
 
 
 @pytest.mark.parametrize('preset,B', [('generated_switching', 40), ('shared_training', 72)])
