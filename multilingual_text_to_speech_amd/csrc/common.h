@@ -79,6 +79,7 @@ int gemm_plain(const float* A, const float* B, float* C, int M, int N, int K, in
                bool tB, float alpha, float beta, const float* bias, int act, hipStream_t s);
 int skinny_launch(const SkinnyArgs& p, hipStream_t s);
 int attn_step_launch(const AttnStepArgs& p, hipStream_t s);
+int attn_step_nch(int B, int L, int A, int Dm, int ksz, int kq);
 int attn_pl_init(const float* Mt, const float* bias, float* PL, long total, int A, hipStream_t s);
 int copy2d(const float* in, float* out, int rows, int cols, int ldi, int ldo, hipStream_t s);
 

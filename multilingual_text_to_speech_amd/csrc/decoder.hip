@@ -304,9 +304,7 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
             q.q_out = a.q_all ? a.q_all + (long)t * B * A : nullptr;
             q.ctx_pack_out = a.ctx_p ? a.ctx_p + (long)(t + 1) * bp16(B) * Dm : nullptr;
             q.B = B; q.L = L; q.A = A; q.Dm = Dm; q.ksz = a.ksz;
-            q.nch = (Dm + 511) / 512; if (q.nch < 4 && B * 4 <= 1024) q.nch = 4;
-            { const char* e = getenv("MTTS_ATTN_NCH"); if (e && atoi(e) > 0) q.nch = atoi(e); }      // tuning knob (scripts/sweep_nch.sh)
-            if ((L + q.nch - 1) / q.nch > 64 && L <= 256) q.nch = (L + 63) / 64;      // <= 64 rows of PL_next per workgroup (MFMA path)
+            q.nch = attn_step_nch(B, L, A, Dm, a.ksz, q.kq);
             MTTS_TRY(attn_step_launch(q, s));
         }
         if (!a.fast) {
