@@ -257,30 +257,26 @@ class Tacotron(Module):
         Lmax = max(lens)
         grouped = hp.encoder_type in ('convolutional', 'generated')
         blended = hp.encoder_type in ('convolutional', 'generated', 'separate')
-        encoded = [None] * n_utt
-        lang_ids = [None] * n_utt
         with torch.no_grad():
+            memory_in, lang = None, None
             for L in sorted(set(lens)):
                 idx = [i for i in range(n_utt) if lens[i] == L]
-                text = torch.stack([texts[i].to(dev) for i in idx])
-                lw = torch.stack([languages[i].to(dev).reshape(L, -1) for i in idx]) if languages is not None else None
+                # one host -> device copy per bucket (not per utterance), one scatter of the bucket's rows into the padded memory
+                text = torch.stack([texts[i].cpu() for i in idx]).to(dev)
+                lw = torch.stack([languages[i].cpu().reshape(L, -1) for i in idx]).to(dev) if languages is not None else None
                 emb = K.embedding(self._embedding.weight, text, padding_idx=0)
                 tl = torch.full((len(idx),), L, dtype=torch.int64)
                 enc = self._encoder(emb, tl, lw, blend=True) if blended else self._encoder(emb, tl, lw)
-                ids = torch.argmax(lw, dim=2) if lw is not None else None
-                for j, i in enumerate(idx):
-                    encoded[i] = enc[j]
-                    lang_ids[i] = ids[j] if ids is not None else None
-            C = encoded[0].shape[-1]
-            memory_in = torch.zeros(n_utt, Lmax, C, device=dev)
-            lang = torch.zeros(n_utt, Lmax, dtype=torch.int64, device=dev) if languages is not None else None
+                rows = torch.as_tensor(idx, dtype=torch.int64, device=dev)
+                if memory_in is None:
+                    memory_in = torch.zeros(n_utt, Lmax, enc.shape[-1], device=dev)
+                    lang = torch.zeros(n_utt, Lmax, dtype=torch.int64, device=dev) if languages is not None else None
+                memory_in[rows, :L] = enc
+                if lang is not None:
+                    lang[rows, :L] = torch.argmax(lw, dim=2)
             spk = None
             if speakers is not None:
                 spk = torch.as_tensor([int(v) for v in speakers], dtype=torch.int64, device=dev).unsqueeze(1).expand(-1, Lmax)
-            for i in range(n_utt):
-                memory_in[i, :lens[i]] = encoded[i]
-                if lang is not None:
-                    lang[i, :lens[i]] = lang_ids[i]
             frames, n = self._decoder.inference(memory_in, spk, lang, lengths=torch.as_tensor(lens, dtype=torch.int64),
                                                 stop_threshold=stop_threshold)
             out = [None] * n_utt
