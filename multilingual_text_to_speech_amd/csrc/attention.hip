@@ -42,12 +42,8 @@ constexpr int UP_LD = 36;     // filter-bank row: 32 taps + 4 pad floats (confli
 // NE4_MAX = PL float4 per thread (L*A/4 <= NE4_MAX * ATT_THREADS): 8 covers the training shapes (L <= 128 at A = 128) inside 128
 // VGPRs, 16 covers synthesis inputs up to L = 256.
 
-// NT threads per workgroup: 512 (grid (B, nch >= 2): the workgroups of a sample repeat the energies), or 1024 for LARGE batches
-// (B >= 128: grid (B, 1 or 2) - one workgroup per sample computes everything once; at batch 240 the 960 x 512-thread grid was two
-// rounds of workgroups that each re-read the sample's whole processed memory and query slabs: 37 us per step, profiles/r04_*).
-// NCM = memory float4 per thread (ceil(L / ng)); with NT = 1024 the 16 waves own (column tile w % 8, row half w / 8) of PL_next.
-template <int G, int NE4_MAX, int NMT = 2, int NT = ATT_THREADS, int NCM = NC_MAX>     // G = A / 4 lanes per position (16 or 32); NMT 16-row tiles of PL_next per wave
-__global__ __launch_bounds__(NT) void attn_step_kernel(AttnStepArgs p) {
+template <int G, int NE4_MAX, int NMT = 2>     // G = A / 4 lanes per position (16 or 32); NMT 16-row tiles of PL_next per workgroup
+__global__ __launch_bounds__(ATT_THREADS) void attn_step_kernel(AttnStepArgs p) {
     step_prio();
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x, ch = blockIdx.y;
@@ -60,14 +56,14 @@ __global__ __launch_bounds__(NT) void attn_step_kernel(AttnStepArgs p) {
     float* w = bias + A;                 // [L]
     float* cumw = w + L;                 // [L + 64]  cum_out with zero halo / slack for the 32-tap MFMA window
     float* Up = sm + ((3 * A + 2 * L + 64 + 3) & ~3);          // [A][UP_LD]
-    float* part = Up + A * UP_LD;        // [4 * NT]
+    float* part = Up + A * UP_LD;        // [4 * ATT_THREADS]
     const int LA4 = (L * A) >> 2;
 
     // ---- geometry of this workgroup's shares
     const int dc = (((Dm + p.nch - 1) / p.nch) + 3) & ~3;
     const int d0 = ch * dc, d1 = min(Dm, d0 + dc);
     const int nc4 = max(0, (d1 - d0) >> 2);
-    const int ng = nc4 > 0 ? max(1, NT / nc4) : 1;
+    const int ng = nc4 > 0 ? max(1, ATT_THREADS / nc4) : 1;
     const int cg = nc4 > 0 ? tid / nc4 : ng, c4 = nc4 > 0 ? tid % nc4 : 0;
     const int lc = (L + p.nch - 1) / p.nch;
     const int l0 = ch * lc, l1 = min(L, l0 + lc);
@@ -76,11 +72,10 @@ __global__ __launch_bounds__(NT) void attn_step_kernel(AttnStepArgs p) {
     // ---- burst of independent loads
     const int len = min(p.lengths[b], L);
     // query partials: thread (group g = tid / A, channel a = tid % A) takes slabs g, g + ngrp, ...
-    const int q_ngrp = NT / A, q_g = tid / A, q_a = tid - q_g * A;
-    constexpr int KQP = NT > 512 ? KQ_PER / 2 : KQ_PER;      // slabs per thread: kq <= KQP * (NT / A)
-    float qp[KQP];
+    const int q_ngrp = ATT_THREADS / A, q_g = tid / A, q_a = tid - q_g * A;
+    float qp[KQ_PER];
 #pragma unroll
-    for (int k = 0; k < KQP; ++k) {
+    for (int k = 0; k < KQ_PER; ++k) {
         const int kk = q_g + k * q_ngrp;
         qp[k] = (kk < p.kq) ? p.qpart[(long)kk * p.q_ks + (long)b * A + q_a] : 0.f;
     }
@@ -91,48 +86,46 @@ __global__ __launch_bounds__(NT) void attn_step_kernel(AttnStepArgs p) {
     {
         const float4* PLb = reinterpret_cast<const float4*>(p.PL + (long)b * L * A);
 #pragma unroll
-        for (int j = 0; j < NE4_MAX; ++j) pl4[j] = PLb[min(tid + j * NT, LA4 - 1)];
+        for (int j = 0; j < NE4_MAX; ++j) pl4[j] = PLb[min(tid + j * ATT_THREADS, LA4 - 1)];
     }
-    float4 mem4[NCM];
+    float4 mem4[NC_MAX];
     {
         const float* mem = p.memory + (long)b * L * Dm + d0 + c4 * 4;
 #pragma unroll
-        for (int j = 0; j < NCM; ++j) {
+        for (int j = 0; j < NC_MAX; ++j) {
             const int l = min(cg + j * ng, L - 1);
             mem4[j] = (nc4 > 0) ? *reinterpret_cast<const float4*>(mem + (long)l * Dm) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     float mtD[NMT][4], us[NU_MAX];
-    const int nct = A >> 4;                                  // column tiles of PL_next; waves beyond them take further row halves
-    const int wcol = NT > 512 ? wave % nct : wave, wrow0 = NT > 512 ? (wave / nct) * (16 * NMT) : 0;
-    const int a_own = min(16 * wcol + i16, A - 1);
+    const int a_own = min(16 * wave + i16, A - 1);
     if (p.PL_next) {
 #pragma unroll
         for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int l = min(l0 + wrow0 + 16 * mt + 4 * q4 + r, L - 1);
+                const int l = min(l0 + 16 * mt + 4 * q4 + r, L - 1);
                 mtD[mt][r] = p.Mt[((long)b * L + l) * A + a_own];
             }
 #pragma unroll
-        for (int j = 0; j < NU_MAX; ++j) us[j] = p.U[min(tid + j * NT, A * ksz - 1)];
+        for (int j = 0; j < NU_MAX; ++j) us[j] = p.U[min(tid + j * ATT_THREADS, A * ksz - 1)];
     }
 
     // ---- q partial sums, v, bias, filter bank -> LDS
     {
         float qs = 0.f;
 #pragma unroll
-        for (int k = 0; k < KQP; ++k) qs += qp[k];
+        for (int k = 0; k < KQ_PER; ++k) qs += qp[k];
         part[tid] = qs;
     }
     if (tid < A) { vv[tid] = v_r; bias[tid] = bias_r; }
     if (p.PL_next) {
 #pragma unroll
         for (int j = 0; j < NU_MAX; ++j) {
-            const int i = tid + j * NT;
+            const int i = tid + j * ATT_THREADS;
             if (i < A * ksz) { const int a = i / ksz, jj = i - a * ksz; Up[a * UP_LD + jj] = us[j]; }
         }
-        for (int i = tid; i < A * (UP_LD - ksz); i += NT) { const int a = i / (UP_LD - ksz), jj = ksz + i % (UP_LD - ksz); Up[a * UP_LD + jj] = 0.f; }
+        for (int i = tid; i < A * (UP_LD - ksz); i += ATT_THREADS) { const int a = i / (UP_LD - ksz), jj = ksz + i % (UP_LD - ksz); Up[a * UP_LD + jj] = 0.f; }
     }
     __syncthreads();
     if (tid < A) {
@@ -150,7 +143,7 @@ __global__ __launch_bounds__(NT) void attn_step_kernel(AttnStepArgs p) {
         const float4 v4v = *reinterpret_cast<const float4*>(vv + a0);
 #pragma unroll
         for (int j = 0; j < NE4_MAX; ++j) {
-            const int i4 = tid + j * NT;
+            const int i4 = tid + j * ATT_THREADS;
             float e = v4v.x * tanhf_(q4v.x + pl4[j].x) + v4v.y * tanhf_(q4v.y + pl4[j].y) + v4v.z * tanhf_(q4v.z + pl4[j].z) +
                       v4v.w * tanhf_(q4v.w + pl4[j].w);
             e = group_sum<G>(e);
@@ -185,7 +178,7 @@ __global__ __launch_bounds__(NT) void attn_step_kernel(AttnStepArgs p) {
     {
         float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int j = 0; j < NCM; ++j) {
+        for (int j = 0; j < NC_MAX; ++j) {
             const int l = cg + j * ng;
             const float wl = (cg < ng && l < L) ? w[l] : 0.f;
             s4.x += wl * mem4[j].x; s4.y += wl * mem4[j].y; s4.z += wl * mem4[j].z; s4.w += wl * mem4[j].w;
@@ -204,30 +197,207 @@ __global__ __launch_bounds__(NT) void attn_step_kernel(AttnStepArgs p) {
     }
 
     // ---- PL for the next step, rows [l0, l1): loc = cumwin x U^T on MFMA, + M + bias
-    if (p.PL_next && (NT > 512 || 16 * wave < A)) {
+    if (p.PL_next && 16 * wave < A) {
         f32x4 acc[NMT];
 #pragma unroll
         for (int mt = 0; mt < NMT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const float4 bf = *reinterpret_cast<const float4*>(Up + (16 * wcol + i16) * UP_LD + 16 * c + 4 * q4);
+            const float4 bf = *reinterpret_cast<const float4*>(Up + (16 * wave + i16) * UP_LD + 16 * c + 4 * q4);
             const float bv[4] = {bf.x, bf.y, bf.z, bf.w};
 #pragma unroll
             for (int mt = 0; mt < NMT; ++mt) {
-                const float* cw = cumw + min(l0 + wrow0 + 16 * mt + i16, L) + 16 * c + 4 * q4;
+                const float* cw = cumw + l0 + 16 * mt + i16 + 16 * c + 4 * q4;
 #pragma unroll
                 for (int s2 = 0; s2 < 4; ++s2) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cw[s2], bv[s2], acc[mt], 0, 0, 0);
             }
         }
-        const int a = 16 * wcol + i16;
+        const int a = 16 * wave + i16;
         const float bb = bias[min(a, A - 1)];
 #pragma unroll
         for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int l = l0 + wrow0 + 16 * mt + 4 * q4 + r;
+                const int l = l0 + 16 * mt + 4 * q4 + r;
                 if (l < l1 && a < A) p.PL_next[((long)b * L + l) * A + a] = acc[mt][r] + mtD[mt][r] + bb;
             }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// large-batch kernel (B >= 128): ONE 1024-thread workgroup per sample (two when the context is too wide for one), and NO
+// processed-memory buffer: PL[l, a] = Mt[l, a] + bias[a] + loc(cum)[l, a] is formed in registers from the cumulative alignment of
+// THIS step (location filter bank on MFMA, as in the persistent kernel) right in front of the energies, instead of being written by
+// step t - 1 and read back by step t.  Per sample and step that removes the read and the write of a [L, A] array (122 KB of the
+// 353 KB at L = 120) - at batch 240 the step kernels are bandwidth bound (profiles/r04_fwd_decoder_b240_*).
+// Wave w = (column tile w % (A / 16), row group w / (A / 16)) owns the row tiles {group + ngroups j}; the partial energies of a
+// column tile are reduced over its 16 lanes (DPP) and summed over the column tiles in a fixed order by the softmax wave.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int ATT_BIG = 1024;        // threads
+constexpr int ATT_BIG_NCM = 9;       // memory float4 per thread
+constexpr int ATT_BIG_ES = 272;      // row of the partial-energy buffer (>= 16 * 16 positions + pad)
+
+template <int NTE>                   // row tiles of 16 positions per wave: L <= 16 * NTE * (16 / (A / 16))
+__global__ __launch_bounds__(ATT_BIG) void attn_step_big_kernel(AttnStepArgs p) {
+    step_prio();
+    constexpr int NT = ATT_BIG;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.x, ch = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int L = p.L, A = p.A, Dm = p.Dm, ksz = p.ksz, pad = (ksz - 1) / 2;
+    float* q = sm;                       // [A]
+    float* vv = q + A;                   // [A]
+    float* bias = vv + A;                // [A]
+    float* w = bias + A;                 // [L]
+    float* cumw = w + L;                 // [L + 64]  cum_in with zero halo / slack for the 32-tap MFMA window
+    float* Up = sm + ((3 * A + 2 * L + 64 + 3) & ~3);          // [A][UP_LD]
+    float* part = Up + A * UP_LD;        // [4 * NT]
+    float* es = part + 4 * NT;           // [A / 16][ATT_BIG_ES] partial energies per column tile
+
+    // ---- geometry
+    const int dc = (((Dm + p.nch - 1) / p.nch) + 3) & ~3;
+    const int d0 = ch * dc, d1 = min(Dm, d0 + dc);
+    const int nc4 = max(0, (d1 - d0) >> 2);
+    const int ng = nc4 > 0 ? max(1, NT / nc4) : 1;
+    const int cg = nc4 > 0 ? tid / nc4 : ng, c4 = nc4 > 0 ? tid % nc4 : 0;
+    const int i16 = lane & 15, q4 = lane >> 4;
+    const int nct = A >> 4, ngroups = (NT / 64) / nct;
+    const int wcol = wave % nct, wgrp = wave / nct;
+    const int a_own = 16 * wcol + i16;
+
+    // ---- burst of independent loads
+    const int len = min(p.lengths[b], L);
+    const int q_ngrp = NT / A, q_g = tid / A, q_a = tid - q_g * A;
+    constexpr int KQP = KQ_PER / 2;
+    float qp[KQP];
+#pragma unroll
+    for (int k = 0; k < KQP; ++k) {
+        const int kk = q_g + k * q_ngrp;
+        qp[k] = (kk < p.kq) ? p.qpart[(long)kk * p.q_ks + (long)b * A + q_a] : 0.f;
+    }
+    const float v_r = p.v[min(tid, A - 1)];
+    const float bias_r = p.bias[min(tid, A - 1)];
+    const float cum_r = p.cum_in[(long)b * L + min(tid, L - 1)];
+    float4 mem4[ATT_BIG_NCM];
+    {
+        const float* mem = p.memory + (long)b * L * Dm + d0 + c4 * 4;
+#pragma unroll
+        for (int j = 0; j < ATT_BIG_NCM; ++j) {
+            const int l = min(cg + j * ng, L - 1);
+            mem4[j] = (nc4 > 0) ? *reinterpret_cast<const float4*>(mem + (long)l * Dm) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    float mtD[NTE][4], us[NU_MAX / 2];
+#pragma unroll
+    for (int j = 0; j < NTE; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int l = min(16 * (wgrp + ngroups * j) + 4 * q4 + r, L - 1);
+            mtD[j][r] = p.Mt[((long)b * L + l) * A + a_own];
+        }
+#pragma unroll
+    for (int j = 0; j < NU_MAX / 2; ++j) us[j] = p.U[min(tid + j * NT, A * ksz - 1)];
+
+    // ---- q partial sums, v, bias, filter bank, cumulative alignment -> LDS
+    {
+        float qs = 0.f;
+#pragma unroll
+        for (int k = 0; k < KQP; ++k) qs += qp[k];
+        part[tid] = qs;
+    }
+    if (tid < A) { vv[tid] = v_r; bias[tid] = bias_r; }
+#pragma unroll
+    for (int j = 0; j < NU_MAX / 2; ++j) {
+        const int i = tid + j * NT;
+        if (i < A * ksz) { const int a = i / ksz, jj = i - a * ksz; Up[a * UP_LD + jj] = us[j]; }
+    }
+    for (int i = tid; i < A * (UP_LD - ksz); i += NT) { const int a = i / (UP_LD - ksz), jj = ksz + i % (UP_LD - ksz); Up[a * UP_LD + jj] = 0.f; }
+    if (tid < L) cumw[pad + tid] = cum_r;
+    if (tid < pad) cumw[tid] = 0.f;
+    if (tid < 64 - pad) cumw[pad + L + tid] = 0.f;
+    __syncthreads();
+    if (tid < A) {
+        float qs = 0.f;
+        for (int g = 0; g < q_ngrp; ++g) qs += part[g * A + tid];
+        q[tid] = qs;
+        if (ch == 0 && p.q_out) p.q_out[(long)b * A + tid] = qs;
+    }
+    __syncthreads();
+
+    // ---- location features on MFMA + partial energies of this wave's tiles
+    {
+        const float qa = q[a_own] + bias[a_own], va = vv[a_own];
+        float4 bf[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) bf[c] = *reinterpret_cast<const float4*>(Up + a_own * UP_LD + 16 * c + 4 * q4);
+#pragma unroll
+        for (int j = 0; j < NTE; ++j) {
+            const int l0t = 16 * (wgrp + ngroups * j);
+            if (l0t < L) {                                                       // wave-uniform
+                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const float bv[4] = {bf[c].x, bf[c].y, bf[c].z, bf[c].w};
+                    const float* cw = cumw + min(l0t + i16, L) + 16 * c + 4 * q4;
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(cw[s2], bv[s2], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = row16_sum(va * tanhf_(qa + mtD[j][r] + acc[r]));
+                    const int l = l0t + 4 * q4 + r;
+                    if (i16 == 0 && l < L) es[wcol * ATT_BIG_ES + l] = e;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- masked softmax (wave 0): energies = sum over the column tiles in a fixed order
+    if (tid < 64) {
+        float mx = -INFINITY;
+        for (int l = lane; l < L; l += 64) {
+            float e = 0.f;
+            for (int ct = 0; ct < nct; ++ct) e += es[ct * ATT_BIG_ES + l];
+            w[l] = e;
+            if (l < len) mx = fmaxf(mx, e);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int l = lane; l < L; l += 64) { const float ex = (l < len) ? __expf(w[l] - mx) : 0.f; w[l] = ex; sum += ex; }
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+        for (int l = lane; l < L; l += 64) w[l] *= inv;
+    }
+    __syncthreads();
+    if (tid < L && ch == 0) {
+        const float wl = w[tid];
+        p.w_out[(long)b * L + tid] = wl;
+        p.cum_out[(long)b * L + tid] = cum_r + wl;
+    }
+
+    // ---- context columns of this chunk (memory rows are already in registers)
+    float4* part4 = reinterpret_cast<float4*>(part);
+    {
+        float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < ATT_BIG_NCM; ++j) {
+            const int l = cg + j * ng;
+            const float wl = (cg < ng && l < L) ? w[l] : 0.f;
+            s4.x += wl * mem4[j].x; s4.y += wl * mem4[j].y; s4.z += wl * mem4[j].z; s4.w += wl * mem4[j].w;
+        }
+        part4[tid] = s4;
+    }
+    __syncthreads();
+    if (tid < nc4) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < ng; ++k) { const float4 v4 = part4[k * nc4 + tid]; t.x += v4.x; t.y += v4.y; t.z += v4.z; t.w += v4.w; }
+        *reinterpret_cast<float4*>(p.ctx_out + (long)b * Dm + d0 + tid * 4) = t;
+        if (p.ctx_pack_out) {
+            const int d = d0 + tid * 4;
+            *reinterpret_cast<float4*>(p.ctx_pack_out + ((((long)(b >> 4) * (Dm >> 4) + (d >> 4)) * 64) + 4 * (d & 12) + (b & 15)) * 4) = t;
+        }
     }
 }
 
@@ -340,19 +510,20 @@ int attn_pl_init(const float* Mt, const float* bias, float* PL, long total, int 
 }
 
 // ---- launch geometry ---------------------------------------------------------------------------------------------
-constexpr int ATT_BIG = 1024;        // threads of the large-batch form (attn_step_kernel<.., NT = 1024>)
-constexpr int ATT_BIG_NCM = 9;       // memory float4 per thread there
+static size_t att_big_lds(int A, int L) {
+    return sizeof(float) * ((((size_t)3 * A + 2 * L + 64 + 3) & ~(size_t)3) + (size_t)A * UP_LD + 4 * ATT_BIG + (size_t)(A / 16) * ATT_BIG_ES);
+}
 static size_t att_fast_lds(int A, int L, int nt) {
     return sizeof(float) * ((((size_t)3 * A + 2 * L + 64 + 3) & ~(size_t)3) + (size_t)A * UP_LD + 4 * nt);
 }
-// can the 1024-thread form take this shape with `nch` workgroups per sample?
+// can the large-batch kernel take this shape with `nch` workgroups per sample?
 static bool att_big_ok(int B, int L, int A, int Dm, int ksz, int kq, int nch) {
-    if (B < 128 || (A != 64 && A != 128) || nch < 1 || nch > 2 || L > ATT_BIG || ksz > 32 || (Dm & 3)) return false;
+    if (B < 128 || (A != 64 && A != 128) || nch < 1 || nch > 2 || L > 256 || ksz > 32 || (Dm & 3)) return false;
     const int dc = (((Dm + nch - 1) / nch) + 3) & ~3, nc4 = dc / 4;
     if (nc4 < 1 || nc4 > ATT_BIG) return false;
-    const int ng = ATT_BIG / nc4, lc = (L + nch - 1) / nch, halves = (ATT_BIG / 64) / (A / 16);
-    return (L + ng - 1) / ng <= ATT_BIG_NCM && lc <= halves * 64 && (long)L * A / 4 <= 8L * ATT_BIG && (long)A * ksz <= (long)NU_MAX * ATT_BIG &&
-           kq <= (KQ_PER / 2) * (ATT_BIG / A) && att_fast_lds(A, L, ATT_BIG) <= 64 * 1024;
+    const int ng = ATT_BIG / nc4, ngroups = (ATT_BIG / 64) / (A / 16);
+    return (L + ng - 1) / ng <= ATT_BIG_NCM && (L + 15) / 16 <= 8 * ngroups && (long)A * ksz <= (long)(NU_MAX / 2) * ATT_BIG &&
+           kq <= (KQ_PER / 2) * (ATT_BIG / A) && att_big_lds(A, L) <= 64 * 1024;
 }
 
 // workgroups per sample for a decoder step (the caller sizes nothing by it: every chunk of a sample writes its own rows / columns)
@@ -372,10 +543,10 @@ int attn_step_launch(const AttnStepArgs& p, hipStream_t s) {
     const int G = p.A / 4;
     if (att_big_ok(p.B, p.L, p.A, p.Dm, p.ksz, p.kq, p.nch)) {
         const dim3 grid(p.B, p.nch), blk(ATT_BIG);
-        const size_t lds_big = att_fast_lds(p.A, p.L, ATT_BIG);
-        if (G == 32) hipLaunchKernelGGL((attn_step_kernel<32, 8, 4, ATT_BIG, ATT_BIG_NCM>), grid, blk, lds_big, s, p);
-        else hipLaunchKernelGGL((attn_step_kernel<16, 8, 4, ATT_BIG, ATT_BIG_NCM>), grid, blk, lds_big, s, p);
-        MTTS_CHECK_LAUNCH("attn_step_kernel");
+        const int ngroups = (ATT_BIG / 64) / (p.A / 16), nte = ((p.L + 15) / 16 + ngroups - 1) / ngroups;
+        if (nte <= 4) hipLaunchKernelGGL((attn_step_big_kernel<4>), grid, blk, att_big_lds(p.A, p.L), s, p);
+        else hipLaunchKernelGGL((attn_step_big_kernel<8>), grid, blk, att_big_lds(p.A, p.L), s, p);
+        MTTS_CHECK_LAUNCH("attn_step_big_kernel");
         return 0;
     }
     const size_t lds = att_lds_bytes(p.A, p.L, p.ksz);
