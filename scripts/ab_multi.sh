@@ -1,5 +1,5 @@
 # Interleaved same-box comparison of several environment settings ("VAR=VAL VAR2=VAL2" strings, "-" = default):
-#   bash scripts/ab_multi.sh REPEATS STEPS "-" "MTTS_LS_NB=4" "MTTS_LS_NB=4 MTTS_SKINNY_LO=1"
+#   bash scripts/ab_multi.sh REPEATS STEPS "-" "MTTS_PDEC_EARLY=0" "MTTS_PERSIST=0"
 n=$1; steps=$2; shift 2
 timeout 100 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > /dev/null 2>&1     # warm the box
 for i in $(seq $n); do for cfg in "$@"; do

@@ -16,8 +16,7 @@ def main():
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'])
     args = ap.parse_args()
     out = bench.secondary_step_roofline(args.preset, args.batch, args.chars, args.frames, torch.device('cuda', 0), args.dtype)
-    print(json.dumps({k: out[k] for k in ('us_per_step', 'frac', 'achieved', 'bytes_per_step', 'dtype')} | {'batch': args.batch, 'preset': args.preset,
-                      'nch': os.environ.get('MTTS_ATTN_NCH', 'auto')}))
+    print(json.dumps({k: out[k] for k in ('us_per_step', 'frac', 'achieved', 'bytes_per_step', 'dtype')} | {'batch': args.batch, 'preset': args.preset}))
 
 
 if __name__ == '__main__':
