@@ -205,7 +205,9 @@ int mtts_pack_rows(const float* src, int ld, int rows, int K, float* dst, void* 
  *   C: gates = sum_ks P + pre + bias -> cell -> h, c, saved gates;  q_part[ut][B][A] = h[:, 16 ut..] W_q[:, 16 ut..]^T
  * Gate columns of P / pre / bias_u are UNIT-MAJOR: column 4u + g holds gate g (i,f,g,o) of unit u.
  * precision 0: fp32 operands, every product as six bf16 MFMA terms of exact 3-way splits (fp32-accurate);
- * precision 1: operands rounded to bf16 (weights stored as bf16 in the packed copy), fp32 accumulation and cell state. */
+ * precision 1: operands rounded to bf16 (weights stored as bf16 in the packed copy), fp32 accumulation and cell state;
+ * precision 2 (batches above 64 rows only: the fused step kernel; the decoder uses it above 128 rows): fp32 operands, the weights stored as three pre-split bf16 planes
+ *              (6 bytes per element), the same six-term products without a per-launch weight split. */
 typedef struct LstmPackArgs {
     const float* w[3];     /* up to 3 K-segments of the [4H, K_s] weight (row stride ldw[s]); K_s % 32 == 0 */
     int K[3];

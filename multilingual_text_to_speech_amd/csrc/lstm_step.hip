@@ -80,7 +80,7 @@ __device__ __forceinline__ float ls_pack_src(const LsPack& p, int row, int k) {
 __global__ void lstm_pack_kernel(LsPack p) {
     const long rows = (long)4 * p.H;
     const long total = rows * p.nkb * 32;
-    const long n = p.precision ? total / 8 : total / 4;          // one lane-quantum (16 B) per thread
+    const long n = p.precision ? total / 8 : total / 4;          // one lane-quantum (16 B; planes: one per plane) per thread
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
         int lane, h = 0; long rest;
         if (p.precision) { lane = (int)(t & 63); rest = t >> 6; }
@@ -90,7 +90,14 @@ __global__ void lstm_pack_kernel(LsPack p) {
         const int i = lane & 15, q = lane >> 4;
         const int row = (i & 3) * p.H + 32 * j + 4 * w + (i >> 2);
         const int k = 32 * kb + 8 * q + 4 * h;
-        if (p.precision) {
+        if (p.precision == 2) {      // exact 3-way split, planes: [col group][k-block][plane][lane] x 16 B
+            unsigned o[3][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ls_split_pair(ls_pack_src(p, row, k + 2 * e), ls_pack_src(p, row, k + 2 * e + 1), o[0][e], o[1][e], o[2][e]);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                reinterpret_cast<uint4*>(p.dst)[((jw * p.nkb + kb) * 3 + pl) * 64 + lane] = make_uint4(o[pl][0], o[pl][1], o[pl][2], o[pl][3]);
+        } else if (p.precision) {
             unsigned o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = bf16_rne(ls_pack_src(p, row, k + 2 * e)) | (bf16_rne(ls_pack_src(p, row, k + 2 * e + 1)) << 16);
@@ -378,9 +385,15 @@ __global__ __launch_bounds__(LS_THREADS, 4) void lstm_fused_kernel(LsFused p) {
     step_prio();
     static_assert(DEPTH == 4 || DEPTH == 2, "the LDS double buffer follows the parity of the slot index");
     constexpr int RPW = 32 * NRT;                           // rows per workgroup
+    // PREC 0: fp32 operands, exact products on v_mfma_f32_16x16x4_f32.  PREC 1: bf16 operands (the bf16 path).  PREC 2: fp32 operands
+    // as three exact bf16 planes - the weights pre-split ONCE per decoder call by mtts_lstm_pack_weights (precision 2), the activations
+    // split by the staging threads on their way into LDS - and six v_mfma_f32_16x16x32_bf16 terms per fragment pair (the products of
+    // csrc/gemm.hip and of the K-split step kernel: fp32-accurate): half the matrix-pipe time of the fp32 MFMA form.
+    constexpr int NPLX = PREC == 2 ? 3 : 1;                 // activation planes in LDS
+    constexpr int NWF = PREC == 2 ? 3 : (PREC ? 1 : 2);     // 16-byte weight quanta per lane and k-block
     constexpr int XLD = PREC ? 20 : 36;                     // LDS row of a staged k-block in 4-byte words: 32 bf16 / 32 floats + pad
     __shared__ __attribute__((aligned(16))) float red[8][16 * NRT][16];
-    __shared__ __attribute__((aligned(16))) float xs[2][RPW][XLD];
+    __shared__ __attribute__((aligned(16))) float xs[2][NPLX][RPW][XLD];
     __shared__ float hs[RPW][17];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -401,7 +414,7 @@ __global__ __launch_bounds__(LS_THREADS, 4) void lstm_fused_kernel(LsFused p) {
                                                             // halves of the workgroup fetch and store the same values - no condition)
     const int grow = min(rg * RPW + srow, B - 1);
     float4 xg[DEPTH];
-    float4 wa[DEPTH][PREC ? 1 : 2];
+    float4 wa[DEPTH][NWF];
     auto issue = [&](int kb, int slot) {
         int kg = 32 * kb;
         const float* xsrc; int ld;
@@ -414,24 +427,32 @@ __global__ __launch_bounds__(LS_THREADS, 4) void lstm_fused_kernel(LsFused p) {
 #ifdef LF_NO_W
         return;
 #endif
-        if (PREC) {
-            wa[slot][0] = reinterpret_cast<const float4*>(p.wp)[((long)cgrp * p.nkb + kb) * 64 + lane];
-        } else {
-            const float4* ws = reinterpret_cast<const float4*>(p.wp) + ((long)cgrp * p.nkb + kb) * 128 + lane;
-            wa[slot][0] = ws[0]; wa[slot][PREC ? 0 : 1] = ws[64];
-        }
+        const float4* ws = reinterpret_cast<const float4*>(p.wp) + ((long)cgrp * p.nkb + kb) * (64 * NWF) + lane;
+#pragma unroll
+        for (int f = 0; f < NWF; ++f) wa[slot][f] = ws[64 * f];
     };
     auto stage = [&](int slot, int buf) {                   // this thread's 16 bytes of the block in `slot` -> LDS
         const float4 v = xg[slot];
-        if (PREC) *reinterpret_cast<uint2*>(&xs[buf][srow][2 * sch]) = make_uint2(bf16_rne(v.x) | (bf16_rne(v.y) << 16), bf16_rne(v.z) | (bf16_rne(v.w) << 16));
-        else *reinterpret_cast<float4*>(&xs[buf][srow][4 * sch]) = make_float4(v.x, v.y, v.z, v.w);
+        if (PREC == 2) {
+            unsigned a1, a2, a3, b1, b2, b3;
+            ls_split_pair(v.x, v.y, a1, a2, a3);
+            ls_split_pair(v.z, v.w, b1, b2, b3);
+            *reinterpret_cast<uint2*>(&xs[buf][0][srow][2 * sch]) = make_uint2(a1, b1);
+            *reinterpret_cast<uint2*>(&xs[buf][NPLX > 1 ? 1 : 0][srow][2 * sch]) = make_uint2(a2, b2);
+            *reinterpret_cast<uint2*>(&xs[buf][NPLX > 2 ? 2 : 0][srow][2 * sch]) = make_uint2(a3, b3);
+        } else if (PREC) *reinterpret_cast<uint2*>(&xs[buf][0][srow][2 * sch]) = make_uint2(bf16_rne(v.x) | (bf16_rne(v.y) << 16), bf16_rne(v.z) | (bf16_rne(v.w) << 16));
+        else *reinterpret_cast<float4*>(&xs[buf][0][srow][4 * sch]) = make_float4(v.x, v.y, v.z, v.w);
     };
     // Every load of the stream is UNCONDITIONAL (blocks past the end re-read the last block and are never multiplied): with loads or
     // their uses under a condition the compiler's wait-count bookkeeping gives up and waits for vmcnt(0) before every block.
     const int last = p.nkb - 1;
 #if defined(LF_NO_X) || defined(LF_NO_W)
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) { xg[d] = make_float4(1.f, 2.f, 3.f, 4.f); wa[d][0] = make_float4(1.f, 2.f, 3.f, 4.f); wa[d][PREC ? 0 : 1] = make_float4(1.f, 2.f, 3.f, 4.f); }
+    for (int d = 0; d < DEPTH; ++d) {
+        xg[d] = make_float4(1.f, 2.f, 3.f, 4.f);
+#pragma unroll
+        for (int f = 0; f < NWF; ++f) wa[d][f] = make_float4(1.f, 2.f, 3.f, 4.f);
+    }
 #endif
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) issue(min(d, last), d);
@@ -468,16 +489,35 @@ __global__ __launch_bounds__(LS_THREADS, 4) void lstm_fused_kernel(LsFused p) {
     auto use = [&](int d, int buf) {                        // block in weight slot d x the staged activation block in xs[buf]
 #ifdef LF_NO_MFMA
 #pragma unroll
-        for (int rt = 0; rt < NRT; ++rt) acc[rt][0][0] += xs[buf][rh * (16 * NRT) + 16 * rt + i16][q4] + wa[d][0].y + wa[d][PREC ? 0 : 1].z;
+        for (int rt = 0; rt < NRT; ++rt) acc[rt][0][0] += xs[buf][0][rh * (16 * NRT) + 16 * rt + i16][q4] + wa[d][0].y + wa[d][NWF - 1].z;
         return;
 #endif
-        if (PREC) {
+        if (PREC == 2) {
+            Frag8 wb[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const float4 w4 = wa[d][pl < NWF ? pl : 0];
+                wb[pl].u[0] = __float_as_uint(w4.x); wb[pl].u[1] = __float_as_uint(w4.y); wb[pl].u[2] = __float_as_uint(w4.z); wb[pl].u[3] = __float_as_uint(w4.w);
+            }
+            Frag8 a[NRT][3];
+#pragma unroll
+            for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const uint4 av = *reinterpret_cast<const uint4*>(&xs[buf][pl < NPLX ? pl : 0][rh * (16 * NRT) + 16 * rt + i16][4 * q4]);
+                    a[rt][pl].u[0] = av.x; a[rt][pl].u[1] = av.y; a[rt][pl].u[2] = av.z; a[rt][pl].u[3] = av.w;
+                }
+            // six terms, small ones first (the order of gemm.hip / lstm_gates_body); the two accumulators of a row tile alternate
+#define LF_MM(PA, PB, S) _Pragma("unroll") for (int rt = 0; rt < NRT; ++rt) acc[rt][S] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[rt][PA].v, wb[PB].v, acc[rt][S], 0, 0, 0);
+            LF_MM(2, 0, 0) LF_MM(0, 2, 1) LF_MM(1, 1, 0) LF_MM(1, 0, 1) LF_MM(0, 1, 0) LF_MM(0, 0, 1)
+#undef LF_MM
+        } else if (PREC) {
             Frag8 wb;
             wb.u[0] = __float_as_uint(wa[d][0].x); wb.u[1] = __float_as_uint(wa[d][0].y);
             wb.u[2] = __float_as_uint(wa[d][0].z); wb.u[3] = __float_as_uint(wa[d][0].w);
 #pragma unroll
             for (int rt = 0; rt < NRT; ++rt) {
-                const uint4 av = *reinterpret_cast<const uint4*>(&xs[buf][rh * (16 * NRT) + 16 * rt + i16][4 * q4]);      // 8 bf16: k = 8 q4 .. + 7
+                const uint4 av = *reinterpret_cast<const uint4*>(&xs[buf][0][rh * (16 * NRT) + 16 * rt + i16][4 * q4]);      // 8 bf16: k = 8 q4 .. + 7
                 Frag8 a; a.u[0] = av.x; a.u[1] = av.y; a.u[2] = av.z; a.u[3] = av.w;
                 acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, wb.v, acc[rt][0], 0, 0, 0);
             }
@@ -487,10 +527,10 @@ __global__ __launch_bounds__(LS_THREADS, 4) void lstm_fused_kernel(LsFused p) {
 #pragma unroll
             for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf) xv[rt][hf] = *reinterpret_cast<const float4*>(&xs[buf][rh * (16 * NRT) + 16 * rt + i16][8 * q4 + 4 * hf]);
+                for (int hf = 0; hf < 2; ++hf) xv[rt][hf] = *reinterpret_cast<const float4*>(&xs[buf][0][rh * (16 * NRT) + 16 * rt + i16][8 * q4 + 4 * hf]);
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
-                const float wv[4] = {wa[d][PREC ? 0 : hf].x, wa[d][PREC ? 0 : hf].y, wa[d][PREC ? 0 : hf].z, wa[d][PREC ? 0 : hf].w};
+                const float wv[4] = {wa[d][hf < NWF ? hf : 0].x, wa[d][hf < NWF ? hf : 0].y, wa[d][hf < NWF ? hf : 0].z, wa[d][hf < NWF ? hf : 0].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -741,7 +781,7 @@ MTTS_API int mtts_lstm_step_ksplit(int k_total) { return ls_ksplit((k_total + 31
 MTTS_API long mtts_lstm_step_partial_floats(int B, int H, int k_total) { return (long)mtts_lstm_step_ksplit(k_total) * B * 4 * H; }
 
 MTTS_API long mtts_lstm_packed_weight_bytes(int H, int k_total, int precision) {
-    return (long)4 * H * k_total * (precision ? 2 : 4);
+    return (long)4 * H * k_total * (precision == 2 ? 6 : precision ? 2 : 4);
 }
 
 MTTS_API int mtts_lstm_pack_weights(const LstmPackArgs* args, void* stream) {
@@ -809,10 +849,16 @@ static int ls_set_attrs() {
 static bool ls_fused_ok(const LstmStepArgs& a) {
     return a.B > 64 && (a.H & 15) == 0 && (!a.qpart || a.A <= 256);
 }
+// weight-pack mode of a decoder LSTM step: fp32 batches above 128 rows (64-row workgroups: two row tiles per wave share every weight
+// fragment) take the weights as three pre-split bf16 planes (precision 2): 34.4 -> 31.9 us per launch at batch 240 in isolation,
+// 96 -> 85 us per decoder step (the two LSTM chains stop competing for the fp32 matrix rate).  With 32-row workgroups (one row tile per
+// wave) the six terms + 50 % more weight bytes lose against eight fp32 MFMAs: 27.9 vs 25.7 us at batch 128 - those keep precision 0.
+int ls_pack_mode(int B, int precision) { return (precision == 0 && B > 128) ? 2 : precision; }
 
 int lstm_step_launch(const LstmStepArgs& a, hipStream_t s) {
     LsGates g; LsCell c;
     MTTS_TRY(ls_marshal(a, g, c));
+    MTTS_REQUIRE(a.precision != 2 || ls_fused_ok(a), "mtts_lstm_step_fwd: precision 2 (pre-split weight planes) is the form of batches above 64 rows (B=%d)", a.B);
     if (ls_fused_ok(a)) {
         LsFused f; memset(&f, 0, sizeof(f));
         f.x0 = g.x0; f.x1 = g.x1; f.x2 = g.x2; f.K0 = g.K0; f.K1 = g.K1; f.K2 = g.K2; f.ld0 = g.ld0; f.ld1 = g.ld1; f.ld2 = g.ld2;
@@ -820,11 +866,13 @@ int lstm_step_launch(const LstmStepArgs& a, hipStream_t s) {
         const int nug = a.H / 16;
         if (a.B > 128) {
             const dim3 grid(nug * ((a.B + 63) / 64));
-            if (a.precision) hipLaunchKernelGGL((lstm_fused_kernel<1, 2, 4>), grid, dim3(LS_THREADS), 0, s, f);
+            if (a.precision == 2) hipLaunchKernelGGL((lstm_fused_kernel<2, 2, 4>), grid, dim3(LS_THREADS), 0, s, f);
+            else if (a.precision) hipLaunchKernelGGL((lstm_fused_kernel<1, 2, 4>), grid, dim3(LS_THREADS), 0, s, f);
             else hipLaunchKernelGGL((lstm_fused_kernel<0, 2, 4>), grid, dim3(LS_THREADS), 0, s, f);
         } else {
             const dim3 grid(nug * ((a.B + 31) / 32));
-            if (a.precision) hipLaunchKernelGGL((lstm_fused_kernel<1, 1, 4>), grid, dim3(LS_THREADS), 0, s, f);
+            if (a.precision == 2) hipLaunchKernelGGL((lstm_fused_kernel<2, 1, 4>), grid, dim3(LS_THREADS), 0, s, f);
+            else if (a.precision) hipLaunchKernelGGL((lstm_fused_kernel<1, 1, 4>), grid, dim3(LS_THREADS), 0, s, f);
             else hipLaunchKernelGGL((lstm_fused_kernel<0, 1, 4>), grid, dim3(LS_THREADS), 0, s, f);
         }
         MTTS_CHECK_LAUNCH("lstm_fused_kernel");

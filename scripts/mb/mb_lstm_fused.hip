@@ -2,7 +2,7 @@
 // of a large batch, per-launch time over back-to-back launches, with compile-time knock-outs that isolate the streams:
 //   -DLF_NO_X     activation fragments not loaded (constant operand)      -DLF_NO_W   weight fragments not loaded
 //   -DLF_NO_MFMA  products skipped                                        -DLF_NO_EPI no cell / query epilogue (accumulators stored raw)
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast [-DLF_...] -o mb_lstm_fused mb_lstm_fused.hip && ./mb_lstm_fused [B] [Kctx] [prec]
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast [-DLF_...] -o mb_lstm_fused mb_lstm_fused.hip && ./mb_lstm_fused [B] [Kctx] [prec: 0 fp32 MFMA, 1 bf16, 2 fp32 as pre-split bf16 planes]
 #include "../../multilingual_text_to_speech_amd/csrc/lstm_step.hip"
 #include <cstdio>
 #include <cstdlib>

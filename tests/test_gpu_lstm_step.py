@@ -60,7 +60,7 @@ def run_step(B, H, Ks, A, precision, zone=0, seed=0, with_pre=True, with_q=True)
 
     # ---- reference (fp64)
     d = lambda t: t.double()
-    if precision:
+    if precision == 1:
         rb = lambda t: t.to(torch.bfloat16).double()
         z = sum(rb(x) @ rb(w).t() for x, w in zip(xs, ws))
     else:
@@ -175,3 +175,43 @@ def test_fused_large_batch_step_zoneout(zone):
 def test_fused_large_batch_step_bf16_operands(B):
     run_step(B, 1024, [288, 1024], 128, 1, seed=B)
     run_step(B, 1024, [256, 288, 1024], 128, 1, seed=B + 1, with_pre=False)
+
+
+@pytest.mark.parametrize('B,H,Ks,A', [(96, 1024, [288, 1024], 128), (128, 1024, [256, 288, 1024], 128), (240, 1024, [544, 1024], 128),
+                                      (200, 1024, [1024, 288, 1024], 128), (70, 128, [128], 128), (130, 64, [96, 64], 48)])
+def test_fused_large_batch_step_presplit_weight_planes(B, H, Ks, A):
+    """precision 2: fp32 operands with the weights stored as three pre-split bf16 planes and the activations split on their way into
+    LDS - the six-term products of the GEMM core (fp32-accurate); what the decoder uses for every fp32 batch above 64 rows."""
+    run_step(B, H, Ks, A, 2, seed=B)
+    run_step(B, H, Ks, A, 2, seed=B + 1, with_pre=False, with_q=False, zone=2)
+
+
+def test_presplit_planes_are_fp32_accurate():
+    """The plane form against fp64 on wide-dynamic-range data, next to torch's fp32 product (cf. test_fp32_split_products_are_fp32_accurate)."""
+    g = torch.Generator().manual_seed(1)
+    B, H, K = 128, 256, 1024
+    dev = 'cuda'
+    x = (torch.randn(B, K, generator=g) * torch.exp2(torch.randint(-6, 6, (B, K), generator=g).float())).to(dev)
+    w = (torch.randn(4 * H, K, generator=g) * torch.exp2(torch.randint(-6, 6, (4 * H, K), generator=g).float())).to(dev)
+    L = lib()
+    packed = torch.empty(int(L.mtts_lstm_packed_weight_bytes(H, K, 2)), dtype=torch.uint8, device=dev)
+    pk = _C.LstmPackArgs()
+    pk.w[0], pk.K[0], pk.ldw[0], pk.nseg, pk.H, pk.precision, pk.dst = w.data_ptr(), K, K, 1, H, 2, ptr(packed)
+    check(L.mtts_lstm_pack_weights(ctypes.byref(pk), stream_ptr()), 'pack')
+    a = _C.LstmStepArgs()
+    a.x[0], a.K[0], a.ldx[0], a.nseg, a.w_packed, a.B, a.H, a.precision = x.data_ptr(), K, K, 1, ptr(packed), B, H, 2
+    part = torch.empty(int(L.mtts_lstm_step_partial_floats(B, H, K)), device=dev)
+    c_prev, h_out, c_out = torch.zeros(B, H, device=dev), torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)
+    gates = torch.empty(B, 4 * H, device=dev)
+    a.partials, a.c_prev, a.h_out, a.c_out, a.gates_out = ptr(part), ptr(c_prev), ptr(h_out), ptr(c_out), ptr(gates)
+    check(L.mtts_lstm_step_fwd(ctypes.byref(a), stream_ptr()), 'lstm_step')
+    torch.cuda.synchronize()
+    # pre-activations back from the saved (activated) input gate: logit(sigmoid(z)) - only where the sigmoid is not saturated
+    ref = x.double() @ w.double().t()
+    scale = x.double().abs() @ w.double().abs().t()
+    ig, zi = gates[:, :H].double(), ref[:, :H]
+    ok = (zi.abs() < 6)
+    z_back = torch.log(ig / (1 - ig))
+    err = (((z_back - zi).abs() / scale[:, :H])[ok]).max().item()
+    err_torch = ((((x @ w.t()).double()[:, :H] - zi).abs() / scale[:, :H])[ok]).max().item()
+    assert err <= 4.0 * err_torch + 2.0 ** -20, (err, err_torch)
