@@ -460,25 +460,31 @@ __global__ __launch_bounds__(LS_THREADS, 4) void lstm_fused_kernel(LsFused p) {
 
     // ---- cell / query operands (independent of the products: requested behind the first blocks, landed long before the epilogue)
     const LsCell& c = p.c;
-    float4 pre4[NRT]; float cp[NRT], hp[NRT]; int hm[NRT], cm[NRT];
+    // (every load unconditional - an absent operand reads a valid stand-in address and is replaced when it is used: a load under a
+    //  condition makes the compiler drain the whole stream in front of the first product)
+    float4 pre4[NRT]; float cp[NRT], hp[NRT]; unsigned hm[NRT], cm[NRT];
+    const float* pre_p = c.pre ? c.pre : c.c_prev;  const int pre_ld = c.pre ? c.ldpre : 0;
+    const float* hp_p = c.h_prev ? c.h_prev : c.c_prev;
+    const uint8_t* hm_p = c.hmask ? c.hmask : reinterpret_cast<const uint8_t*>(c.c_prev);
+    const uint8_t* cm_p = c.cmask ? c.cmask : reinterpret_cast<const uint8_t*>(c.c_prev);
 #pragma unroll
     for (int n = 0; n < NRT; ++n) {
         const int pi = lane + 64 * n, rl = pi >> 2, uu = pi & 3;
         const int row = min(row0 + rl, B - 1), u = 16 * ug + 4 * ct + uu;
         const long hi = (long)row * H + u;
-        pre4[n] = c.pre ? *reinterpret_cast<const float4*>(c.pre + (long)row * c.ldpre + 4 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+        pre4[n] = *reinterpret_cast<const float4*>(pre_p + (c.pre ? (long)row * pre_ld + 4 * u : 0));
         cp[n] = c.c_prev[hi];
-        hp[n] = c.h_prev ? c.h_prev[hi] : 0.f;
-        hm[n] = c.hmask ? (int)c.hmask[hi] : 1;
-        cm[n] = c.cmask ? (int)c.cmask[hi] : 1;
+        hp[n] = hp_p[hi];
+        hm[n] = hm_p[hi];
+        cm[n] = cm_p[hi];
     }
     constexpr int NQ = 2;                                   // query channel tiles per wave: A <= 8 waves x 2 x 16 = 256
     const int nct = c.qpart ? c.A >> 4 : 0;
     float4 wq4[NQ];
 #pragma unroll
     for (int k = 0; k < NQ; ++k) {
-        const int cta = wave + 8 * k;
-        wq4[k] = (cta < nct) ? *reinterpret_cast<const float4*>(c.wq + (long)(16 * cta + i16) * H + 16 * ug + 4 * q4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int cta = min(wave + 8 * k, max(nct - 1, 0));
+        wq4[k] = *reinterpret_cast<const float4*>((nct ? c.wq + (long)(16 * cta + i16) * H + 16 * ug + 4 * q4 : c.c_prev));
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -584,14 +590,16 @@ __global__ __launch_bounds__(LS_THREADS, 4) void lstm_fused_kernel(LsFused p) {
         const bool valid = row < B;
         float4 g4 = *reinterpret_cast<const float4*>(&rw[rl][4 * uu]);
         if (c.bias_u) { const float4 b4 = *reinterpret_cast<const float4*>(c.bias_u + 4 * u); g4.x += b4.x; g4.y += b4.y; g4.z += b4.z; g4.w += b4.w; }
-        g4.x += pre4[n].x; g4.y += pre4[n].y; g4.z += pre4[n].z; g4.w += pre4[n].w;
+        if (c.pre) { g4.x += pre4[n].x; g4.y += pre4[n].y; g4.z += pre4[n].z; g4.w += pre4[n].w; }
         const float ig = sigmoidf_(g4.x), fg = sigmoidf_(g4.y), gg = tanhf_(g4.z), og = sigmoidf_(g4.w);
         const float cn = fg * cp[n] + ig * gg;
         const float hn = og * tanhf_(cn);
+        const float hpv = c.h_prev ? hp[n] : 0.f;
+        const bool hk = !c.hmask || hm[n] != 0u, ck = !c.cmask || cm[n] != 0u;
         float ho, co = cn;
-        if (c.zone == 1) { ho = hm[n] ? hn : hp[n]; co = cm[n] ? cn : cp[n]; }
-        else if (c.zone == 2) { ho = c.zh * hp[n] + (1.f - c.zh) * hn; co = c.zc * cp[n] + (1.f - c.zc) * cn; }
-        else ho = c.hmask ? (hm[n] ? hn * c.hscale : 0.f) : hn;
+        if (c.zone == 1) { ho = hk ? hn : hpv; co = ck ? cn : cp[n]; }
+        else if (c.zone == 2) { ho = c.zh * hpv + (1.f - c.zh) * hn; co = c.zc * cp[n] + (1.f - c.zc) * cn; }
+        else ho = c.hmask ? (hk ? hn * c.hscale : 0.f) : hn;
         if (valid) {
             const long hi = (long)row * H + u;
             c.h_out[hi] = ho;
