@@ -105,6 +105,37 @@ def _blend_groups(x, x_langs, groups):
     return xr
 
 
+def _pure_languages(x_langs):
+    """Batched synthesis: the language id of every utterance whose per-character weights name ONE language for all its characters
+    (plain multilingual synthesis), or None when some utterance mixes languages (code switching)."""
+    nz = x_langs != 0
+    if not bool((nz.sum(2) == 1).all()):
+        return None
+    ids = torch.argmax(nz.to(torch.int8), dim=2)                          # [B, L]
+    if not bool((ids == ids[:, :1]).all()):
+        return None
+    return ids[:, 0]
+
+
+def _compact_groups(x, lang, groups):
+    """Utterance b goes through its OWN language group only: rows are laid out as (slot r, group g) -> row r * G + g like a training
+    batch (sample i belongs to group i mod G), groups with fewer utterances are padded with zero rows.  Returns the compact batch and
+    the row of every utterance in it.  In eval mode the blocks have no cross-sample coupling (BatchNorm uses its running statistics),
+    so an utterance's rows are exactly the rows the all-groups expansion computes for its language - the other G - 1 copies, which the
+    blend multiplies by zero, are simply not computed (5x less encoder work for 5 languages)."""
+    B = x.shape[0]
+    order = torch.argsort(lang, stable=True)
+    counts = torch.bincount(lang, minlength=groups)
+    n_max = int(counts.max())
+    starts = torch.cumsum(counts, 0) - counts
+    slot = torch.arange(B, device=x.device) - starts[lang[order]]         # position of the utterance inside its group
+    rows = torch.empty(B, dtype=torch.int64, device=x.device)
+    rows[order] = slot * groups + lang[order]
+    xc = x.new_zeros(n_max * groups, x.shape[1], x.shape[2])
+    xc[rows] = x
+    return xc, rows
+
+
 _LAYERS = [(1, 1, False), (1, 1, False)] + [(3, 3 ** i, True) for i in range(4)] * 2 + [(3, 1, True)] * 2 + [(1, 1, True)] * 2
 
 
@@ -124,14 +155,21 @@ class ConvolutionalEncoder(Module):
 
     def forward(self, x, x_lenghts=None, x_langs=None, blend=False):
         single = x_langs is not None and x_langs.shape[0] == 1 and not blend
+        rows = None
         if single:
             x = x.expand((self._groups, -1, -1))
         elif blend:
-            x = _expand_groups(x, self._groups)
+            lang = _pure_languages(x_langs) if not self.training else None
+            if lang is not None:
+                x, rows = _compact_groups(x, lang, self._groups)
+            else:
+                x = _expand_groups(x, self._groups)
         x = _to_groups(x.contiguous(), self._groups, self._input_dim)
         for n, layer in enumerate(self._layers):
             x = layer(x, f'enc.{n}')
         x = _from_groups(x, self._groups, self._output_dim)
+        if rows is not None:
+            return x[rows]
         if blend:
             return _blend_batch(x, x_langs, self._groups)
         return _blend_groups(x, x_langs, self._groups) if single else x
@@ -154,15 +192,22 @@ class GeneratedConvolutionalEncoder(Module):
 
     def forward(self, x, x_lenghts=None, x_langs=None, blend=False):
         single = x_langs is not None and x_langs.shape[0] == 1 and not blend
+        rows = None
         if single:
             x = x.expand((self._groups, -1, -1))
         elif blend:
-            x = _expand_groups(x, self._groups)
+            lang = _pure_languages(x_langs) if not self.training else None
+            if lang is not None:
+                x, rows = _compact_groups(x, lang, self._groups)
+            else:
+                x = _expand_groups(x, self._groups)
         e = K.embedding(self._embedding.weight, torch.arange(self._groups, device=x.device))
         x = _to_groups(x.contiguous(), self._groups, self._input_dim)
         for n, layer in enumerate(self._layers):
             x = layer(e, x, f'enc.{n}')
         x = _from_groups(x, self._groups, self._output_dim)
+        if rows is not None:
+            return x[rows]
         if blend:
             return _blend_batch(x, x_langs, self._groups)
         return _blend_groups(x, x_langs, self._groups) if single else x
