@@ -69,12 +69,14 @@ def test_roofline_b240_shape_forward_matches_oracle():
     run_train_step_case('generated_switching', 240, 120, 48, {}, check_grads=False)
 
 
-@pytest.mark.parametrize('preset,B,L,T', [('shared_training', 128, 40, 5), ('generated_switching', 130, 120, 4), ('shared_training', 128, 201, 3)])
-def test_large_batch_step_kernels_forward_match_oracle(preset, B, L, T):
+@pytest.mark.parametrize('preset,B,L,T,over', [('shared_training', 128, 40, 5, {}), ('generated_switching', 130, 120, 4, {}), ('shared_training', 128, 201, 3, {}),
+                                               ('shared_training', 128, 30, 3, {'attention_dimension': 64}),                 # four 16-channel tiles: four row groups
+                                               ('generated_switching', 130, 250, 2, {'attention_kernel_size': 15})])         # 16 position tiles (two workgroups per sample), short filter
+def test_large_batch_step_kernels_forward_match_oracle(preset, B, L, T, over):
     """Batches of 128 and more: the fused LSTM step (lstm_fused_kernel, 32- and 64-row workgroups) and the 1024-thread attention
     step (one workgroup per sample at Dm = 288, two at Dm = 544 or at synthesis-length inputs) - mel outputs, stop logits and
     alignments against the CPU oracle (reference Decoder._decode, modules/tacotron2.py:148-209)."""
-    run_train_step_case(preset, B, L, T, {}, check_grads=False)
+    run_train_step_case(preset, B, L, T, over, check_grads=False)
 
 
 def test_benchmark_shape_forward_matches_oracle():
