@@ -1082,6 +1082,7 @@ unsigned* ps_err_word(const DecoderArgs& a) {
     unsigned* e = a.persist_err ? (unsigned*)a.persist_err : (unsigned*)((char*)a.persist_ws + PS_ERR_OFF);
     PsDevice& D = ps_dev();
     std::lock_guard<std::mutex> lk(D.mu);
+    if (D.err_of.size() > 64) D.err_of.clear();      // callers allocate a workspace per decode: remember the recent ones only
     D.err_of[a.persist_ws] = e;
     return e;
 }
