@@ -4,6 +4,14 @@
 
 constexpr int ATB_THREADS = 512;
 
+// micro-benchmark builds only (scripts/mb/mb_attn_bwd.hip, -DATB_PROF): workgroup 0 / thread 0 stamps the shader clock per stage
+#ifdef ATB_PROF
+__device__ unsigned long long g_atb_stamps[16];
+#define ATB_STAMP(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_atb_stamps[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define ATB_STAMP(k) do { } while (0)
+#endif
+
 __device__ __forceinline__ float block_sum(float v, float* red, int tid) {
     v = wave_sum(v);
     if ((tid & 63) == 0) red[tid >> 6] = v;
@@ -29,6 +37,7 @@ constexpr int BNP_MAX = 8;    // partial slabs (fused launch, 128-VGPR budget)
 constexpr int BNX_MAX = 2;    // context floats per thread (Dm <= 1024)
 constexpr int BUP_LD = 36;    // U row (32 taps + pad)
 constexpr int BROWS = 32;     // padded row count of a chunk
+constexpr int BG_LD = 34;     // g tile row (32 taps + pad)
 
 template <int NP = BNP_MAX>
 __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& p, float* sm, const int b, const int ch) {
@@ -49,18 +58,18 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& p, float* sm, c
     float* dex = w + L;                  // [L]
     float* cumw = dex + L;               // [L + 64]
     float* de = cumw + L + 64;           // [BROWS]
-    float* dcl = de + BROWS;             // [64]
-    float* red = dcl + 64;               // [16]
+    float* red = de + BROWS;             // [16]
     float* dctx_s = red + 16;            // [Dm]
     float* Up = sm + ((5 * A + 3 * L + 64 + BROWS + 64 + 16 + Dm + 3) & ~3);     // [A][BUP_LD]   U[a][tap]
     float* UT = Up + A * BUP_LD;         // [32][DS_LD]   U^T[tap][a]
     float* dsL = UT + 32 * DS_LD;        // [BROWS][DS_LD]
+    float* gL = Up;                      // [2][BROWS][BG_LD]  g tiles of the two K halves; U[a][tap] is dead after the PL recompute
     const long slab = (long)b * p.nch + ch;
+    ATB_STAMP(0);
 
     // ---- burst of independent loads
     const int ac = min(tid, A - 1), lcl = min(tid, L - 1);
     const float q_r = p.q[(long)b * A + ac], v_r = p.v[ac], bias_r = p.bias[ac];
-    const float dvs_r = p.dv_slab[slab * A + ac], dbs_r = p.dbias_slab[slab * A + ac];
     const float w_r = p.w[(long)b * L + lcl], cum_r = p.cum_in[(long)b * L + lcl];
     const float dco_r = p.dcum_out[(long)b * L + lcl];
     const float dal_r = p.dalign ? p.dalign[(long)b * L + lcl] : 0.f;
@@ -95,31 +104,15 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& p, float* sm, c
             const long off = ((long)b * L + min(l0 + 16 * mt + 4 * q4 + r, L - 1)) * A + a_own;
             mtD[mt][r] = p.Mt[off]; dmtD[mt][r] = p.dMt[off];
         }
-    float us[BNU_MAX];
-#pragma unroll
-    for (int j = 0; j < BNU_MAX; ++j) us[j] = p.U[min(tid + j * ATB_THREADS, AK - 1)];
-    // dU slab in the accumulator layout of the dU contraction: rows a = 16*wave + 4*q4 + r, columns tap = 16*nt + i16
-    float dusD[2][4];
-    const float* dUs_in = p.dU_slab + slab * AK;
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int a = min(16 * wave + 4 * q4 + r, A - 1), jj = min(16 * nt + i16, ksz - 1);
-            dusD[nt][r] = dUs_in[a * ksz + jj];
-        }
+    // The v / bias slabs of this (sample, chunk) have ONE writer per launch: no-return float atomics at L2 give the same result as
+    // load + add + store without a load in the entry burst.  (Not so for dMt and the filter-bank slab: a million single-dword atomics per
+    // launch are L2-rate bound - 15.6 against 12.6 us per launch, scripts/mb/mb_attn_bwd.hip.)
 
     // ---- stage in LDS
     if (tid < A) { q[tid] = q_r; vv[tid] = v_r; bias[tid] = bias_r; }
     if (tid < L) { w[tid] = w_r; dex[tid] = dal_r + dco_r; cumw[pad + tid] = cum_r; }
     if (tid < pad) cumw[tid] = 0.f;
     if (tid < 64 - pad) cumw[pad + L + tid] = 0.f;
-    if (tid < 64) dcl[tid] = 0.f;
-#pragma unroll
-    for (int j = 0; j < BNU_MAX; ++j) {
-        const int i = tid + j * ATB_THREADS;
-        if (i < AK) { const int a = i / ksz, jj = i - a * ksz; Up[a * BUP_LD + jj] = us[j]; UT[jj * DS_LD + a] = us[j]; }
-    }
     for (int i = tid; i < A * (32 - ksz); i += ATB_THREADS) {      // zero taps ksz..31
         const int a = i / (32 - ksz), jj = ksz + i % (32 - ksz);
         Up[a * BUP_LD + jj] = 0.f; UT[jj * DS_LD + a] = 0.f;
@@ -135,20 +128,58 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& p, float* sm, c
         }
     }
     if (tid < L) sdot += w_r * (dal_r + dco_r);
+    sdot = wave_total_hi(sdot);
+    if (lane == 63) red[wave] = sdot;
     __syncthreads();
-    const float S = block_sum(sdot, red, tid);
+    ATB_STAMP(1);                                         // loads landed, operands staged in LDS
+    // the filter bank (the same 16 KB for every workgroup and step: L2 hits) is requested now and staged behind the dw stage, which
+    // covers its latency; in the entry burst its 8 registers per thread pushed the 128-VGPR fused launch into spills
+    float us[BNU_MAX];
+#pragma unroll
+    for (int j = 0; j < BNU_MAX; ++j) us[j] = p.U[min(tid + j * ATB_THREADS, AK - 1)];
+    float S = 0.f;                                        // softmax-backward scalar: sum_d dctx ctx + sum_l w (dalign + dcum)
+#pragma unroll
+    for (int i = 0; i < ATB_THREADS / 64; ++i) S += red[i];
+    ATB_STAMP(2);
 
     // ---- dw for the own rows (wave per row, memory rows already in registers), de = w (dw - S); padded rows -> 0
+    float dwr[BNR_MAX];                                   // select instead of branch on the Dm tail: one LDS read per k, no exec-mask regions
+#pragma unroll
+    for (int j = 0; j < BNR_MAX; ++j) dwr[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < BND_MAX; ++k) {
+        const int d = lane + 64 * k;
+        const float xr = dctx_s[min(d, Dm - 1)], x = d < Dm ? xr : 0.f;
+#pragma unroll
+        for (int j = 0; j < BNR_MAX; ++j) dwr[j] += x * memr[j][k];       // memr beyond Dm is a clamped (finite) re-read times 0
+    }
 #pragma unroll
     for (int j = 0; j < BNR_MAX; ++j) {
         const int r = wave + j * nwaves;
-        float acc = 0.f;
+        float acc = dwr[j];
+        acc = wave_total_hi(acc);
+        if (lane == 63 && r < BROWS) de[r] = (r < nl) ? w[l0 + r] * (dex[l0 + r] + acc - S) : 0.f;
+    }
 #pragma unroll
-        for (int k = 0; k < BND_MAX; ++k) { const int d = lane + 64 * k; acc += (d < Dm) ? dctx_s[d] * memr[j][k] : 0.f; }
-        acc = wave_sum(acc);
-        if (lane == 0 && r < BROWS) de[r] = (r < nl) ? w[l0 + r] * (dex[l0 + r] + acc - S) : 0.f;
+    for (int j = 0; j < BNU_MAX; ++j) {
+        const int i = tid + j * ATB_THREADS;
+        if (i < AK) { const int a = i / ksz, jj = i - a * ksz; Up[a * BUP_LD + jj] = us[j]; UT[jj * DS_LD + a] = us[j]; }
+    }
+    // dU slab in the accumulator layout of the dU contraction (rows a = 16*wave + 4*q4 + r, columns tap = 16*nt + i16): requested here,
+    // two stages ahead of its use, so that the entry burst stays inside the register budget
+    float dusD[2][4];
+    {
+        const float* dUs_in = p.dU_slab + slab * AK;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a = min(16 * wave + 4 * q4 + r, A - 1), jj = min(16 * nt + i16, ksz - 1);
+                dusD[nt][r] = dUs_in[a * ksz + jj];
+            }
     }
     __syncthreads();
+    ATB_STAMP(3);                                         // dw / de of the own rows
 
     // ---- PL recompute on MFMA, ds = de * v * (1 - tanh^2), dMt accumulation, dq / dv column sums
     if (16 * wave < A) {
@@ -186,10 +217,11 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& p, float* sm, c
         if (q4 == 0 && a < A) { accq[a] = sq; accv[a] = sv; }
     }
     __syncthreads();
+    ATB_STAMP(4);                                         // PL recompute (MFMA), tanh, ds, dMt read-modify-write, column sums
     if (tid < A) {
         atomicAdd(p.dq + (long)b * A + tid, accq[tid]);
-        p.dbias_slab[slab * A + tid] = dbs_r + accq[tid];
-        p.dv_slab[slab * A + tid] = dvs_r + accv[tid];
+        atomicAdd(p.dbias_slab + slab * A + tid, accq[tid]);
+        atomicAdd(p.dv_slab + slab * A + tid, accv[tid]);
     }
 
     // ---- dU[a, tap] += sum_rows ds[row, a] * cumwin[row][tap]      (A operand ds^T, B operand Toeplitz window)
@@ -218,7 +250,10 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& p, float* sm, c
             }
     }
 
-    // ---- g[row, tap] = sum_a ds[row, a] * U[a][tap]; dcum window: dcl[row + tap] += g.  4 tiles x 2 K-halves over 8 waves
+    ATB_STAMP(5);                                         // dq atomics, slab updates, dU contraction + slab read-modify-write
+    // ---- g[row, tap] = sum_a ds[row, a] * U[a][tap]; dcum window: dcum[row + tap] += g.  4 tiles x 2 K-halves over 8 waves; the tiles go to
+    //      LDS and the anti-diagonals are summed in a fixed order (round 4: LDS float atomics here cost 2 us per launch and made the sum
+    //      order-dependent)
     {
         const int tile = wave & 3, mt = tile >> 1, nt = tile & 1, kh = wave >> 2;
         const int nchunk = A >> 4, c_lo = kh * (nchunk >> 1), c_hi = kh ? nchunk : (nchunk >> 1);
@@ -234,15 +269,28 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& p, float* sm, c
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int rr = 16 * mt + 4 * q4 + r, jj = 16 * nt + i16;
-            if (rr < nl && jj < ksz) atomicAdd(&dcl[rr + jj], acc[r]);
+            gL[(kh * BROWS + rr) * BG_LD + jj] = acc[r];
         }
     }
     __syncthreads();
-    for (int i = tid; i < nl + ksz - 1; i += ATB_THREADS) {
+    ATB_STAMP(6);                                         // g contraction
+    {   // window position i = row + tap: 8 lanes per position, rows = sub + 8 k
+        const int i = tid >> 3, sub = tid & 7;
+        float sg = 0.f;
+#pragma unroll
+        for (int k = 0; k < BROWS / 8; ++k) {
+            const int rr = sub + 8 * k, jj = i - rr;
+            const bool ok = rr < nl && jj >= 0 && jj < ksz;
+            const int off = ok ? rr * BG_LD + jj : 0;
+            const float g0 = gL[off], g1 = gL[BROWS * BG_LD + off];
+            sg += ok ? g0 + g1 : 0.f;
+        }
+        sg += dpp_f<0xB1>(sg); sg += dpp_f<0x4E>(sg); sg += dpp_f<0x141>(sg);       // the 8 lanes of a position
         const int m = l0 - pad + i;
-        if (m >= 0 && m < L) atomicAdd(p.dcum_in + (long)b * L + m, dcl[i]);
+        if (sub == 0 && i < nl + ksz - 1 && m >= 0 && m < L) atomicAdd(p.dcum_in + (long)b * L + m, sg);
     }
     if (tid >= l0 && tid < l1) atomicAdd(p.dcum_in + (long)b * L + tid, dco_r);     // carry: cum_out = cum_in + w
+    ATB_STAMP(7);                                         // global dcum atomics issued
 }
 
 

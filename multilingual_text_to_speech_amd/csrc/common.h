@@ -113,6 +113,14 @@ __device__ __forceinline__ float row16_sum(float x) {
     x += dpp_f<0x140>(x);     // row_mirror
     return x;
 }
+// wave-wide sum on DPP alone (gfx9 row_bcast15 / row_bcast31: no LDS round trips); the total lands in lanes 48..63.  The
+// summation order differs from wave_sum's butterfly.
+__device__ __forceinline__ float wave_total_hi(float x) {
+    x = row16_sum(x);
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x142, 0xA, 0xF, false));   // lane 15 of rows 0, 2 -> rows 1, 3
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x143, 0xC, 0xF, false));   // lane 31 -> rows 2, 3
+    return x;
+}
 // sum over groups of G consecutive lanes (G = 16, 32 or 64); every lane gets its group's sum
 template <int G>
 __device__ __forceinline__ float group_sum(float x) {
