@@ -53,15 +53,30 @@ __device__ __forceinline__ float tanhf_(float x) {
     return copysignf(r, x);
 }
 
+// Wave-wide sum / max on DPP alone (quad_perm, row mirrors, gfx9 row_bcast15 / row_bcast31) + one v_readlane: no LDS round trips
+// (the __shfl_xor butterfly is six dependent ds_bpermute round trips, ~0.3 us per reduction on a lone wave - round-4 timelines of the
+// attention backward and of pdec's softmax).  Every lane gets the result.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_rows(float old, float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(x), CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_rows<0xB1, 0xF>(0.f, v);      // quad_perm [1,0,3,2]
+    v += dpp_rows<0x4E, 0xF>(0.f, v);      // quad_perm [2,3,0,1]
+    v += dpp_rows<0x141, 0xF>(0.f, v);     // row_half_mirror
+    v += dpp_rows<0x140, 0xF>(0.f, v);     // row_mirror: every lane of a 16-lane row holds the row's sum
+    v += dpp_rows<0x142, 0xA>(0.f, v);     // row_bcast15: lane 15 of rows 0, 2 -> rows 1, 3
+    v += dpp_rows<0x143, 0xC>(0.f, v);     // row_bcast31: lane 31 -> rows 2, 3; the total sits in row 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_rows<0xB1, 0xF>(v, v));
+    v = fmaxf(v, dpp_rows<0x4E, 0xF>(v, v));
+    v = fmaxf(v, dpp_rows<0x141, 0xF>(v, v));
+    v = fmaxf(v, dpp_rows<0x140, 0xF>(v, v));
+    v = fmaxf(v, dpp_rows<0x142, 0xA>(v, v));
+    v = fmaxf(v, dpp_rows<0x143, 0xC>(v, v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 
@@ -113,12 +128,11 @@ __device__ __forceinline__ float row16_sum(float x) {
     x += dpp_f<0x140>(x);     // row_mirror
     return x;
 }
-// wave-wide sum on DPP alone (gfx9 row_bcast15 / row_bcast31: no LDS round trips); the total lands in lanes 48..63.  The
-// summation order differs from wave_sum's butterfly.
+// wave_sum without the final broadcast: the total lands in lanes 48..63
 __device__ __forceinline__ float wave_total_hi(float x) {
     x = row16_sum(x);
-    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x142, 0xA, 0xF, false));   // lane 15 of rows 0, 2 -> rows 1, 3
-    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x143, 0xC, 0xF, false));   // lane 31 -> rows 2, 3
+    x += dpp_rows<0x142, 0xA>(0.f, x);
+    x += dpp_rows<0x143, 0xC>(0.f, x);
     return x;
 }
 // sum over groups of G consecutive lanes (G = 16, 32 or 64); every lane gets its group's sum

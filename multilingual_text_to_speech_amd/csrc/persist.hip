@@ -951,8 +951,11 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             PD_STAMP(6);
             early = eflag[0] != 0u;
             if (early) gates_h_prefetch(t + 1);
-            // ---- masked softmax over the positions (wave 0), cumulative alignment
-            if (wave == 0) {
+            // ---- masked softmax over the positions, cumulative alignment.  EVERY wave computes it (the others would idle at the barrier
+            //      below), wave 0 stores: with the DPP reductions of common.h inside an `if (wave == 0)` region this compiler rejects the
+            //      kernel ("Illegal instruction detected: Operand has incorrect register class", ROCm 7.2), and the shuffle butterflies
+            //      they replace were ~1.4 k of this stage's 3.3 k cycles
+            {
                 float e0[2], mx = -INFINITY;
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
@@ -969,10 +972,9 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     const int l = lane + 64 * k;
-                    if (l < L) {
+                    if (l < L && wave == 0) {
                         const float wl_ = e0[k] * inv, cn = cumw[pad + l] + wl_;
-                        wsm[l] = wl_; cumw[pad + l] = cn;
-                        if (sj == 0) { p.align[((size_t)t * B + sb) * L + l] = wl_; p.cum[((size_t)(t + 1) * B + sb) * L + l] = cn; }
+                        wsm[l] = wl_; cumw[pad + l] = cn;       // their copies in HBM are written by the last wave after the context stage
                     }
                 }
             }
@@ -991,6 +993,15 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 if (lg < ng) *reinterpret_cast<float4*>(ctxp + (lg * nc4 + c4) * 4) = s4;
             }
             __syncthreads();
+            // alignment / cumulative alignment of this step -> HBM (saved for the backward): off wave 0's softmax chain, where the two
+            // stores queued behind the early h-part loads
+            if (sj == 0 && wave == PS_THREADS / 64 - 1) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int l = lane + 64 * k;
+                    if (l < L) { p.align[((size_t)t * B + sb) * L + l] = wsm[l]; p.cum[((size_t)(t + 1) * B + sb) * L + l] = cumw[pad + l]; }
+                }
+            }
             if (tid < nc4) {
                 float4 tt = make_float4(0.f, 0.f, 0.f, 0.f);
                 for (int k = 0; k < ng; ++k) { const float4 v4 = *reinterpret_cast<const float4*>(ctxp + (k * nc4 + tid) * 4); tt.x += v4.x; tt.y += v4.y; tt.z += v4.z; tt.w += v4.w; }
