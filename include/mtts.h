@@ -249,7 +249,8 @@ typedef struct LstmStepArgs {
     int A;
     float* qpart;          /* [H/16][B][A] query-projection partials (summed by mtts_attn_step_fwd with kq = H/16) or NULL */
     int nb_max;            /* 32-wide k-blocks per K-slice: 0 = up to 10 (fewest partial slabs); 4 = short slices, two workgroups per CU
-                              (training: shares CUs with concurrently running GEMM workgroups) */
+                              (training: shares CUs with concurrently running GEMM workgroups).  Batches above 64 rows: 4 = another step
+                              kernel runs beside this one (keeps the two-workgroups-per-CU kernel), 0 = the launch has the chip to itself */
 } LstmStepArgs;
 
 int mtts_lstm_step_ksplit(int k_total);                    /* upper bound of the slab count over every nb_max >= 4 */

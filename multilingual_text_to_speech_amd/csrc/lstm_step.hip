@@ -380,6 +380,105 @@ struct LsFused {
     LsCell c;             // part / KS unused
 };
 
+// Cell / query operands of a wave's (row, unit) pairs and its query-weight fragments.  Every load is unconditional - an absent operand
+// reads a valid stand-in address and is replaced when it is used: a load under a condition makes the compiler drain the whole operand
+// stream in front of the first product.
+constexpr int LF_NQ = 2;                                    // query channel tiles per wave: A <= 8 waves x 2 x 16 = 256
+template <int NRT>
+struct LfCellOps { float4 pre4[NRT]; float cp[NRT], hp[NRT]; unsigned hm[NRT], cm[NRT]; float4 wq4[LF_NQ]; int nct; };
+
+template <int NRT>
+__device__ __forceinline__ void lf_cell_prefetch(const LsCell& c, LfCellOps<NRT>& o, int row0, int ug, int ct, int wave, int lane) {
+    const int B = c.B, H = c.H, i16 = lane & 15, q4 = lane >> 4;
+    const float* pre_p = c.pre ? c.pre : c.c_prev;  const int pre_ld = c.pre ? c.ldpre : 0;
+    const float* hp_p = c.h_prev ? c.h_prev : c.c_prev;
+    const uint8_t* hm_p = c.hmask ? c.hmask : reinterpret_cast<const uint8_t*>(c.c_prev);
+    const uint8_t* cm_p = c.cmask ? c.cmask : reinterpret_cast<const uint8_t*>(c.c_prev);
+#pragma unroll
+    for (int n = 0; n < NRT; ++n) {
+        const int pi = lane + 64 * n, rl = pi >> 2, uu = pi & 3;
+        const int row = min(row0 + rl, B - 1), u = 16 * ug + 4 * ct + uu;
+        const long hi = (long)row * H + u;
+        o.pre4[n] = *reinterpret_cast<const float4*>(pre_p + (c.pre ? (long)row * pre_ld + 4 * u : 0));
+        o.cp[n] = c.c_prev[hi];
+        o.hp[n] = hp_p[hi];
+        o.hm[n] = hm_p[hi];
+        o.cm[n] = cm_p[hi];
+    }
+    o.nct = c.qpart ? c.A >> 4 : 0;
+#pragma unroll
+    for (int k = 0; k < LF_NQ; ++k) {
+        const int cta = min(wave + 8 * k, max(o.nct - 1, 0));
+        o.wq4[k] = *reinterpret_cast<const float4*>((o.nct ? c.wq + (long)(16 * cta + i16) * H + 16 * ug + 4 * q4 : c.c_prev));
+    }
+}
+
+// Gate pre-activations of the wave's own [16 NRT rows x 16 gate columns] tile (accumulator layout) -> wave-private LDS patch -> cell per
+// (row, unit) -> h tile in LDS -> query partials q_part[ug][rows of the workgroup][A] on exact fp32 MFMA (wave <-> channel tiles).
+template <int NRT>
+__device__ __forceinline__ void lf_cell_epilogue(const LsCell& c, const LfCellOps<NRT>& o, float (*red)[16 * NRT][16], float (*hs)[17],
+                                                 const f32x4 (&g)[NRT], int row0, int rg, int ug, int ct, int rh, int wave, int lane) {
+    constexpr int RPW = 32 * NRT;
+    const int B = c.B, H = c.H, N = 4 * H, i16 = lane & 15, q4 = lane >> 4;
+    float (*rw)[16] = red[wave];
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rw[16 * rt + 4 * q4 + r][i16] = g[rt][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int n = 0; n < NRT; ++n) {
+        const int pi = lane + 64 * n, rl = pi >> 2, uu = pi & 3;
+        const int row = row0 + rl, u = 16 * ug + 4 * ct + uu;
+        const bool valid = row < B;
+        float4 g4 = *reinterpret_cast<const float4*>(&rw[rl][4 * uu]);
+        if (c.bias_u) { const float4 b4 = *reinterpret_cast<const float4*>(c.bias_u + 4 * u); g4.x += b4.x; g4.y += b4.y; g4.z += b4.z; g4.w += b4.w; }
+        if (c.pre) { g4.x += o.pre4[n].x; g4.y += o.pre4[n].y; g4.z += o.pre4[n].z; g4.w += o.pre4[n].w; }
+        const float ig = sigmoidf_(g4.x), fg = sigmoidf_(g4.y), gg = tanhf_(g4.z), og = sigmoidf_(g4.w);
+        const float cn = fg * o.cp[n] + ig * gg;
+        const float hn = og * tanhf_(cn);
+        const float hpv = c.h_prev ? o.hp[n] : 0.f;
+        const bool hk = !c.hmask || o.hm[n] != 0u, ck = !c.cmask || o.cm[n] != 0u;
+        float ho, co = cn;
+        if (c.zone == 1) { ho = hk ? hn : hpv; co = ck ? cn : o.cp[n]; }
+        else if (c.zone == 2) { ho = c.zh * hpv + (1.f - c.zh) * hn; co = c.zc * o.cp[n] + (1.f - c.zc) * cn; }
+        else ho = c.hmask ? (hk ? hn * c.hscale : 0.f) : hn;
+        if (valid) {
+            const long hi = (long)row * H + u;
+            c.h_out[hi] = ho;
+            c.c_out[hi] = co;
+            if (c.gates_out) {
+                float* go = c.gates_out + (long)row * N + u;
+                go[0] = ig; go[H] = fg; go[2 * H] = gg; go[3 * H] = og;
+            }
+        }
+        hs[rh * (16 * NRT) + rl][4 * ct + uu] = valid ? ho : 0.f;
+    }
+    if (!c.qpart) return;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < LF_NQ; ++k) {
+        const int cta = wave + 8 * k;
+        if (cta >= o.nct) break;
+        const float bv[4] = {o.wq4[k].x, o.wq4[k].y, o.wq4[k].z, o.wq4[k].w};
+#pragma unroll
+        for (int rtq = 0; rtq < RPW / 16; ++rtq) {
+            const float av[4] = {hs[16 * rtq + i16][4 * q4 + 0], hs[16 * rtq + i16][4 * q4 + 1], hs[16 * rtq + i16][4 * q4 + 2], hs[16 * rtq + i16][4 * q4 + 3]};
+            f32x4 qa = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) qa = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bv[s2], qa, 0, 0, 0);
+            float* out = c.qpart + ((long)ug * B) * c.A + 16 * cta + i16;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int orow = rg * RPW + 16 * rtq + 4 * q4 + rr;
+                if (orow < B) out[(long)orow * c.A] = qa[rr];
+            }
+        }
+    }
+}
+
 template <int PREC, int NRT, int DEPTH>
 __global__ __launch_bounds__(LS_THREADS, 4) void lstm_fused_kernel(LsFused p) {
     step_prio();
@@ -460,32 +559,8 @@ __global__ __launch_bounds__(LS_THREADS, 4) void lstm_fused_kernel(LsFused p) {
 
     // ---- cell / query operands (independent of the products: requested behind the first blocks, landed long before the epilogue)
     const LsCell& c = p.c;
-    // (every load unconditional - an absent operand reads a valid stand-in address and is replaced when it is used: a load under a
-    //  condition makes the compiler drain the whole stream in front of the first product)
-    float4 pre4[NRT]; float cp[NRT], hp[NRT]; unsigned hm[NRT], cm[NRT];
-    const float* pre_p = c.pre ? c.pre : c.c_prev;  const int pre_ld = c.pre ? c.ldpre : 0;
-    const float* hp_p = c.h_prev ? c.h_prev : c.c_prev;
-    const uint8_t* hm_p = c.hmask ? c.hmask : reinterpret_cast<const uint8_t*>(c.c_prev);
-    const uint8_t* cm_p = c.cmask ? c.cmask : reinterpret_cast<const uint8_t*>(c.c_prev);
-#pragma unroll
-    for (int n = 0; n < NRT; ++n) {
-        const int pi = lane + 64 * n, rl = pi >> 2, uu = pi & 3;
-        const int row = min(row0 + rl, B - 1), u = 16 * ug + 4 * ct + uu;
-        const long hi = (long)row * H + u;
-        pre4[n] = *reinterpret_cast<const float4*>(pre_p + (c.pre ? (long)row * pre_ld + 4 * u : 0));
-        cp[n] = c.c_prev[hi];
-        hp[n] = hp_p[hi];
-        hm[n] = hm_p[hi];
-        cm[n] = cm_p[hi];
-    }
-    constexpr int NQ = 2;                                   // query channel tiles per wave: A <= 8 waves x 2 x 16 = 256
-    const int nct = c.qpart ? c.A >> 4 : 0;
-    float4 wq4[NQ];
-#pragma unroll
-    for (int k = 0; k < NQ; ++k) {
-        const int cta = min(wave + 8 * k, max(nct - 1, 0));
-        wq4[k] = *reinterpret_cast<const float4*>((nct ? c.wq + (long)(16 * cta + i16) * H + 16 * ug + 4 * q4 : c.c_prev));
-    }
+    LfCellOps<NRT> co;
+    lf_cell_prefetch<NRT>(c, co, row0, ug, ct, wave, lane);
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- products over the whole K
@@ -574,65 +649,244 @@ __global__ __launch_bounds__(LS_THREADS, 4) void lstm_fused_kernel(LsFused p) {
     if (row0 + i16 < B) c.h_out[(long)(row0 + i16) * H + 16 * ug + 4 * ct + q4] = acc[0][0][0] + acc[0][1][1] + acc[NRT - 1][0][2] + acc[NRT - 1][1][3];
     return;
 #endif
-    // ---- cell: tile -> wave-private LDS patch -> (row, unit) per lane
-    float (*rw)[16] = red[wave];
+    // ---- cell of the wave's own tile, h tile, query partials
+    f32x4 gsum[NRT];
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rw[16 * rt + 4 * q4 + r][i16] = acc[rt][0][r] + acc[rt][1][r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int r = 0; r < 4; ++r) gsum[rt][r] = acc[rt][0][r] + acc[rt][1][r];
+    lf_cell_epilogue<NRT>(c, co, red, hs, gsum, row0, rg, ug, ct, rh, wave, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// F2: the fused step with bf16-plane products (PREC 1: the bf16 path; PREC 2: fp32 as three exact planes, six terms) re-tiled around the
+// matrix pipe.  Round-4 knock-outs of F (scripts/mb/mb_lstm_fused.hip, batch 240, K = 1312): 31 us per launch against 6 us of MFMA -
+// every 32-k block paid its own barrier with only 2 x 12 MFMAs per SIMD behind it, four waves read every activation fragment from LDS
+// (96 KB of fragment reads per 64 k and workgroup: the LDS port, not the matrix pipe, set the pace), the two waves of a column group
+// fetched the SAME weight fragments, and the fragment reads of a block started only after its staging stores.  Here
+//   * one barrier per 128 k: wave w = (column-group pair w & 1, k quarter w >> 1) multiplies ITS 32-k quarter of the block for ALL
+//     16-row tiles of the workgroup and TWO column groups (2 NRT tiles x 2 groups x 6 terms = 48 MFMAs per wave and barrier): every
+//     weight fragment is fetched by exactly one wave, every activation fragment is read from LDS by two;
+//   * the activation fragments of row tile r + 1 are read while the terms of tile r issue (register double buffer), the next block is
+//     staged (split + LDS stores) behind the first tiles' terms, global loads run two blocks (256 k) ahead;
+//   * the four k quarters meet once, after the loop, through LDS; then wave w = (column group w & 3, row half w >> 2) runs the cell /
+//     query epilogue of F on its own tile.
+// One workgroup per CU (dynamic LDS up to 102 KiB, <= 256 VGPRs): the two LSTM chains of a decoder step take turns on the chip - side
+// by side they competed for the same LDS port and matrix pipe, their sum is what a step costs either way.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int PREC, int NRT> struct Lf2Geom {
+    static constexpr int RPW = 32 * NRT, NPLX = PREC == 2 ? 3 : 1, XLD = 68;       // LDS row of a staged 128-k block in 4-byte words: 128 bf16 + pad
+    static constexpr int XS_BYTES = 2 * NPLX * RPW * XLD * 4;                      // double-buffered activation planes
+    static constexpr int PART_BYTES = 4 * 4 * RPW * 16 * 4;                        // [k quarter][column group][row][16] partial tiles
+    static constexpr int RED_BYTES = 8 * 16 * NRT * 16 * 4, HS_BYTES = RPW * 17 * 4;
+    static constexpr int SM_BYTES = XS_BYTES > PART_BYTES ? (XS_BYTES > RED_BYTES + HS_BYTES ? XS_BYTES : RED_BYTES + HS_BYTES)
+                                                          : (PART_BYTES > RED_BYTES + HS_BYTES ? PART_BYTES : RED_BYTES + HS_BYTES);
+};
+
+template <int PREC, int NRT>
+__global__ __launch_bounds__(LS_THREADS, 2) void lstm_fused2_kernel(LsFused p) {
+    step_prio();
+    static_assert(PREC == 1 || PREC == 2, "plane products only (fp32 MFMA: lstm_fused_kernel<0, ..>)");
+    using G = Lf2Geom<PREC, NRT>;
+    // 128-k blocks in flight (global -> registers): weights DW, activations DX.  The activations are consumed one block EARLIER than the
+    // weights (block it + 1 is staged during iteration it); a third slot pays only for the 64-row fp32 form (27.8 vs 28.6 us at batch
+    // 240; 32-row workgroups and the bf16 form are 0.5-1.8 us FASTER with two: scripts/mb/mb_lstm_fused.hip).
+    constexpr int DW = 2, DX = (PREC == 2 && NRT == 2) ? 3 : 2, UNR = DX == 3 ? 6 : 2;
+    static_assert(UNR % DW == 0 && UNR % DX == 0 && UNR % 2 == 0, "ring slots and the LDS buffer are static in the unrolled body");
+    constexpr int RPW = G::RPW, RT = 2 * NRT;               // rows per workgroup; 16-row tiles (every wave multiplies all of them)
+    constexpr int NPLX = G::NPLX, XLD = G::XLD;
+    constexpr int NXG = 2 * NRT;                            // 16-byte quanta a thread stages per block: RPW x 128 floats / 512 threads
+    // LDS: the activation planes during the loop; afterwards the partial tiles of the k quarters, then the epilogue's patches / h tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char lf2_sm[];
+    unsigned (*xs)[NPLX][RPW][XLD] = reinterpret_cast<unsigned (*)[NPLX][RPW][XLD]>(lf2_sm);
+    float (*part)[4][RPW][16] = reinterpret_cast<float (*)[4][RPW][16]>(lf2_sm);
+    float (*red)[16 * NRT][16] = reinterpret_cast<float (*)[16 * NRT][16]>(lf2_sm);
+    float (*hs)[17] = reinterpret_cast<float (*)[17]>(lf2_sm + G::RED_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, q4 = lane >> 4;
+    const int B = p.c.B, H = p.c.H, nug = H >> 4, RG = (int)gridDim.x / nug;
+    int ug, rg;
+    if ((nug & 7) == 0) { const int id = blockIdx.x, slot = id >> 3; ug = (id & 7) * (nug >> 3) + slot / RG; rg = slot % RG; }      // row groups of a unit group share an XCD
+    else { ug = (int)blockIdx.x / RG; rg = (int)blockIdx.x % RG; }
+    const int ctp = wave & 1, kq = wave >> 1;               // loop role: column groups 2 ctp, 2 ctp + 1; k quarter
+    const int ct = wave & 3, rh = wave >> 2;                // epilogue role: column group, row half
+    const int row0 = rg * RPW + rh * (16 * NRT);
+    const int last = p.nkb - 1, nit = (p.nkb + 3) >> 2;     // 32-k blocks of the packed weight; 128-k iterations
+
+    // staging role: row of the block, 16-byte chunk of a 32-k quarter; 64-row workgroups: all four quarters, 32-row ones: 2 (tid >> 8) + j
+    const int srow = (tid >> 3) & (RPW - 1), sch = tid & 7;
+    const int grow = min(rg * RPW + srow, B - 1);
+    const int sq0 = NRT == 2 ? 0 : 2 * (tid >> 8);
+    float4 xg[DX][NXG];
+    float4 wa[DW][2][NPLX];
+    // every load unconditional (blocks past the end re-read the last one)
+    auto issue_x = [&](int it, int slot) {
 #pragma unroll
-    for (int n = 0; n < NRT; ++n) {
-        const int pi = lane + 64 * n, rl = pi >> 2, uu = pi & 3;
-        const int row = row0 + rl, u = 16 * ug + 4 * ct + uu;
-        const bool valid = row < B;
-        float4 g4 = *reinterpret_cast<const float4*>(&rw[rl][4 * uu]);
-        if (c.bias_u) { const float4 b4 = *reinterpret_cast<const float4*>(c.bias_u + 4 * u); g4.x += b4.x; g4.y += b4.y; g4.z += b4.z; g4.w += b4.w; }
-        if (c.pre) { g4.x += pre4[n].x; g4.y += pre4[n].y; g4.z += pre4[n].z; g4.w += pre4[n].w; }
-        const float ig = sigmoidf_(g4.x), fg = sigmoidf_(g4.y), gg = tanhf_(g4.z), og = sigmoidf_(g4.w);
-        const float cn = fg * cp[n] + ig * gg;
-        const float hn = og * tanhf_(cn);
-        const float hpv = c.h_prev ? hp[n] : 0.f;
-        const bool hk = !c.hmask || hm[n] != 0u, ck = !c.cmask || cm[n] != 0u;
-        float ho, co = cn;
-        if (c.zone == 1) { ho = hk ? hn : hpv; co = ck ? cn : cp[n]; }
-        else if (c.zone == 2) { ho = c.zh * hpv + (1.f - c.zh) * hn; co = c.zc * cp[n] + (1.f - c.zc) * cn; }
-        else ho = c.hmask ? (hk ? hn * c.hscale : 0.f) : hn;
-        if (valid) {
-            const long hi = (long)row * H + u;
-            c.h_out[hi] = ho;
-            c.c_out[hi] = co;
-            if (c.gates_out) {
-                float* go = c.gates_out + (long)row * N + u;
-                go[0] = ig; go[H] = fg; go[2 * H] = gg; go[3 * H] = og;
+        for (int j = 0; j < NXG; ++j) {
+            int kg = 32 * min(4 * it + sq0 + j, last);
+            const float* xsrc; int ld;
+            if (kg < p.K0) { xsrc = p.x0; ld = p.ld0; }
+            else if (kg < p.K0 + p.K1) { xsrc = p.x1; ld = p.ld1; kg -= p.K0; }
+            else { xsrc = p.x2; ld = p.ld2; kg -= p.K0 + p.K1; }
+#ifndef LF_NO_X          // (scripts/mb/mb_lstm_fused.hip: stream knock-outs of the timing harness)
+            xg[slot][j] = *reinterpret_cast<const float4*>(xsrc + (long)grow * ld + kg + 4 * sch);
+#endif
+        }
+    };
+    auto issue_w = [&](int it, int slot) {
+#ifdef LF_NO_W
+        return;
+#endif
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const float4* ws = reinterpret_cast<const float4*>(p.wp) + ((long)(ug * 4 + 2 * ctp + cc) * p.nkb + min(4 * it + kq, last)) * (64 * NPLX) + lane;
+#pragma unroll
+            for (int f = 0; f < NPLX; ++f) wa[slot][cc][f] = ws[64 * f];
+        }
+    };
+    // block `it` (register slot `slot`) -> LDS buffer `buf`; a 32-k quarter past the end of K is staged as zeros (its weight fragment
+    // is a finite re-read)
+    auto stage = [&](int it, int slot, int buf) {
+#pragma unroll
+        for (int j = 0; j < NXG; ++j) {
+            const int quarter = sq0 + j;
+            const bool ok = 4 * it + quarter <= last;
+            float4 v = xg[slot][j];
+            v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+            unsigned* dst = &xs[buf][0][srow][16 * quarter + 2 * sch];
+            if (PREC == 2) {
+                unsigned a1, a2, a3, b1, b2, b3;
+                ls_split_pair(v.x, v.y, a1, a2, a3);
+                ls_split_pair(v.z, v.w, b1, b2, b3);
+                *reinterpret_cast<uint2*>(dst) = make_uint2(a1, b1);
+                *reinterpret_cast<uint2*>(dst + (NPLX > 1 ? 1 : 0) * (RPW * XLD)) = make_uint2(a2, b2);
+                *reinterpret_cast<uint2*>(dst + (NPLX > 2 ? 2 : 0) * (RPW * XLD)) = make_uint2(a3, b3);
+            } else {
+                *reinterpret_cast<uint2*>(dst) = make_uint2(bf16_rne(v.x) | (bf16_rne(v.y) << 16), bf16_rne(v.z) | (bf16_rne(v.w) << 16));
             }
         }
-        hs[rh * (16 * NRT) + rl][4 * ct + uu] = valid ? ho : 0.f;
-    }
-    if (!c.qpart) return;
+    };
+#if defined(LF_NO_X) || defined(LF_NO_W)
+#pragma unroll
+    for (int d = 0; d < DX; ++d)
+#pragma unroll
+        for (int j = 0; j < NXG; ++j) xg[d][j] = make_float4(1.f, 2.f, 3.f, 4.f);
+#pragma unroll
+    for (int d = 0; d < DW; ++d)
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int f = 0; f < NPLX; ++f) wa[d][cc][f] = make_float4(1.f, 2.f, 3.f, 4.f);
+#endif
+#pragma unroll
+    for (int d = 0; d < DX; ++d) issue_x(d, d);
+#pragma unroll
+    for (int d = 0; d < DW; ++d) issue_w(d, d);
+    __builtin_amdgcn_sched_barrier(0);
+    const LsCell& c = p.c;
+    LfCellOps<NRT> co;
+    lf_cell_prefetch<NRT>(c, co, row0, ug, ct, wave, lane);
+    __builtin_amdgcn_sched_barrier(0);
+
+    f32x4 acc[RT][2];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) { acc[rt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[rt][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    auto load_a = [&](int buf, int rt, Frag8 (&a)[NPLX]) {
+#pragma unroll
+        for (int pl = 0; pl < NPLX; ++pl) {
+            const uint4 av = *reinterpret_cast<const uint4*>(&xs[buf][pl][16 * rt + i16][16 * kq + 4 * q4]);      // 8 bf16: k = 32 kq + 8 q4 ..
+            a[pl].u[0] = av.x; a[pl].u[1] = av.y; a[pl].u[2] = av.z; a[pl].u[3] = av.w;
+        }
+    };
+    // one iteration: the wave's 32-k quarter of block `it` (weights in slot u % DW, activations in LDS buffer u & 1) times all row tiles
+    // for its two column groups; block it + 1 is staged (split: VALU, + LDS stores) behind the terms of the first row tiles.
+    // (Measured and dropped: the two waves of a SIMD staging at opposite ends of the iteration, so that one's VALU work meets the
+    // other's matrix work: 29.1 vs 27.9 us at batch 240 - the loop is not issue bound)
+    auto step = [&](int it, int u, bool stage_next) {
+        const int d = u % DW;
+        Frag8 wb[2][NPLX];
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int pl = 0; pl < NPLX; ++pl) {
+                const float4 w4 = wa[d][cc][pl];
+                wb[cc][pl].u[0] = __float_as_uint(w4.x); wb[cc][pl].u[1] = __float_as_uint(w4.y); wb[cc][pl].u[2] = __float_as_uint(w4.z); wb[cc][pl].u[3] = __float_as_uint(w4.w);
+            }
+        Frag8 a[2][NPLX];
+        load_a(u & 1, 0, a[0]);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            if (rt + 1 < RT) load_a(u & 1, rt + 1, a[(rt + 1) & 1]);
+            Frag8 (&ar)[NPLX] = a[rt & 1];
+#ifdef LF_NO_MFMA
+            acc[rt][0][0] += __uint_as_float(ar[0].u[0] ^ ar[NPLX - 1].u[3]) + __uint_as_float(wb[0][0].u[1]) + __uint_as_float(wb[1][NPLX - 1].u[2]);
+#else
+            if (PREC == 2) {       // six terms, small ones first (the order of gemm.hip / lstm_gates_body); the two column groups alternate
+#define LF2_MM(PA, PB) acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[PA].v, wb[0][PB].v, acc[rt][0], 0, 0, 0); \
+                       acc[rt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[PA].v, wb[1][PB].v, acc[rt][1], 0, 0, 0);
+                LF2_MM(2, 0) LF2_MM(0, 2) LF2_MM(1, 1) LF2_MM(1, 0) LF2_MM(0, 1) LF2_MM(0, 0)
+#undef LF2_MM
+            } else {
+                acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[0].v, wb[0][0].v, acc[rt][0], 0, 0, 0);
+                acc[rt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[0].v, wb[1][0].v, acc[rt][1], 0, 0, 0);
+            }
+#endif
+#ifndef LF_NO_STAGE
+            if (rt == (RT > 2 ? 1 : 0) && stage_next) stage(it + 1, (u + 1) % DX, (u + 1) & 1);
+#endif
+        }
+    };
+    // block it lives in weight slot it % DW, activation slot it % DX and LDS buffer it & 1 (all static in the body unrolled UNR times).
+    // ONE barrier per block: it publishes the next block's LDS copy and retires this block's fragment reads before that buffer is
+    // rewritten.
+    stage(0, 0, 0);
+    issue_x(DX, 0);                                         // block 0's slot is free again
     __syncthreads();
-    // ---- q_part[ug][rows of this workgroup][A] = h_tile [RPW x 16] W_q[:, 16 ug .. +16]^T (exact fp32 MFMA), wave <-> channel tiles
+    const int nfull = (nit / UNR) * UNR;
+    for (int it0 = 0; it0 < nfull; it0 += UNR) {
 #pragma unroll
-    for (int k = 0; k < NQ; ++k) {
-        const int cta = wave + 8 * k;
-        if (cta >= nct) break;
-        const float bv[4] = {wq4[k].x, wq4[k].y, wq4[k].z, wq4[k].w};
-#pragma unroll
-        for (int rtq = 0; rtq < RPW / 16; ++rtq) {
-            const float av[4] = {hs[16 * rtq + i16][4 * q4 + 0], hs[16 * rtq + i16][4 * q4 + 1], hs[16 * rtq + i16][4 * q4 + 2], hs[16 * rtq + i16][4 * q4 + 3]};
-            f32x4 qa = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) qa = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bv[s2], qa, 0, 0, 0);
-            float* out = c.qpart + ((long)ug * B) * c.A + 16 * cta + i16;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int orow = rg * RPW + 16 * rtq + 4 * q4 + rr;
-                if (orow < B) out[(long)orow * c.A] = qa[rr];
-            }
+        for (int u = 0; u < UNR; ++u) {
+            step(it0 + u, u, true);
+            issue_w(it0 + u + DW, u % DW);                  // the slots this iteration has consumed: its weights, and the activations of
+            issue_x(it0 + u + 1 + DX, (u + 1) % DX);        // block it + 1 it has just staged
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
         }
     }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+        if (u < nit - nfull) {                              // (uniform condition; requests past the end re-read the last block)
+            step(nfull + u, u, true);
+            issue_w(nfull + u + DW, u % DW);
+            issue_x(nfull + u + 1 + DX, (u + 1) % DX);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+        }
+
+#ifdef LF_NO_EPI
+    if (row0 + i16 < B) c.h_out[(long)(row0 + i16) * H + 16 * ug + 4 * ct + q4] = acc[0][0][0] + acc[0][1][1] + acc[RT - 1][0][2] + acc[RT - 1][1][3];
+    return;
+#endif
+    // ---- the four k quarters meet (the loop's last barrier has retired every read of the activation planes: their space now holds
+    //      the partial tiles): part[kq][column group][row][16]
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[kq][2 * ctp + cc][16 * rt + 4 * q4 + r][i16] = acc[rt][cc][r];
+    __syncthreads();
+    f32x4 gsum[NRT];
+#pragma unroll
+    for (int n = 0; n < NRT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * NRT * rh + 16 * n + 4 * q4 + r;
+            gsum[n][r] = (part[0][ct][row][i16] + part[1][ct][row][i16]) + (part[2][ct][row][i16] + part[3][ct][row][i16]);
+        }
+    __syncthreads();                                        // the space is rewritten by the epilogue's patches
+    lf_cell_epilogue<NRT>(c, co, red, hs, gsum, row0, rg, ug, ct, rh, wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -853,15 +1107,28 @@ static int ls_set_attrs() {
     return 0;
 }
 
+static int lf2_set_attrs() {      // dynamic LDS above 64 KiB needs the per-device opt-in
+    static bool done_dev[64] = {false};
+    int dev_ = 0; (void)hipGetDevice(&dev_);
+    bool& done = done_dev[dev_ & 63];
+    if (!done) {
+        MTTS_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_fused2_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, Lf2Geom<2, 2>::SM_BYTES));
+        MTTS_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_fused2_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, Lf2Geom<1, 2>::SM_BYTES));
+        MTTS_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_fused2_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, Lf2Geom<2, 1>::SM_BYTES));
+        MTTS_CHECK_HIP(hipFuncSetAttribute((const void*)lstm_fused2_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, Lf2Geom<1, 1>::SM_BYTES));
+        done = true;
+    }
+    return 0;
+}
+
 // batches of more than 64 rows take the fused kernel (lstm_fused_kernel): 64-row workgroups above 128 rows, 32-row ones up to 128
 static bool ls_fused_ok(const LstmStepArgs& a) {
     return a.B > 64 && (a.H & 15) == 0 && (!a.qpart || a.A <= 256);
 }
-// weight-pack mode of a decoder LSTM step: fp32 batches above 128 rows (64-row workgroups: two row tiles per wave share every weight
-// fragment) take the weights as three pre-split bf16 planes (precision 2): 34.4 -> 31.9 us per launch at batch 240 in isolation,
-// 96 -> 85 us per decoder step (the two LSTM chains stop competing for the fp32 matrix rate).  With 32-row workgroups (one row tile per
-// wave) the six terms + 50 % more weight bytes lose against eight fp32 MFMAs: 27.9 vs 25.7 us at batch 128 - those keep precision 0.
-int ls_pack_mode(int B, int precision) { return (precision == 0 && B > 128) ? 2 : precision; }
+// weight-pack mode of a decoder LSTM step: fp32 batches above 64 rows (the fused kernels) take the weights as three pre-split bf16
+// planes (precision 2, six bf16 MFMA terms per fragment pair in lstm_fused2_kernel) instead of fp32 fragments on the fp32 matrix
+// instruction: per launch 27.8 vs 34.4 us at batch 240 (K = 1312), 19.9 vs 25.6 us at batch 128 (K = 1568), 25.2 vs 34.4 (K = 2336).
+int ls_pack_mode(int B, int precision) { return (precision == 0 && B > 64) ? 2 : precision; }
 
 int lstm_step_launch(const LstmStepArgs& a, hipStream_t s) {
     LsGates g; LsCell c;
@@ -872,14 +1139,24 @@ int lstm_step_launch(const LstmStepArgs& a, hipStream_t s) {
         f.x0 = g.x0; f.x1 = g.x1; f.x2 = g.x2; f.K0 = g.K0; f.K1 = g.K1; f.K2 = g.K2; f.ld0 = g.ld0; f.ld1 = g.ld1; f.ld2 = g.ld2;
         f.wp = g.wp; f.nkb = g.nkb; f.c = c;
         const int nug = a.H / 16;
+        // nb_max == 4 is the caller's statement that another step kernel runs beside this one (the two LSTM chains of the teacher-forced
+        // schedule on two streams): those launches keep F - 128 VGPRs, 51 KiB of LDS, two workgroups per CU - because the chains hide in
+        // each other's stalls (decoder step at batch 240: 86.8 us with F against 91.0 with the faster-alone F2, which owns its CU).
+        // A lone chain (the free-running schedule) takes F2.
+        const bool lf_old = a.nb_max == 4;
+        if (!lf_old && a.precision != 0) MTTS_TRY(lf2_set_attrs());
         if (a.B > 128) {
             const dim3 grid(nug * ((a.B + 63) / 64));
-            if (a.precision == 2) hipLaunchKernelGGL((lstm_fused_kernel<2, 2, 4>), grid, dim3(LS_THREADS), 0, s, f);
+            if (a.precision == 2 && !lf_old) hipLaunchKernelGGL((lstm_fused2_kernel<2, 2>), grid, dim3(LS_THREADS), (Lf2Geom<2, 2>::SM_BYTES), s, f);
+            else if (a.precision == 1 && !lf_old) hipLaunchKernelGGL((lstm_fused2_kernel<1, 2>), grid, dim3(LS_THREADS), (Lf2Geom<1, 2>::SM_BYTES), s, f);
+            else if (a.precision == 2) hipLaunchKernelGGL((lstm_fused_kernel<2, 2, 4>), grid, dim3(LS_THREADS), 0, s, f);
             else if (a.precision) hipLaunchKernelGGL((lstm_fused_kernel<1, 2, 4>), grid, dim3(LS_THREADS), 0, s, f);
             else hipLaunchKernelGGL((lstm_fused_kernel<0, 2, 4>), grid, dim3(LS_THREADS), 0, s, f);
         } else {
             const dim3 grid(nug * ((a.B + 31) / 32));
-            if (a.precision == 2) hipLaunchKernelGGL((lstm_fused_kernel<2, 1, 4>), grid, dim3(LS_THREADS), 0, s, f);
+            if (a.precision == 2 && !lf_old) hipLaunchKernelGGL((lstm_fused2_kernel<2, 1>), grid, dim3(LS_THREADS), (Lf2Geom<2, 1>::SM_BYTES), s, f);
+            else if (a.precision == 1 && !lf_old) hipLaunchKernelGGL((lstm_fused2_kernel<1, 1>), grid, dim3(LS_THREADS), (Lf2Geom<1, 1>::SM_BYTES), s, f);
+            else if (a.precision == 2) hipLaunchKernelGGL((lstm_fused_kernel<2, 1, 4>), grid, dim3(LS_THREADS), 0, s, f);
             else if (a.precision) hipLaunchKernelGGL((lstm_fused_kernel<1, 1, 4>), grid, dim3(LS_THREADS), 0, s, f);
             else hipLaunchKernelGGL((lstm_fused_kernel<0, 1, 4>), grid, dim3(LS_THREADS), 0, s, f);
         }

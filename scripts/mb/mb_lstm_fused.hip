@@ -1,8 +1,11 @@
-// Stand-alone timing harness for lstm_fused_kernel (csrc/lstm_step.hip compiled into this translation unit): the decoder's LSTM step
-// of a large batch, per-launch time over back-to-back launches, with compile-time knock-outs that isolate the streams:
-//   -DLF_NO_X     activation fragments not loaded (constant operand)      -DLF_NO_W   weight fragments not loaded
-//   -DLF_NO_MFMA  products skipped                                        -DLF_NO_EPI no cell / query epilogue (accumulators stored raw)
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast [-DLF_...] -o mb_lstm_fused mb_lstm_fused.hip && ./mb_lstm_fused [B] [Kctx] [prec: 0 fp32 MFMA, 1 bf16, 2 fp32 as pre-split bf16 planes]
+// Stand-alone timing harness for the fused LSTM step kernels of large batches (csrc/lstm_step.hip compiled into this translation unit):
+// per-launch time over back-to-back launches, with compile-time knock-outs that isolate the streams of lstm_fused_kernel (F) and
+// lstm_fused2_kernel (F2):
+//   -DLF_NO_X     activation fragments not loaded (constant operand)      -DLF_NO_W     weight fragments not loaded
+//   -DLF_NO_MFMA  products skipped                                        -DLF_NO_EPI   no cell / query epilogue (accumulators stored raw)
+//   -DLF_NO_STAGE (F2) no staging of the next block (no wait for its loads, no split, no LDS stores)
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast [-DLF_...] -o mb_lstm_fused mb_lstm_fused.hip
+//   ./mb_lstm_fused [B] [Kctx] [prec: 0 fp32 MFMA, 1 bf16, 2 fp32 as pre-split bf16 planes] [nb_max: 0 = F2 for prec 1 / 2 (lone chain), 4 = F]
 #include "../../multilingual_text_to_speech_amd/csrc/lstm_step.hip"
 #include <cstdio>
 #include <cstdlib>
@@ -20,7 +23,7 @@ static float* dev_rand(size_t n, float scale) {
 }
 
 int main(int argc, char** argv) {
-    const int B = argc > 1 ? atoi(argv[1]) : 240, Kc = argc > 2 ? atoi(argv[2]) : 288, prec = argc > 3 ? atoi(argv[3]) : 0;
+    const int B = argc > 1 ? atoi(argv[1]) : 240, Kc = argc > 2 ? atoi(argv[2]) : 288, prec = argc > 3 ? atoi(argv[3]) : 0, nbmax = argc > 4 ? atoi(argv[4]) : 0;
     const int H = 1024, A = 128, K = Kc + H, NREP = 200;
     LstmStepArgs a; memset(&a, 0, sizeof(a));
     float* w = dev_rand((size_t)4 * H * K, 0.1f);
@@ -32,7 +35,7 @@ int main(int argc, char** argv) {
     int n = 0;
     if (Kc > 0) { a.x[n] = dev_rand((size_t)B * Kc, 1.f); a.K[n] = Kc; a.ldx[n] = Kc; ++n; }
     a.x[n] = dev_rand((size_t)B * H, 1.f); a.K[n] = H; a.ldx[n] = H; ++n;
-    a.nseg = n; a.w_packed = wp; a.precision = prec; a.B = B; a.H = H;
+    a.nseg = n; a.w_packed = wp; a.precision = prec; a.B = B; a.H = H; a.nb_max = nbmax;
     a.partials = dev_rand((size_t)mtts_lstm_step_partial_floats(B, H, K), 0.f);
     a.pre = dev_rand((size_t)B * 4 * H, 1.f); a.ldpre = 4 * H; a.bias_u = bias_u;
     a.c_prev = dev_rand((size_t)B * H, 1.f);
