@@ -74,7 +74,7 @@ static LstmStepArgs gen_step_args(const DecoderArgs& a, int t) {
     const long BH = (long)B * H, B4H = 4 * BH;
     LstmStepArgs k; memset(&k, 0, sizeof(k));
     k.x[0] = a.h_gen + t * BH; k.K[0] = H; k.ldx[0] = H; k.nseg = 1;
-    k.w_packed = a.gen_w2p; k.precision = ls_pack_mode(a.B, a.precision); k.B = B; k.H = H; k.partials = a.gate_part_gen; k.nb_max = 4;
+    k.w_packed = a.gen_w2p; k.precision = ls_pack_mode(a.B, a.precision, !a.fast); k.B = B; k.H = H; k.partials = a.gate_part_gen; k.nb_max = 4;
     k.pre = a.pre_gen + t * B4H; k.ldpre = 4 * H; k.bias_u = a.gen_bias_u;
     k.h_prev = a.h_gen + t * BH; k.c_prev = a.c_gen + t * BH;
     k.h_out = a.h_gen + (t + 1) * BH; k.c_out = a.c_gen + (t + 1) * BH;
@@ -151,7 +151,7 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
             LstmPackArgs k; memset(&k, 0, sizeof(k));
             k.w[0] = a.att_w_ih + P; k.K[0] = Dm; k.ldw[0] = P + Dm;
             k.w[1] = a.att_w_hh; k.K[1] = H; k.ldw[1] = H;
-            k.nseg = 2; k.H = H; k.precision = ls_pack_mode(a.B, a.precision); k.dst = a.att_w2p;
+            k.nseg = 2; k.H = H; k.precision = ls_pack_mode(a.B, a.precision, !a.fast); k.dst = a.att_w2p;
             k.b_ih = a.att_b_ih; k.b_hh = a.att_b_hh; k.bias_u = a.att_bias_u;
             MTTS_TRY(mtts_lstm_pack_weights(&k, s));
             MTTS_TRY(mtts_lstm_rows_unit_major(a.att_w_ih, P + Dm, H, P, a.att_w_pre_u, s));
@@ -165,7 +165,7 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
             k.w[0] = a.att_w_ih; k.K[0] = P; k.ldw[0] = P + Dm;
             k.w[1] = a.att_w_ih + P; k.K[1] = Dm; k.ldw[1] = P + Dm;
             k.w[2] = a.att_w_hh; k.K[2] = H; k.ldw[2] = H;
-            k.nseg = 3; k.H = H; k.precision = ls_pack_mode(a.B, a.precision); k.dst = a.att_w2p;
+            k.nseg = 3; k.H = H; k.precision = ls_pack_mode(a.B, a.precision, !a.fast); k.dst = a.att_w2p;
             k.b_ih = a.att_b_ih; k.b_hh = a.att_b_hh; k.bias_u = a.att_bias_u;
             MTTS_TRY(mtts_lstm_pack_weights(&k, s));
             k.w[0] = a.gen_w_ih; k.K[0] = H; k.ldw[0] = H + Dm;
@@ -176,7 +176,7 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
         }
         if (gen_uses_lstep(a)) {
             LstmPackArgs k; memset(&k, 0, sizeof(k));
-            k.w[0] = a.gen_w_hh; k.K[0] = H; k.ldw[0] = H; k.nseg = 1; k.H = H; k.precision = ls_pack_mode(a.B, a.precision); k.dst = a.gen_w2p;
+            k.w[0] = a.gen_w_hh; k.K[0] = H; k.ldw[0] = H; k.nseg = 1; k.H = H; k.precision = ls_pack_mode(a.B, a.precision, !a.fast); k.dst = a.gen_w2p;
             k.b_ih = a.gen_b_ih; k.b_hh = a.gen_b_hh; k.bias_u = a.gen_bias_u;
             MTTS_TRY(mtts_lstm_pack_weights(&k, s));
             MTTS_TRY(mtts_lstm_rows_unit_major(a.gen_w_ih, H + Dm, H, H + Dm, a.gen_w_ih_u, s));
@@ -248,7 +248,7 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
             if (use_lg) { k.x[n] = pren + t * BP; k.K[n] = P; k.ldx[n] = P; ++n; }
             k.x[n] = a.ctx + t * BD; k.K[n] = Dm; k.ldx[n] = Dm; ++n;
             k.x[n] = a.h_att + t * BH; k.K[n] = H; k.ldx[n] = H; ++n;
-            k.nseg = n; k.w_packed = a.att_w2p; k.precision = ls_pack_mode(a.B, a.precision); k.B = B; k.H = H; k.partials = a.gate_part;
+            k.nseg = n; k.w_packed = a.att_w2p; k.precision = ls_pack_mode(a.B, a.precision, !a.fast); k.B = B; k.H = H; k.partials = a.gate_part;
             if (use_ls) { k.pre = a.pre_att + t * B4H; k.ldpre = 4 * H; k.nb_max = 4; }      // training: short slices, 2 workgroups per CU
             k.bias_u = a.att_bias_u;
             k.h_prev = a.h_att + t * BH; k.c_prev = a.c_att + t * BH;
@@ -313,7 +313,7 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
                 k.x[0] = a.h_att + (t + 1) * BH; k.K[0] = H; k.ldx[0] = H;
                 k.x[1] = a.ctx + (t + 1) * BD; k.K[1] = Dm; k.ldx[1] = Dm;
                 k.x[2] = a.h_gen + t * BH; k.K[2] = H; k.ldx[2] = H;
-                k.nseg = 3; k.w_packed = a.gen_w2p; k.precision = ls_pack_mode(a.B, a.precision); k.B = B; k.H = H; k.partials = a.gate_part_gen;
+                k.nseg = 3; k.w_packed = a.gen_w2p; k.precision = ls_pack_mode(a.B, a.precision, !a.fast); k.B = B; k.H = H; k.partials = a.gate_part_gen;
                 k.bias_u = a.gen_bias_u;
                 k.h_prev = a.h_gen + t * BH; k.c_prev = a.c_gen + t * BH;
                 k.h_out = a.h_gen + (t + 1) * BH; k.c_out = a.c_gen + (t + 1) * BH;

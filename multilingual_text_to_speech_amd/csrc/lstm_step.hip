@@ -1125,10 +1125,13 @@ static int lf2_set_attrs() {      // dynamic LDS above 64 KiB needs the per-devi
 static bool ls_fused_ok(const LstmStepArgs& a) {
     return a.B > 64 && (a.H & 15) == 0 && (!a.qpart || a.A <= 256);
 }
-// weight-pack mode of a decoder LSTM step: fp32 batches above 64 rows (the fused kernels) take the weights as three pre-split bf16
-// planes (precision 2, six bf16 MFMA terms per fragment pair in lstm_fused2_kernel) instead of fp32 fragments on the fp32 matrix
-// instruction: per launch 27.8 vs 34.4 us at batch 240 (K = 1312), 19.9 vs 25.6 us at batch 128 (K = 1568), 25.2 vs 34.4 (K = 2336).
-int ls_pack_mode(int B, int precision) { return (precision == 0 && B > 64) ? 2 : precision; }
+// weight-pack mode of a decoder LSTM step.  fp32 steps of the fused kernels take the weights as three pre-split bf16 planes (precision
+// 2: six bf16 MFMA terms per fragment pair) instead of fp32 fragments on the fp32 matrix instruction wherever that is faster per launch:
+//   lone chain (free-running schedule, lstm_fused2_kernel), every batch above 64 rows: 27.8 vs 34.4 us at batch 240 (K = 1312),
+//     19.9 vs 25.6 us at batch 128 (K = 1568), 25.2 vs 34.4 us (K = 2336);
+//   two chains side by side (teacher-forced schedule, lstm_fused_kernel): above 128 rows only (64-row workgroups: 31.1 vs 34.4 us at
+//     batch 240; with 32-row workgroups six terms + 50 % more weight bytes lose: 27.5 vs 25.6 us at batch 128).
+int ls_pack_mode(int B, int precision, bool lone_chain) { return (precision == 0 && (B > 128 || (lone_chain && B > 64))) ? 2 : precision; }
 
 int lstm_step_launch(const LstmStepArgs& a, hipStream_t s) {
     LsGates g; LsCell c;

@@ -25,9 +25,9 @@ MTTS_API long mtts_decoder_buffer_elems(const DecoderArgs* args, const char* fie
         {"pre_att", T * B * 4 * H}, {"pre_gen", T * B * 4 * H}, {"q_all", T * B * A},
         {"h_att_p", (T + 1) * Bp * H}, {"h_gen_p", (T + 1) * Bp * H}, {"ctx_p", (T + 1) * Bp * Dm},
         {"att_w_ctx_p", 4 * H * Dm}, {"att_w_hh_p", 4 * H * H}, {"gen_w_hh_p", 4 * H * H}, {"w_query_p", r16(A) * H},
-        {"att_w2p", mtts_lstm_packed_weight_bytes((int)H, (int)att_k(a), ls_pack_mode((int)B, a.precision))}, {"att_bias_u", 4 * H}, {"att_w_pre_u", 4 * H * P},
+        {"att_w2p", mtts_lstm_packed_weight_bytes((int)H, (int)att_k(a), ls_pack_mode((int)B, a.precision, !a.fast))}, {"att_bias_u", 4 * H}, {"att_w_pre_u", 4 * H * P},
         {"gate_part", mtts_lstm_step_partial_floats((int)B, (int)H, (int)att_k(a))},
-        {"gen_w2p", mtts_lstm_packed_weight_bytes((int)H, (int)gen_k(a), ls_pack_mode((int)B, a.precision))}, {"gen_bias_u", 4 * H}, {"gen_w_ih_u", 4 * H * (H + Dm)},
+        {"gen_w2p", mtts_lstm_packed_weight_bytes((int)H, (int)gen_k(a), ls_pack_mode((int)B, a.precision, !a.fast))}, {"gen_bias_u", 4 * H}, {"gen_w_ih_u", 4 * H * (H + Dm)},
         {"gate_part_gen", mtts_lstm_step_partial_floats((int)B, (int)H, (int)gen_k(a))},
         {"prenet_wp0", P * M}, {"prenet_wp1", P * P},
         {"persist_ws", mtts_decoder_persist_ws_bytes((int)B, (int)L, (int)H, (int)Dm, (int)A)},

@@ -11,8 +11,9 @@ hdr $O/train_step_kernels.txt "# rocprofv3 --kernel-trace --stats -- python benc
 # decoder forward / backward of the roofline legs).  Per (kernel, workgroups, HSA queue) table by scripts/trace_summary.py.  pdec_kernel / pgen7_kernel (256 wg) =
 # the persistent attention-LSTM+attention and generator-LSTM recurrences (ONE launch each per decoder forward, 600 steps).  rocprofv3's own statistics:
 # r04_train_step_kernel_stats.csv"
-python $R/scripts/phase_summary.py $O/step/step_kernel_trace.csv --step 2 > $O/train_step_phases.txt 2>&1
-hdr $O/train_step_phases.txt "# phases of the last traced train step of the same run (scripts/phase_summary.py)"
+python $R/scripts/phase_summary.py $O/step/step_kernel_trace.csv --step 2 --detail 12 > $O/train_step_phases.txt 2>&1
+hdr $O/train_step_phases.txt "# phases of the last traced train step of the same run (scripts/phase_summary.py --detail 12: per phase the busy / idle time and the
+# twelve largest (kernel, workgroups) rows)"
 cp $O/step/step_kernel_stats.csv $O/train_step_kernel_stats.csv 2>/dev/null
 # 3. decoder forward alone (240-frame decode between markers): batch 64 fp32 (persistent kernels), batch 240 fp32 / bf16 (fused step kernels)
 for cfg in "shared_training 64 f32 fwd_decoder_trace" "generated_switching 240 f32 fwd_decoder_b240_f32" "generated_switching 240 bf16 fwd_decoder_b240_bf16"; do
@@ -38,9 +39,15 @@ hdr $O/pmc_train_step_traffic.txt "# the same two PMC passes over python bench.p
 rm -rf $O/pmc_fetch $O/pmc_write
 # 5. micro-benchmarks: persistent kernels (hand-off forms bit-equal, per-step times, in-kernel timelines), fused large-batch LSTM step with stream knock-outs
 ( for b in 64 40 16; do timeout 80 $R/scripts/mb/mb_persist $b 240; done ) > $O/mb_persistent_timelines.txt 2>&1
-( for v in "" _X _W _MFMA _EPI _X_W _X_W_MFMA; do echo "== knock-out: ${v:-none}"; timeout 60 $R/scripts/mb/mb_lstm_fused$v 240 288 0; done
-  echo "== bf16"; timeout 60 $R/scripts/mb/mb_lstm_fused 240 288 1; echo "== generator LSTM (K = 1024)"; timeout 60 $R/scripts/mb/mb_lstm_fused 240 0 0
-  echo "== batch 128, K = 544 + 1024"; timeout 60 $R/scripts/mb/mb_lstm_fused 128 544 0 ) > $O/mb_lstm_fused.txt 2>&1
+( echo "# scripts/mb/mb_lstm_fused [B] [Kctx] [prec] [nb_max]: per-launch time of the fused LSTM step (K = Kctx + 1024); prec 0 fp32 MFMA / 1 bf16 / 2 fp32 as"
+  echo "# pre-split bf16 planes; nb_max 4 = lstm_fused_kernel (F: two workgroups per CU, beside another chain), 0 = lstm_fused2_kernel (F2: lone chain)"
+  for cfg in "240 288 2" "240 0 2" "240 288 1" "240 0 1" "128 544 2" "128 1312 2" "128 544 1"; do for nb in 4 0; do echo "== $cfg nb_max $nb: $(timeout 60 $R/scripts/mb/mb_lstm_fused $cfg $nb | tail -1)"; done; done
+  echo "== fp32 MFMA form (prec 0, F): $(timeout 60 $R/scripts/mb/mb_lstm_fused 240 288 0 4 | tail -1)"
+  echo "== fp32 MFMA form (prec 0, F): $(timeout 60 $R/scripts/mb/mb_lstm_fused 128 544 0 4 | tail -1)"
+  echo "# stream knock-outs of F2 (compile-time switches of the harness), batch 240 / 128, fp32 planes and bf16"
+  for cfg in "240 288 2" "128 544 2" "240 288 1"; do for v in "" _X _W _MFMA _EPI _STAGE _X_W _X_W_MFMA _X_W_MFMA_STAGE; do echo "== $cfg knock-out ${v:-none}: $(timeout 60 $R/scripts/mb/mb_lstm_fused$v $cfg | tail -1)"; done; done ) > $O/mb_lstm_fused.txt 2>&1
+( echo "# scripts/mb/mb_attn_bwd [B] [L] [Dm] [n_part]: attention-step backward alone (back-to-back launches) and the in-kernel stage timeline of workgroup 0"
+  for cfg in "64 120 544 7" "64 66 544 7" "16 120 544 7" "40 120 544 7"; do timeout 60 $R/scripts/mb/mb_attn_bwd $cfg | tail -2; done ) > $O/mb_attn_bwd_timeline.txt 2>&1
 # 6. inference kernels
 timeout 300 rocprofv3 --kernel-trace -d $O/inf -o inf --output-format csv -- python $R/scripts/prof_inference.py --frames 240 > $O/inf.log 2>&1
 python $R/scripts/trace_summary.py $O/inf/inf_kernel_trace.csv --region 1 --top 16 2>&1 | cut -c1-200 > $O/inference_kernels.txt
