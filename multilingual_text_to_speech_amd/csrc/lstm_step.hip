@@ -906,6 +906,12 @@ constexpr int PN_MAXK1 = 6;      // 16-wide k-chunks of layer 1: Kin <= 96
 constexpr int PN_NCG = 4;        // column groups of layer 2 (grid.y): more workgroups for a 22-MFLOP problem
 constexpr int PN_MAXK2 = 8;      // layer-2 k-chunks per wave: the 8 waves are 4 column tiles x 2 K-halves, P <= 256
 
+#ifdef PN_PROF           // micro-benchmark builds only (scripts/mb/mb_prenet2.hip): workgroup (0, 0) / thread 0 stamps the shader clock per stage
+__device__ unsigned long long g_pn_stamps[8];
+#define PN_STAMP(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_pn_stamps[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PN_STAMP(k) do { } while (0)
+#endif
 __global__ __launch_bounds__(512) void prenet2_kernel(Prenet2 p) {
     extern __shared__ __attribute__((aligned(16))) float psm[];      // y1 tile [16][P + 4], then the K-half partial sums [4][16][17]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -921,6 +927,7 @@ __global__ __launch_bounds__(512) void prenet2_kernel(Prenet2 p) {
     const bool t2_ok = (wave & 3) < tpg && t2 < nct;
     const int t2c = min(t2, nct - 1);
     const int kc_lo = kh * ((nk2 + 1) >> 1), kc_hi = kh ? nk2 : ((nk2 + 1) >> 1);
+    PN_STAMP(0);
     // ---- EVERY global operand of both layers is requested here, before any arithmetic: one memory round trip (weights come
     //      from the Infinity Cache at best: eight other kernels ran since the previous step), then ~2.5 us of MFMA.
     //      Weights are in MFMA tile order ([column tile][k chunk][lane][4], mtts_pack_weight): one coalesced 1 KiB read per wave
@@ -951,6 +958,7 @@ __global__ __launch_bounds__(512) void prenet2_kernel(Prenet2 p) {
     }
     // epilogue operands of layer 2: thread -> (row tid >> 4, column within the tile tid & 15) for tile (tid >> 8) ... see below
     // ---- layer 1 (every workgroup of a row tile computes all of it: 0.65 MFLOP)
+    PN_STAMP(1);                                         // loads issued
     f32x4 acc[PN_MAXCT];
 #pragma unroll
     for (int c = 0; c < PN_MAXCT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -982,6 +990,7 @@ __global__ __launch_bounds__(512) void prenet2_kernel(Prenet2 p) {
         }
     }
     __syncthreads();
+    PN_STAMP(2);                                         // layer 1 done (operands landed, MFMA, epilogue, LDS)
     // ---- layer 2: this wave's (column tile, K-half)
     f32x4 acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -994,6 +1003,7 @@ __global__ __launch_bounds__(512) void prenet2_kernel(Prenet2 p) {
             for (int s2 = 0; s2 < 4; ++s2) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bv[s2], acc2, 0, 0, 0);
         }
     }
+    PN_STAMP(3);                                         // layer 2 products
     __syncthreads();                                    // all reads of the y1 tile are done: reuse the buffer for the K-half exchange
     float* red = psm + (wave & 3) * (16 * 17);
     if (kh == 1) {
@@ -1013,6 +1023,7 @@ __global__ __launch_bounds__(512) void prenet2_kernel(Prenet2 p) {
             p.y2[(long)row * P + col] = v;
         }
     }
+    PN_STAMP(4);                                         // K-half exchange + epilogue stores issued
 }
 
 // Returns -1 when the shape is outside the kernel's bounds (the caller then runs the layers one by one), 0 on success.

@@ -198,7 +198,7 @@ def test_fused2_matches_fused_to_rounding(precision):
     """The two fused kernels on the same operands: same products, different summation trees (k quarters) - equal to fp32 rounding."""
     h0 = run_step(240, 1024, [544, 1024], 128, precision, seed=77, nb_max=0)
     h4 = run_step(240, 1024, [544, 1024], 128, precision, seed=77, nb_max=4)
-    assert (h0 - h4).abs().max().item() <= 2e-6
+    assert (h0 - h4).abs().max().item() <= 1e-5
 
 
 def test_presplit_planes_are_fp32_accurate():
