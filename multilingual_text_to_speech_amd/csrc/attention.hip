@@ -266,28 +266,22 @@ __global__ __launch_bounds__(ATT_BIG) void attn_step_big_kernel(AttnStepArgs p) 
     const int wcol = wave % nct, wgrp = wave / nct;
     const int a_own = 16 * wcol + i16;
 
-    // ---- burst of independent loads
-    const int len = min(p.lengths[b], L);
+    // ---- burst of independent loads.  Every one of them is UNCONDITIONAL on a clamped address and none of the values is touched
+    //      before the last request has gone out (round 4): as `cond ? *p : 0` the query partials and the memory rows came out of the
+    //      compiler as separate exec-masked blocks with `s_waitcnt vmcnt(0)` between them, and the sequence length - a per-sample
+    //      scalar - was waited for right behind its load: five serial round trips in front of the first product.
+    int len_raw = p.lengths[b];
     const int q_ngrp = NT / A, q_g = tid / A, q_a = tid - q_g * A;
     constexpr int KQP = KQ_PER / 2;
     float qp[KQP];
 #pragma unroll
     for (int k = 0; k < KQP; ++k) {
-        const int kk = q_g + k * q_ngrp;
-        qp[k] = (kk < p.kq) ? p.qpart[(long)kk * p.q_ks + (long)b * A + q_a] : 0.f;
+        const int kk = min(q_g + k * q_ngrp, p.kq - 1);
+        qp[k] = p.qpart[(long)kk * p.q_ks + (long)b * A + q_a];
     }
     const float v_r = p.v[min(tid, A - 1)];
     const float bias_r = p.bias[min(tid, A - 1)];
     const float cum_r = p.cum_in[(long)b * L + min(tid, L - 1)];
-    float4 mem4[ATT_BIG_NCM];
-    {
-        const float* mem = p.memory + (long)b * L * Dm + d0 + c4 * 4;
-#pragma unroll
-        for (int j = 0; j < ATT_BIG_NCM; ++j) {
-            const int l = min(cg + j * ng, L - 1);
-            mem4[j] = (nc4 > 0) ? *reinterpret_cast<const float4*>(mem + (long)l * Dm) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
     float mtD[NTE][4], us[NU_MAX / 2];
 #pragma unroll
     for (int j = 0; j < NTE; ++j)
@@ -303,7 +297,7 @@ __global__ __launch_bounds__(ATT_BIG) void attn_step_big_kernel(AttnStepArgs p) 
     {
         float qs = 0.f;
 #pragma unroll
-        for (int k = 0; k < KQP; ++k) qs += qp[k];
+        for (int k = 0; k < KQP; ++k) qs += (q_g + k * q_ngrp < p.kq) ? qp[k] : 0.f;
         part[tid] = qs;
     }
     if (tid < A) { vv[tid] = v_r; bias[tid] = bias_r; }
@@ -317,6 +311,17 @@ __global__ __launch_bounds__(ATT_BIG) void attn_step_big_kernel(AttnStepArgs p) 
     if (tid < pad) cumw[tid] = 0.f;
     if (tid < 64 - pad) cumw[pad + L + tid] = 0.f;
     __syncthreads();
+    // the memory rows of the context are only needed after the softmax: requested here, where the registers of the first burst
+    // (query partials, filter bank) are free again, they travel under the location features, the energies and the softmax
+    float4 mem4[ATT_BIG_NCM];
+    {
+        const float* mem = p.memory + (long)b * L * Dm + (nc4 > 0 ? d0 + c4 * 4 : 0);
+#pragma unroll
+        for (int j = 0; j < ATT_BIG_NCM; ++j) {
+            const int l = min(cg + j * ng, L - 1);
+            mem4[j] = *reinterpret_cast<const float4*>(mem + (long)l * Dm);
+        }
+    }
     if (tid < A) {
         float qs = 0.f;
         for (int g = 0; g < q_ngrp; ++g) qs += part[g * A + tid];
@@ -355,6 +360,8 @@ __global__ __launch_bounds__(ATT_BIG) void attn_step_big_kernel(AttnStepArgs p) 
     __syncthreads();
 
     // ---- masked softmax (wave 0): energies = sum over the column tiles in a fixed order
+    asm volatile("" : "+v"(len_raw));                 // the length stays an opaque register value until here
+    const int len = min(len_raw, L);
     if (tid < 64) {
         float mx = -INFINITY;
         for (int l = lane; l < L; l += 64) {
@@ -374,7 +381,7 @@ __global__ __launch_bounds__(ATT_BIG) void attn_step_big_kernel(AttnStepArgs p) 
     if (tid < L && ch == 0) {
         const float wl = w[tid];
         p.w_out[(long)b * L + tid] = wl;
-        p.cum_out[(long)b * L + tid] = cum_r + wl;
+        p.cum_out[(long)b * L + tid] = cumw[pad + tid] + wl;      // (the LDS copy: one register less across the kernel)
     }
 
     // ---- context columns of this chunk (memory rows are already in registers)

@@ -148,7 +148,6 @@ int add3(float* out, int ldo, const float* a, int lda, const float* b, int ldb, 
 int attn_bwd_plus_skinny(const AttnBwdArgs& a, const SkinnyArgs& k, hipStream_t s);
 int lstm_step_launch(const LstmStepArgs& a, hipStream_t s);
 int ls_pack_mode(int B, int precision, bool lone_chain);      // 2 = fp32 weights as three pre-split bf16 planes (lstm_step.hip)
-int sum_slabs(const float* part, int n, long stride, int ldp, const float* bias, float* out, int rows, int cols, int ldo, int act, hipStream_t s);
 // persistent recurrences (persist.hip)
 bool persist_enabled();
 bool pgen_supported(const DecoderArgs& a);

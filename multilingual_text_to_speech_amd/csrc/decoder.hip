@@ -341,16 +341,10 @@ MTTS_API int mtts_decoder_fwd(const DecoderArgs* args, void* stream) {
                 k.nseg = 2; k.B = B; k.N = M + 1; k.ksplit = 1;
                 k.seg[0] = seg_h(a.h_gen, use_lg ? nullptr : a.h_gen_p, t + 1, B, H, a.w_out, nullptr, H + Dm);      // (the K-split cell kernel
                 k.seg[1] = seg_h(a.ctx, use_lg ? nullptr : a.ctx_p, t + 1, B, Dm, a.w_out + H, nullptr, H + Dm);      //  writes no packed copies)
-                if (use_lg && (long)8 * B * Mo <= (long)B * 4 * H) {
-                    // few output columns, long K: split K eight ways for parallelism (partials in the idle generator scratch) and
-                    // finish with a small reduction instead of streaming [B, H + Dm] through 6 workgroups
-                    k.ksplit = 8; k.out = a.gate_part_gen; k.ldo = Mo; k.out_ks = (long)B * Mo;
-                    MTTS_TRY(skinny_launch(k, s));
-                    MTTS_TRY(sum_slabs(a.gate_part_gen, 8, (long)B * Mo, Mo, a.b_out, a.out + (long)(t + 1) * B * Mo, B, M + 1, Mo, 0, s));
-                } else {
-                    k.out = a.out + (long)(t + 1) * B * Mo; k.ldo = Mo; k.bias = a.b_out;
-                    MTTS_TRY(skinny_launch(k, s));
-                }
+                // few output columns (6 tiles), long K: 16-row workgroups with every K chunk in flight (skinny_kernel_wide) - one
+                // launch and one memory round trip (round 4; before: an 8-way K split + a slab-sum launch, 6.8 + 5.4 us at batch 128)
+                k.out = a.out + (long)(t + 1) * B * Mo; k.ldo = Mo; k.bias = a.b_out;
+                MTTS_TRY(skinny_launch(k, s));
             }
         }
         if (a.fast && !pg && (((t + 1 - a.t0) % CH) == 0 || t + 1 == a.t1)) {

@@ -8,7 +8,9 @@
 #include "attention_bwd_body.h"
 #include "skinny_body.h"
 
-// launch bound 4 waves/SIMD (<= 128 VGPRs): an attention workgroup and a GEMM workgroup must fit on one CU together
+// launch bound 4 waves/SIMD (<= 128 VGPRs): an attention workgroup and a GEMM workgroup must fit on one CU together.
+// PK: operands of the product in MFMA tile order (skinny_body's packed-only instantiation); the product is a plain one (PLAIN).
+template <int PK>
 __global__ __launch_bounds__(NT, 4) void attn_bwd_plus_skinny_kernel(AttnBwdArgs a, SkinnyArgs k, int n_attn, int sk_cbs) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int id = blockIdx.x;
@@ -17,7 +19,7 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_plus_skinny_kernel(AttnBwdArgs
     } else {
         const int j = id - n_attn;
         float (&red)[NW][64][17] = *reinterpret_cast<float (*)[NW][64][17]>(sm);
-        skinny_body<4, 2>(k, red, j % sk_cbs, 0, j / sk_cbs);
+        skinny_body<4, 2, PK, 1>(k, red, j % sk_cbs, 0, j / sk_cbs);
     }
 }
 
@@ -35,7 +37,10 @@ int attn_bwd_plus_skinny(const AttnBwdArgs& a, const SkinnyArgs& k, hipStream_t 
     size_t lds = attn_bwd_fast_lds(a);
     const size_t lds_sk = sizeof(float) * NW * 64 * 17;
     if (lds_sk > lds) lds = lds_sk;
-    hipLaunchKernelGGL(attn_bwd_plus_skinny_kernel, dim3(n_attn + cbs * q.ksplit), dim3(NT), lds, s, a, q, n_attn, cbs);
+    const dim3 grid(n_attn + cbs * q.ksplit);
+    if (q.seg[0].xpack && q.seg[0].wpack) hipLaunchKernelGGL(attn_bwd_plus_skinny_kernel<1>, grid, dim3(NT), lds, s, a, q, n_attn, cbs);
+    else if (!q.seg[0].xpack && !q.seg[0].wpack) hipLaunchKernelGGL(attn_bwd_plus_skinny_kernel<2>, grid, dim3(NT), lds, s, a, q, n_attn, cbs);
+    else hipLaunchKernelGGL(attn_bwd_plus_skinny_kernel<0>, grid, dim3(NT), lds, s, a, q, n_attn, cbs);
     MTTS_CHECK_LAUNCH("attn_bwd_plus_skinny_kernel");
     return 0;
 }

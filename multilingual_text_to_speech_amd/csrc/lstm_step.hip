@@ -932,31 +932,41 @@ __global__ __launch_bounds__(512) void prenet2_kernel(Prenet2 p) {
     //      from the Infinity Cache at best: eight other kernels ran since the previous step), then ~2.5 us of MFMA.
     //      Weights are in MFMA tile order ([column tile][k chunk][lane][4], mtts_pack_weight): one coalesced 1 KiB read per wave
     //      instruction - row-major rows would be 64 separate 16-byte requests each and leave the kernel texture-address bound.
+    // Every load is UNCONDITIONAL on a clamped address and its value is not touched before the arithmetic (round 4): written as
+    // `ok ? *p : 0` the compiler turned the x fragments into four flat dword loads each through a select against a zeroed scratch
+    // slot, the weight fragments into dword pieces under exec branches, and put `s_waitcnt vmcnt(0)` behind every keep-flag byte
+    // (five serial round trips in front of the first product).  K tails are zeroed on the x side when the fragment is used;
+    // column tiles past the end compute on tile nct - 1 and are never stored.
     float4 a4[PN_MAXK1], b1f[PN_MAXCT][PN_MAXK1], b2f[PN_MAXK2];
+    bool aok[PN_MAXK1];
     float bias1[PN_MAXCT];
-    int keep1[PN_MAXCT][4];
+    int keep1[PN_MAXCT][4], keep2[4];
 #pragma unroll
     for (int kc = 0; kc < PN_MAXK1; ++kc) {
         const int k = 16 * kc + 4 * q4;
-        const bool ok = k < p.Kin;
-        a4[kc] = ok ? *reinterpret_cast<const float4*>(p.x + (long)arow * p.ldx + k) : z4;
+        aok[kc] = k < p.Kin;
+        a4[kc] = *reinterpret_cast<const float4*>(p.x + (long)arow * p.ldx + (aok[kc] ? k : 0));
 #pragma unroll
-        for (int c = 0; c < PN_MAXCT; ++c) {
-            const int ct = wave + 8 * c;
-            b1f[c][kc] = (ok && ct < nct) ? *reinterpret_cast<const float4*>(p.w1 + (((long)ct * nk1 + kc) * 64 + lane) * 4) : z4;
-        }
+        for (int c = 0; c < PN_MAXCT; ++c)
+            b1f[c][kc] = *reinterpret_cast<const float4*>(p.w1 + (((long)min(wave + 8 * c, nct - 1) * nk1 + min(kc, nk1 - 1)) * 64 + lane) * 4);
     }
 #pragma unroll
     for (int kc = 0; kc < PN_MAXK2; ++kc)
         b2f[kc] = *reinterpret_cast<const float4*>(p.w2 + (((long)t2c * nk2 + min(kc_lo + kc, nk2 - 1)) * 64 + lane) * 4);
 #pragma unroll
-    for (int c = 0; c < PN_MAXCT; ++c) {
-        const int col = 16 * min(wave + 8 * c, nct - 1) + i16;
-        bias1[c] = p.b1[col];
+    for (int c = 0; c < PN_MAXCT; ++c) bias1[c] = p.b1[16 * min(wave + 8 * c, nct - 1) + i16];
+    const float bias2 = p.b2[16 * t2c + i16];            // layer-2 epilogue operands travel with the rest
+    // keep flags: loaded unconditionally as well (without masks the loads re-read byte 0 of the weights and are ignored) - a
+    // branch around them made the compiler wait for everything in flight at the join
+    const uint8_t* m1p = p.m1 ? p.m1 : reinterpret_cast<const uint8_t*>(p.w1);
+    const uint8_t* m2p = p.m2 ? p.m2 : reinterpret_cast<const uint8_t*>(p.w2);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) keep1[c][r] = p.m1 ? (int)p.m1[(long)min(row0 + 4 * q4 + r, p.B - 1) * P + col] : 1;
-    }
-    // epilogue operands of layer 2: thread -> (row tid >> 4, column within the tile tid & 15) for tile (tid >> 8) ... see below
+    for (int c = 0; c < PN_MAXCT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            keep1[c][r] = (int)m1p[p.m1 ? (long)min(row0 + 4 * q4 + r, p.B - 1) * P + 16 * min(wave + 8 * c, nct - 1) + i16 : 0];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) keep2[r] = (int)m2p[p.m2 ? (long)min(row0 + 4 * q4 + r, p.B - 1) * P + 16 * t2c + i16 : 0];
     // ---- layer 1 (every workgroup of a row tile computes all of it: 0.65 MFLOP)
     PN_STAMP(1);                                         // loads issued
     f32x4 acc[PN_MAXCT];
@@ -964,7 +974,8 @@ __global__ __launch_bounds__(512) void prenet2_kernel(Prenet2 p) {
     for (int c = 0; c < PN_MAXCT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kc = 0; kc < PN_MAXK1; ++kc) {
-        const float av[4] = {a4[kc].x, a4[kc].y, a4[kc].z, a4[kc].w};
+        const float4 az = aok[kc] ? a4[kc] : z4;
+        const float av[4] = {az.x, az.y, az.z, az.w};
 #pragma unroll
         for (int c = 0; c < PN_MAXCT; ++c) {
             const float bv[4] = {b1f[c][kc].x, b1f[c][kc].y, b1f[c][kc].z, b1f[c][kc].w};
@@ -1013,13 +1024,12 @@ __global__ __launch_bounds__(512) void prenet2_kernel(Prenet2 p) {
     __syncthreads();
     if (kh == 0 && t2_ok) {
         const int col = 16 * t2 + i16;
-        const float bb = p.b2[col];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = row0 + 4 * q4 + r;
             if (row >= p.B) continue;
-            float v = fmaxf(acc2[r] + red[(4 * q4 + r) * 17 + i16] + bb, 0.f);
-            if (p.m2) v = p.m2[(long)row * P + col] ? v * p.scale : 0.f;
+            float v = fmaxf(acc2[r] + red[(4 * q4 + r) * 17 + i16] + bias2, 0.f);
+            if (p.m2) v = keep2[r] ? v * p.scale : 0.f;
             p.y2[(long)row * P + col] = v;
         }
     }

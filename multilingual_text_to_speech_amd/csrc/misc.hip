@@ -287,24 +287,6 @@ MTTS_API int mtts_dropout_keep_mask(uint8_t* out, long n, float p, uint64_t seed
     return 0;
 }
 
-// out[r, c] = act(bias[c] + sum_k part[k][r][c]): epilogue of a K-split skinny product whose consumer is not a fused kernel
-__global__ void sum_slabs_kernel(const float* __restrict__ part, int n, long stride, int ldp, const float* __restrict__ bias,
-                                 float* __restrict__ out, int rows, int cols, int ldo, int act) {
-    const long total = (long)rows * cols;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long r = i / cols; const int c = (int)(i - r * cols);
-        float v = bias ? bias[c] : 0.f;
-        for (int k = 0; k < n; ++k) v += part[k * stride + r * ldp + c];
-        out[r * ldo + c] = apply_act(act, v);
-    }
-}
-
-int sum_slabs(const float* part, int n, long stride, int ldp, const float* bias, float* out, int rows, int cols, int ldo, int act,
-              hipStream_t s) {
-    hipLaunchKernelGGL(sum_slabs_kernel, dim3(nblocks((long)rows * cols)), dim3(256), 0, s, part, n, stride, ldp, bias, out, rows, cols, ldo, act);
-    MTTS_CHECK_LAUNCH("sum_slabs_kernel");
-    return 0;
-}
 
 // ---- stop rule of batched free-running synthesis, on the device ---------------------------------------------------------------------
 // Reference Decoder._decode, modules/tacotron2.py:201-207 (batch 1): a frame whose stop probability reaches the threshold arms a

@@ -43,49 +43,66 @@ struct SegTab {
     int cb, mt0, mt_last;                 // column block / first absolute 16-row tile of this workgroup / last existing tile
 };
 
+// One zero tile (1 KiB): the target of every request that must read as zero - chunks past the end of K, the K tail of a row-major
+// operand.  The ADDRESS is selected, never the loaded value: a select (or a branch) on the value makes the compiler wait for the
+// load right behind it (`s_waitcnt vmcnt(0)` per row-major operand and chunk - one memory round trip each; round 4).
+static __device__ __attribute__((aligned(16))) float g_sk_zero[256];
+
 // Loads are QUAD-COALESCED: lane l fetches 16 B of row (l >> 2) at k-quad (l & 3), so four consecutive lanes cover
 // 64 contiguous bytes and one wave instruction covers a 16-row x 16-k tile in 16 requests.  (Fetching directly in the
 // MFMA operand layout - row = l & 15, k-quad = l >> 4 - puts consecutive lanes on different rows: 64 separate 16-B
 // requests per instruction, and the texture-address unit becomes the bottleneck: 18 us -> 12.5 us per LSTM step.)
 // The MFMA layout is restored in registers with ds_bpermute when the fragment is consumed.
-template <int MT>
+// PK = 1: every segment has both operands in MFMA tile order (the per-step products of the decoder backward): no row-major address,
+// no layout conversion; PK = 2: row-major operands only (BiLSTM steps, query / frame projections); PK = 0: mixed - the launcher
+// picks the instantiation.
+template <int MT, int PK>
 __device__ __forceinline__ void sk_load(const SegTab t, int c, const int (&rows)[MT], int wrow, int kq, int lane, Frag<MT>& f) {
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    f.w = z; f.xp = true; f.wp = true;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) f.x[m] = z;
-    if (c >= t.total) return;                       // wave-uniform
+    const bool live = c < t.total;                  // wave-uniform
+    const int cc = live ? c : 0;
     // chunk index (global over the segments) -> segment parameters; everything here is wave-uniform
-    const bool in0 = c < t.n0, in1 = c < t.n0 + t.n1;
+    const bool in0 = cc < t.n0, in1 = cc < t.n0 + t.n1;
     const float* sx = in0 ? t.x0 : (in1 ? t.x1 : t.x2);
     const float* sw = in0 ? t.w0 : (in1 ? t.w1 : t.w2);
+    const int nc = in0 ? t.n0 : (in1 ? t.n1 : t.n2);
+    const int cs = in0 ? cc : (in1 ? cc - t.n0 : cc - t.n0 - t.n1);      // chunk within its segment
+    const float* zp = g_sk_zero + lane * 4;
+    if (PK == 1) {       // 1 KiB contiguous tiles, already in MFMA operand order
+        f.xp = true; f.wp = true;
+        const float* wa = sw + (((long)t.cb * nc + cs) * 64 + lane) * 4;
+        f.w = *reinterpret_cast<const float4*>(live ? wa : zp);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const float* xa = sx + (((long)min(t.mt0 + m, t.mt_last) * nc + cs) * 64 + lane) * 4;
+            f.x[m] = *reinterpret_cast<const float4*>(live ? xa : zp);
+        }
+        return;
+    }
     const int sK = in0 ? t.K0 : (in1 ? t.K1 : t.K2);
     const int ldx = in0 ? t.ldx0 : (in1 ? t.ldx1 : t.ldx2);
     const int ldw = in0 ? t.ldw0 : (in1 ? t.ldw1 : t.ldw2);
+    if (PK == 2) {       // row-major operands only
+        const int k = cs * 16 + kq * 4;
+        const bool ok = live && k < sK;             // per lane
+        f.xp = false; f.wp = false;
+        f.w = *reinterpret_cast<const float4*>(ok ? sw + (long)wrow * ldw + k : zp);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) f.x[m] = *reinterpret_cast<const float4*>(ok ? sx + (long)rows[m] * ldx + k : zp);
+        return;
+    }
     const int xp = in0 ? t.xp0 : (in1 ? t.xp1 : t.xp2);
     const int wp = in0 ? t.wp0 : (in1 ? t.wp1 : t.wp2);
-    const int nc = in0 ? t.n0 : (in1 ? t.n1 : t.n2);
-    const int cs = in0 ? c : (in1 ? c - t.n0 : c - t.n0 - t.n1);      // chunk within its segment
     const int k = cs * 16 + kq * 4;
-    const bool ok = k < sK;
-    const int kc = ok ? k : 0;
+    const bool ok = live && k < sK;                 // per lane; packed tiles are whole (zero padded by the packing kernels)
     f.xp = xp != 0; f.wp = wp != 0;
-    if (wp) {       // 1 KiB contiguous tile, already in MFMA operand order
-        f.w = *reinterpret_cast<const float4*>(sw + (((long)t.cb * nc + cs) * 64 + lane) * 4);
-    } else {
-        const float4 wv = *reinterpret_cast<const float4*>(sw + (long)wrow * ldw + kc);
-        f.w = ok ? wv : z;
+    {
+        const float* wa = wp ? sw + (((long)t.cb * nc + cs) * 64 + lane) * 4 : sw + (long)wrow * ldw + k;
+        f.w = *reinterpret_cast<const float4*>((wp ? live : ok) ? wa : zp);
     }
-    if (xp) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-            f.x[m] = *reinterpret_cast<const float4*>(sx + (((long)min(t.mt0 + m, t.mt_last) * nc + cs) * 64 + lane) * 4);
-    } else {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const float4 xv = *reinterpret_cast<const float4*>(sx + (long)rows[m] * ldx + kc);
-            f.x[m] = ok ? xv : z;
-        }
+    for (int m = 0; m < MT; ++m) {
+        const float* xa = xp ? sx + (((long)min(t.mt0 + m, t.mt_last) * nc + cs) * 64 + lane) * 4 : sx + (long)rows[m] * ldx + k;
+        f.x[m] = *reinterpret_cast<const float4*>((xp ? live : ok) ? xa : zp);
     }
 }
 
@@ -93,13 +110,13 @@ __device__ __forceinline__ float4 to_mfma_layout(const float4 v, int src_lane) {
     return make_float4(__shfl(v.x, src_lane, 64), __shfl(v.y, src_lane, 64), __shfl(v.z, src_lane, 64), __shfl(v.w, src_lane, 64));
 }
 
-template <int MT>
+template <int MT, int PK>
 __device__ __forceinline__ void sk_mma(const Frag<MT>& f, f32x4 (&acc)[MT], int src_lane) {
-    const float4 w4 = f.wp ? f.w : to_mfma_layout(f.w, src_lane);
+    const float4 w4 = (PK == 1 || (PK == 0 && f.wp)) ? f.w : to_mfma_layout(f.w, src_lane);
     const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        const float4 x4 = f.xp ? f.x[m] : to_mfma_layout(f.x[m], src_lane);
+        const float4 x4 = (PK == 1 || (PK == 0 && f.xp)) ? f.x[m] : to_mfma_layout(f.x[m], src_lane);
         const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[s], wv[s], acc[m], 0, 0, 0);
@@ -112,13 +129,17 @@ struct FwdPre {            // LSTM cell forward, one (row, unit) per thread
     int hm, cm, len;
     bool valid;
 };
+constexpr int MAX_PART = 8;
 struct BwdPre {            // LSTM cell backward, one (row, unit)
     float dh_extra, dc, g[4], cp;
     int hm, cm, len;
     bool valid;
 };
-constexpr int MAX_PART = 8;
+struct BwdRaw { float a, b, parts[MAX_PART]; };      // the addends of dh_extra as they were loaded (summed by bwd_finish)
 
+// Epilogue operands of the fused LSTM cells.  Absent operands (null pointers, kernel-uniform) are skipped by branches: requesting
+// them unconditionally from a fallback address was measured SLOWER (scripts/bench_skinny.py, cell backward at batch 64: 4.5 -> 5.5 us -
+// eight more requests per thread, all of a launch on one cache line).
 __device__ __forceinline__ void fwd_prefetch(const SkinnyArgs& p, int row, int u, bool valid, FwdPre& f) {
     f.valid = valid;
     const int r = valid ? row : 0, uu = valid ? u : 0;
@@ -137,28 +158,34 @@ __device__ __forceinline__ void fwd_prefetch(const SkinnyArgs& p, int row, int u
     f.len = p.lengths ? p.lengths[r] : 0x7fffffff;
 }
 
-__device__ __forceinline__ void bwd_prefetch(const SkinnyArgs& p, int row, int u, bool valid, BwdPre& f) {
+// The addends of dh_extra are only REQUESTED here; bwd_finish sums them (same order as ever: a, b, parts 0..7) after the main
+// loop's first fragments have been requested as well.
+__device__ __forceinline__ void bwd_prefetch(const SkinnyArgs& p, int row, int u, bool valid, BwdPre& f, BwdRaw& w) {
     f.valid = valid;
     const int r = valid ? row : 0, uu = valid ? u : 0;
     const long hi = (long)r * p.H + uu;
     f.len = p.lengths ? p.lengths[r] : 0x7fffffff;
     // packed-sequence semantics (reference modules/encoder.py:41-44: pad_packed_sequence): the output at a padded position is a
     // constant zero, so the upstream gradient of a carried step is dropped - only the recurrent / carried parts pass through
-    float e = (p.dh_a && p.t < f.len) ? p.dh_a[(long)r * p.ld_dh_a + uu] : 0.f;
-    if (p.dh_b) e += p.dh_b[hi];
-    float parts[MAX_PART];
+    w.a = (p.dh_a && p.t < f.len) ? p.dh_a[(long)r * p.ld_dh_a + uu] : 0.f;
+    w.b = p.dh_b ? p.dh_b[hi] : 0.f;
 #pragma unroll
     for (int k = 0; k < MAX_PART; ++k)
-        parts[k] = (k < p.n_part) ? p.part[(long)k * p.part_ks + (long)r * p.part_ld + p.part_col0 + uu] : 0.f;
-#pragma unroll
-    for (int k = 0; k < MAX_PART; ++k) e += parts[k];
-    f.dh_extra = e;
+        w.parts[k] = (k < p.n_part) ? p.part[(long)k * p.part_ks + (long)r * p.part_ld + p.part_col0 + uu] : 0.f;
     f.dc = p.dc_in[hi];
     const float* gp = p.gates + (long)r * 4 * p.H + uu;
     f.g[0] = gp[0]; f.g[1] = gp[p.H]; f.g[2] = gp[2 * p.H]; f.g[3] = gp[3 * p.H];
     f.cp = p.c_prev[hi];
     f.hm = p.hmask ? (int)p.hmask[hi] : 1;
     f.cm = p.cmask ? (int)p.cmask[hi] : 1;
+}
+
+__device__ __forceinline__ void bwd_finish(const SkinnyArgs& p, BwdPre& f, const BwdRaw& w) {
+    float e = w.a;
+    if (p.dh_b) e += w.b;
+#pragma unroll
+    for (int k = 0; k < MAX_PART; ++k) e += w.parts[k];
+    f.dh_extra = e;
 }
 
 template <int MT>
@@ -173,24 +200,26 @@ template <int MT>
 __device__ __forceinline__ void fwd_cell(const SkinnyArgs& p, const float (&red)[NW][MT * 16][17], int rr, int uu, int row,
                                          int u, const FwdPre& f) {
     if (!f.valid) return;
+    const int hm = f.hm, cm = f.cm, len = f.len;
     float g4[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) g4[g] = red_sum<MT>(red, rr, g * 4 + uu) + f.pre[g] + f.bi[g] + f.bh[g];
+    for (int g = 0; g < 4; ++g)
+        g4[g] = red_sum<MT>(red, rr, g * 4 + uu) + f.pre[g] + f.bi[g] + f.bh[g];
     const long hi = (long)row * p.H + u;
     const float cp = f.cp;
     const float ig = sigmoidf_(g4[0]), fg = sigmoidf_(g4[1]), gg = tanhf_(g4[2]), og = sigmoidf_(g4[3]);
     const float cn = fg * cp + ig * gg;
     const float hn = og * tanhf_(cn);
-    const bool carried = p.t >= f.len;
+    const bool carried = p.t >= len;
     if (p.gates_out) {
         float* go = p.gates_out + (long)row * 4 * p.H + u;
         go[0] = carried ? 0.f : ig; go[p.H] = carried ? 0.f : fg; go[2 * p.H] = carried ? 0.f : gg; go[3 * p.H] = carried ? 0.f : og;
     }
     float ho, co = cn;
     if (carried) { ho = f.hp; co = cp; }
-    else if (p.zone == 1) { ho = f.hm ? hn : f.hp; co = f.cm ? cn : cp; }          // keep flag set -> take the new value
+    else if (p.zone == 1) { ho = hm ? hn : f.hp; co = cm ? cn : cp; }          // keep flag set -> take the new value
     else if (p.zone == 2) { ho = p.zh * f.hp + (1.f - p.zh) * hn; co = p.zc * cp + (1.f - p.zc) * cn; }
-    else ho = p.hmask ? (f.hm ? hn * p.hscale : 0.f) : hn;
+    else ho = p.hmask ? (hm ? hn * p.hscale : 0.f) : hn;
     p.h_out[hi] = ho;
     p.c_out[hi] = co;
     if (p.h_pack_out)      // MFMA tile order copy for the next step's X operand: lane 16*q + i, column 4*q + s of chunk u / 16
@@ -202,19 +231,20 @@ template <int MT>
 __device__ __forceinline__ void bwd_cell(const SkinnyArgs& p, const float (&red)[NW][MT * 16][17], int rr, int cc, int row,
                                          int u, const BwdPre& f) {
     if (!f.valid) return;
+    const int hm = f.hm, cm = f.cm, len = f.len;
     const long hi = (long)row * p.H + u;
     const float dh = red_sum<MT>(red, rr, cc) + f.dh_extra;
     const float dc = f.dc;
     const float ig = f.g[0], fg = f.g[1], gg = f.g[2], og = f.g[3];
     const float cp = f.cp;
-    const bool carried = p.t >= f.len;
+    const bool carried = p.t >= len;
     float dh_carry = 0.f, dc_carry = 0.f, dhn = dh, dcn = dc;
     if (carried) { dh_carry = dh; dc_carry = dc; dhn = 0.f; dcn = 0.f; }
     else if (p.zone == 1) {
-        if (!f.hm) { dh_carry = dh; dhn = 0.f; }
-        if (!f.cm) { dc_carry = dc; dcn = 0.f; }
+        if (!hm) { dh_carry = dh; dhn = 0.f; }
+        if (!cm) { dc_carry = dc; dcn = 0.f; }
     } else if (p.hmask) {
-        dhn = f.hm ? dh * p.hscale : 0.f;
+        dhn = hm ? dh * p.hscale : 0.f;
     }
     const float cn = fg * cp + ig * gg;
     const float th = tanhf_(cn);
@@ -235,7 +265,8 @@ __device__ __forceinline__ void bwd_cell(const SkinnyArgs& p, const float (&red)
 }
 
 // Body of the skinny kernel for workgroup (column block cb, row tile, K split ks); `red` is the workgroup's LDS reduction buffer.
-template <int MT, int DEPTH = 4>
+// PLAIN = 1: the plain-product epilogue only (p.lstm == 0 is the caller's promise): the fused attention-backward launch
+template <int MT, int DEPTH = 4, int PK = 0, int PLAIN = 0>
 __device__ __forceinline__ void skinny_body(const SkinnyArgs& p, float (&red)[NW][MT * 16][17], const int cb, const int row_tile,
                                             const int ks) {
     step_prio();
@@ -246,23 +277,23 @@ __device__ __forceinline__ void skinny_body(const SkinnyArgs& p, float (&red)[NW
     const int row0 = row_tile * (MT * 16);
 
     // ---- epilogue operands first (independent of the GEMM): one memory round trip, overlapped with the main loop
-    FwdPre fp; BwdPre bp0, bp1;
+    FwdPre fp; BwdPre bp0, bp1; BwdRaw br0, br1;
     fp.valid = false; bp0.valid = false; bp1.valid = false;
-    if (p.lstm == 1) {
+    if (!PLAIN && p.lstm == 1) {
         const int rr = tid >> 2, uu = tid & 3;
         const int row = row0 + rr, u = cb * 4 + uu;
         fwd_prefetch(p, row, u, tid < MT * 64 && row < p.B && u < p.H, fp);
-    } else if (p.lstm == 2) {
+    } else if (!PLAIN && p.lstm == 2) {
         {
             const int rr = tid >> 4, cc = tid & 15;
             const int row = row0 + rr, u = cb * 16 + cc;
-            bwd_prefetch(p, row, u, tid < MT * 256 && row < p.B && u < p.H, bp0);
+            bwd_prefetch(p, row, u, tid < MT * 256 && row < p.B && u < p.H, bp0, br0);
         }
         if (MT * 256 > NT) {
             const int e = tid + NT;
             const int rr = e >> 4, cc = e & 15;
             const int row = row0 + rr, u = cb * 16 + cc;
-            bwd_prefetch(p, row, u, e < MT * 256 && row < p.B && u < p.H, bp1);
+            bwd_prefetch(p, row, u, e < MT * 256 && row < p.B && u < p.H, bp1, br1);
         }
     }
 
@@ -271,7 +302,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyArgs& p, float (&red)[NW
     const int r4 = lane >> 2, kq4 = lane & 3;
     const int src_lane = 4 * (lane & 15) + (lane >> 4);
     int wrow;
-    if (p.lstm == 1) { const int u = min(cb * 4 + (r4 & 3), p.H - 1); wrow = (r4 >> 2) * p.H + u; }
+    if (!PLAIN && p.lstm == 1) { const int u = min(cb * 4 + (r4 & 3), p.H - 1); wrow = (r4 >> 2) * p.H + u; }
     else wrow = min(cb * 16 + r4, p.N - 1);
     int rows[MT];
 #pragma unroll
@@ -297,35 +328,25 @@ __device__ __forceinline__ void skinny_body(const SkinnyArgs& p, float (&red)[NW
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // chunk c is served by wave (c % NW) of K-split ((c / NW) % ksplit); 4-deep software pipeline per wave
+    // chunk c is served by wave (c % NW) of K-split ((c / NW) % ksplit); DEPTH-deep software pipeline per wave (4: default; 2: fewer
+    // registers, used where the workgroup shares a CU with another one; 16: everything in flight at once - few-workgroup launches of
+    // the free-running loop pay ONE memory round trip).  The first DEPTH requests are unconditional (chunks past the end re-read
+    // chunk 0 and are never multiplied) and go out right behind the epilogue operands.
     const int step = NW * p.ksplit;
     int c = ks * NW + wave;
-    if (c < total) {
-        if (DEPTH == 4) {
-            Frag<MT> f0, f1, f2, f3;
-            sk_load<MT>(t, c, rows, wrow, kq4, lane, f0);
-            sk_load<MT>(t, c + step, rows, wrow, kq4, lane, f1);
-            sk_load<MT>(t, c + 2 * step, rows, wrow, kq4, lane, f2);
-            sk_load<MT>(t, c + 3 * step, rows, wrow, kq4, lane, f3);
-            for (; c < total; c += 4 * step) {
-                sk_mma<MT>(f0, acc, src_lane);
-                sk_load<MT>(t, c + 4 * step, rows, wrow, kq4, lane, f0);
-                sk_mma<MT>(f1, acc, src_lane);
-                sk_load<MT>(t, c + 5 * step, rows, wrow, kq4, lane, f1);
-                sk_mma<MT>(f2, acc, src_lane);
-                sk_load<MT>(t, c + 6 * step, rows, wrow, kq4, lane, f2);
-                sk_mma<MT>(f3, acc, src_lane);
-                sk_load<MT>(t, c + 7 * step, rows, wrow, kq4, lane, f3);
-            }
-        } else {      // 2-deep variant: fewer registers, used where the workgroup shares a CU with another one
-            Frag<MT> f0, f1;
-            sk_load<MT>(t, c, rows, wrow, kq4, lane, f0);
-            sk_load<MT>(t, c + step, rows, wrow, kq4, lane, f1);
-            for (; c < total; c += 2 * step) {
-                sk_mma<MT>(f0, acc, src_lane);
-                sk_load<MT>(t, c + 2 * step, rows, wrow, kq4, lane, f0);
-                sk_mma<MT>(f1, acc, src_lane);
-                sk_load<MT>(t, c + 3 * step, rows, wrow, kq4, lane, f1);
+    {
+        Frag<MT> f[DEPTH];
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) sk_load<MT, PK>(t, c + i * step, rows, wrow, kq4, lane, f[i]);
+        if (!PLAIN && p.lstm == 2) {
+            bwd_finish(p, bp0, br0);
+            if (MT * 256 > NT) bwd_finish(p, bp1, br1);
+        }
+        for (; c < total; c += DEPTH * step) {
+#pragma unroll
+            for (int i = 0; i < DEPTH; ++i) {
+                sk_mma<MT, PK>(f[i], acc, src_lane);
+                sk_load<MT, PK>(t, c + (DEPTH + i) * step, rows, wrow, kq4, lane, f[i]);
             }
         }
     }
@@ -337,7 +358,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyArgs& p, float (&red)[NW
         for (int r = 0; r < 4; ++r) red[wave][m * 16 + lq * 4 + r][li] = acc[m][r];
     __syncthreads();
 
-    if (p.lstm == 0) {
+    if (PLAIN || p.lstm == 0) {
         for (int e = tid; e < MT * 16 * 16; e += NT) {
             const int rr = e >> 4, cc = e & 15;
             const int row = row0 + rr, col = cb * 16 + cc;

@@ -734,6 +734,34 @@ def test_skinny_gemm_matches_torch_on_random_shapes(seed):
     assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item()), (B, N, [x.shape[1] for x in xs], ks)
 
 
+@pytest.mark.parametrize('B,N,Ks,ldo', [(128, 81, (1024, 288), 84), (240, 81, (1024, 544), 84), (1, 81, (1024, 288), 84), (37, 20, (4096,), 20),
+                                         (128, 256, (80,), 256)])
+def test_skinny_gemm_one_round_trip_variant(B, N, Ks, ldo):
+    """skinny_kernel_wide (16-row workgroups, every K chunk of a wave requested before the first product): the frame / stop
+    projection of the free-running loop (reference modules/tacotron2.py:191-193; M + 1 = 81 columns into rows of 84) at synthesis
+    batch sizes, a K long enough to loop (4096 > 16 chunks x 8 waves x 16), and a prenet-layer shape; bias fused, row stride > N."""
+    import ctypes
+    from multilingual_text_to_speech_amd import _C
+    from multilingual_text_to_speech_amd._C import check, lib, ptr, stream_ptr
+    g = torch.Generator().manual_seed(77)
+    xs = [torch.randn(B, K, generator=g).cuda() for K in Ks]
+    Kt = sum(Ks)
+    w = (torch.randn(N, Kt, generator=g) / Kt ** 0.5).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    a = _C.SkinnyArgs()
+    a.nseg, a.B, a.N, a.ksplit = len(Ks), B, N, 1
+    k0 = 0
+    for i, x in enumerate(xs):
+        a.seg[i].x, a.seg[i].w, a.seg[i].K, a.seg[i].ldx, a.seg[i].ldw = ptr(x), w.data_ptr() + 4 * k0, x.shape[1], x.shape[1], Kt
+        k0 += x.shape[1]
+    out = torch.full((B, ldo), 7.0, device='cuda')
+    a.out, a.ldo, a.bias = ptr(out), ldo, ptr(bias)
+    check(lib().mtts_skinny_gemm(ctypes.byref(a), stream_ptr()), 'mtts_skinny_gemm')
+    ref = torch.cat(xs, 1).double() @ w.double().t() + bias.double()
+    assert (out[:, :N].double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    assert (out[:, N:] == 7.0).all()                      # padding columns of the row are not touched
+
+
 def test_fused_adam_two_groups_mixed_steps_match_torch():
     """hp.encoder_optimizer layout (reference train.py:261-270): two parameter groups with their own learning rates, one global
     clip coefficient over ALL parameters, and a parameter that receives no gradient in the first step (its bias-correction step
