@@ -233,6 +233,21 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_kernel(AttnStepArgs p) 
 // Wave w = (column tile w % (A / 16), row group w / (A / 16)) owns the row tiles {group + ngroups j}; the partial energies of a
 // column tile are reduced over its 16 lanes (DPP) and summed over the column tiles in a fixed order by the softmax wave.
 // ------------------------------------------------------------------------------------------------------------
+// floor(a / b) for 0 <= a <= 2048, 1 <= b <= 2048 without the integer-division sequence (~25 vector instructions): float reciprocal
+// + one correction step each way
+__device__ __forceinline__ int small_div(int a, int b) {
+    int q = (int)(((float)a + 0.5f) * __builtin_amdgcn_rcpf((float)b));
+    q -= (q * b > a);
+    q += ((q + 1) * b <= a);
+    return q;
+}
+// tanh with the hardware reciprocal (1 ulp) instead of the IEEE division sequence (10 instructions): the energies of the large-batch
+// kernel evaluate it 4 NTE times per lane
+__device__ __forceinline__ float tanh_rcp_(float x) {
+    const float e = __expf(-2.0f * fabsf(x));
+    return copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x);
+}
+
 constexpr int ATT_BIG = 1024;        // threads
 constexpr int ATT_BIG_NCM = 9;       // memory float4 per thread
 constexpr int ATT_BIG_ES = 272;      // row of the partial-energy buffer (>= 16 * 16 positions + pad)
@@ -255,15 +270,20 @@ __global__ __launch_bounds__(ATT_BIG) void attn_step_big_kernel(AttnStepArgs p) 
     float* part = Up + A * UP_LD;        // [4 * NT]
     float* es = part + 4 * NT;           // [A / 16][ATT_BIG_ES] partial energies per column tile
 
-    // ---- geometry
-    const int dc = (((Dm + p.nch - 1) / p.nch) + 3) & ~3;
+    // ---- geometry.  The kernel is bound by the instructions its 16 waves issue (4 per SIMD: 3 400 instructions per wave, 2 200 of
+    //      them on the vector pipe, took 17 of the launch's 21 us), so nothing here divides by a run-time value on the vector pipe
+    //      (A is 64 or 128; the column split of the context goes through a float reciprocal), and the address of every request is
+    //      a wave-uniform base plus a 32-bit per-lane byte offset that advances by additions (round 4: 139 quarter-rate integer
+    //      multiplies and 83 64-bit multiply-adds per wave before).
+    const int dc = ((p.nch == 2 ? (Dm + 1) >> 1 : Dm) + 3) & ~3;
     const int d0 = ch * dc, d1 = min(Dm, d0 + dc);
     const int nc4 = max(0, (d1 - d0) >> 2);
-    const int ng = nc4 > 0 ? max(1, NT / nc4) : 1;
-    const int cg = nc4 > 0 ? tid / nc4 : ng, c4 = nc4 > 0 ? tid % nc4 : 0;
+    const int ng = nc4 > 0 ? max(1, small_div(NT, nc4)) : 1;
+    const int cg = nc4 > 0 ? small_div(tid, nc4) : ng, c4 = nc4 > 0 ? tid - cg * nc4 : 0;
     const int i16 = lane & 15, q4 = lane >> 4;
-    const int nct = A >> 4, ngroups = (NT / 64) / nct;
-    const int wcol = wave % nct, wgrp = wave / nct;
+    const int log2A = A == 128 ? 7 : 6;
+    const int nct = A >> 4, ngroups = A == 128 ? 2 : 4;           // (NT / 64) / nct
+    const int wcol = wave & (nct - 1), wgrp = wave >> (log2A - 4);
     const int a_own = 16 * wcol + i16;
 
     // ---- burst of independent loads.  Every one of them is UNCONDITIONAL on a clamped address and none of the values is touched
@@ -271,27 +291,42 @@ __global__ __launch_bounds__(ATT_BIG) void attn_step_big_kernel(AttnStepArgs p) 
     //      compiler as separate exec-masked blocks with `s_waitcnt vmcnt(0)` between them, and the sequence length - a per-sample
     //      scalar - was waited for right behind its load: five serial round trips in front of the first product.
     int len_raw = p.lengths[b];
-    const int q_ngrp = NT / A, q_g = tid / A, q_a = tid - q_g * A;
+    const int q_ngrp = NT >> log2A, q_g = tid >> log2A, q_a = tid & (A - 1);
     constexpr int KQP = KQ_PER / 2;
     float qp[KQP];
+    {
+        const char* qb = reinterpret_cast<const char*>(p.qpart + (long)b * A);
+        const unsigned q_ks = (unsigned)p.q_ks * 4u;
+        const unsigned qo_max = (unsigned)(p.kq - 1) * q_ks + (unsigned)q_a * 4u, qo_step = (unsigned)q_ngrp * q_ks;
+        unsigned qo = (unsigned)q_g * q_ks + (unsigned)q_a * 4u;
 #pragma unroll
-    for (int k = 0; k < KQP; ++k) {
-        const int kk = min(q_g + k * q_ngrp, p.kq - 1);
-        qp[k] = p.qpart[(long)kk * p.q_ks + (long)b * A + q_a];
+        for (int k = 0; k < KQP; ++k) { qp[k] = *reinterpret_cast<const float*>(qb + min(qo, qo_max)); qo += qo_step; }
     }
     const float v_r = p.v[min(tid, A - 1)];
     const float bias_r = p.bias[min(tid, A - 1)];
     const float cum_r = p.cum_in[(long)b * L + min(tid, L - 1)];
-    float mtD[NTE][4], us[NU_MAX / 2];
+    float mtD[NTE][4], us[4];
+    {
+        const char* mtb = reinterpret_cast<const char*>(p.Mt + (long)b * L * A);
+        const unsigned mo_max = (unsigned)((L - 1) * A + a_own) * 4u, rowb = (unsigned)A * 4u;
+        unsigned mo[4];
+        mo[0] = (unsigned)(4 * q4 * A + a_own) * 4u;
 #pragma unroll
-    for (int j = 0; j < NTE; ++j)
+        for (int r = 1; r < 4; ++r) mo[r] = mo[r - 1] + rowb;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int l = min(16 * (wgrp + ngroups * j) + 4 * q4 + r, L - 1);
-            mtD[j][r] = p.Mt[((long)b * L + l) * A + a_own];
+        for (int j = 0; j < NTE; ++j) {
+            const unsigned tb = (unsigned)(16 * (wgrp + ngroups * j)) * rowb;           // wave-uniform
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mtD[j][r] = *reinterpret_cast<const float*>(mtb + min(tb + mo[r], mo_max));
         }
+    }
+    // filter bank: thread (channel tid >> 3, taps 4 (tid & 7) .. + 3)
+    const int ua = tid >> 3, uj = (tid & 7) * 4;
+    {
+        const int u0 = min(ua, A - 1) * ksz + uj, umax = A * ksz - 1;
 #pragma unroll
-    for (int j = 0; j < NU_MAX / 2; ++j) us[j] = p.U[min(tid + j * NT, A * ksz - 1)];
+        for (int e = 0; e < 4; ++e) us[e] = p.U[min(u0 + e, umax)];
+    }
 
     // ---- q partial sums, v, bias, filter bank, cumulative alignment -> LDS
     {
@@ -300,13 +335,13 @@ __global__ __launch_bounds__(ATT_BIG) void attn_step_big_kernel(AttnStepArgs p) 
         for (int k = 0; k < KQP; ++k) qs += (q_g + k * q_ngrp < p.kq) ? qp[k] : 0.f;
         part[tid] = qs;
     }
-    if (tid < A) { vv[tid] = v_r; bias[tid] = bias_r; }
-#pragma unroll
-    for (int j = 0; j < NU_MAX / 2; ++j) {
-        const int i = tid + j * NT;
-        if (i < A * ksz) { const int a = i / ksz, jj = i - a * ksz; Up[a * UP_LD + jj] = us[j]; }
+    if (tid < A) {
+        vv[tid] = v_r; bias[tid] = bias_r;
+        *reinterpret_cast<float4*>(Up + tid * UP_LD + 32) = make_float4(0.f, 0.f, 0.f, 0.f);            // pad floats of the row
     }
-    for (int i = tid; i < A * (UP_LD - ksz); i += NT) { const int a = i / (UP_LD - ksz), jj = ksz + i % (UP_LD - ksz); Up[a * UP_LD + jj] = 0.f; }
+    if (ua < A)
+        *reinterpret_cast<float4*>(Up + ua * UP_LD + uj) = make_float4(uj < ksz ? us[0] : 0.f, uj + 1 < ksz ? us[1] : 0.f,
+                                                                       uj + 2 < ksz ? us[2] : 0.f, uj + 3 < ksz ? us[3] : 0.f);
     if (tid < L) cumw[pad + tid] = cum_r;
     if (tid < pad) cumw[tid] = 0.f;
     if (tid < 64 - pad) cumw[pad + L + tid] = 0.f;
@@ -315,12 +350,11 @@ __global__ __launch_bounds__(ATT_BIG) void attn_step_big_kernel(AttnStepArgs p) 
     // (query partials, filter bank) are free again, they travel under the location features, the energies and the softmax
     float4 mem4[ATT_BIG_NCM];
     {
-        const float* mem = p.memory + (long)b * L * Dm + (nc4 > 0 ? d0 + c4 * 4 : 0);
+        const char* mb = reinterpret_cast<const char*>(p.memory + (long)b * L * Dm + (nc4 > 0 ? d0 : 0));
+        const unsigned eo_max = (unsigned)((L - 1) * Dm + c4 * 4) * 4u, eo_step = (unsigned)(ng * Dm) * 4u;
+        unsigned eo = (unsigned)(cg * Dm + c4 * 4) * 4u;
 #pragma unroll
-        for (int j = 0; j < ATT_BIG_NCM; ++j) {
-            const int l = min(cg + j * ng, L - 1);
-            mem4[j] = *reinterpret_cast<const float4*>(mem + (long)l * Dm);
-        }
+        for (int j = 0; j < ATT_BIG_NCM; ++j) { mem4[j] = *reinterpret_cast<const float4*>(mb + min(eo, eo_max)); eo += eo_step; }
     }
     if (tid < A) {
         float qs = 0.f;
@@ -350,7 +384,7 @@ __global__ __launch_bounds__(ATT_BIG) void attn_step_big_kernel(AttnStepArgs p) 
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = row16_sum(va * tanhf_(qa + mtD[j][r] + acc[r]));
+                    const float e = row16_sum(va * tanh_rcp_(qa + mtD[j][r] + acc[r]));
                     const int l = l0t + 4 * q4 + r;
                     if (i16 == 0 && l < L) es[wcol * ATT_BIG_ES + l] = e;
                 }
