@@ -707,8 +707,8 @@ float mtts_prof_empty_ms(void);
 
 const char* mtts_last_error(void);
 int mtts_version(void);
-/* Bitmask of timing-experiment compile switches baked into this library (1 = MTTS_DBG_SKIP_GEN_STEPS, 2 = MTTS_DBG_SKIP_WGRAD; such a
- * build computes WRONG results on purpose).  0 for every production build. */
+/* Bitmask of compile-time switches that make a build compute WRONG results on purpose (timing experiments).  The product sources
+ * have none left (round 4); always 0 - bindings keep refusing anything else. */
 int mtts_build_flags(void);
 /* sizeof() of the structs above in declaration order (0 = GemmArgs ... 6 = BiLstmArgs, 7 = AttnBwdArgs, 8 = DecoderGradArgs, 9 = BiLstmGradArgs, 10 = TacoLossArgs, 11 = AdamArgs, 12 = LstmPackArgs, 13 = LstmStepArgs, 14 = GenParamsArgs); -1 when out of range */
 int mtts_sizeof_struct(int which);

@@ -34,7 +34,7 @@ def _compile(src, obj):
 
 def _flags_stamp(bdir):
     """The object cache is only valid for the flags it was built with: a change of FLAGS / MTTS_EXTRA_FLAGS (A/B builds with
-    -DMTTS_DBG_* switches!) rebuilds everything instead of silently linking stale objects."""
+    -D switches) rebuilds everything instead of silently linking stale objects."""
     import hashlib
     want = hashlib.sha256(" ".join(FLAGS + os.environ.get("MTTS_EXTRA_FLAGS", "").split()).encode()).hexdigest()
     path = os.path.join(bdir, "flags.sha256")

@@ -44,7 +44,6 @@ constexpr int UP_LD = 36;     // filter-bank row: 32 taps + 4 pad floats (confli
 
 template <int G, int NE4_MAX, int NMT = 2>     // G = A / 4 lanes per position (16 or 32); NMT 16-row tiles of PL_next per workgroup
 __global__ __launch_bounds__(ATT_THREADS) void attn_step_kernel(AttnStepArgs p) {
-    step_prio();
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x, ch = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -254,7 +253,6 @@ constexpr int ATT_BIG_ES = 272;      // row of the partial-energy buffer (>= 16 
 
 template <int NTE>                   // row tiles of 16 positions per wave: L <= 16 * NTE * (16 / (A / 16))
 __global__ __launch_bounds__(ATT_BIG) void attn_step_big_kernel(AttnStepArgs p) {
-    step_prio();
     constexpr int NT = ATT_BIG;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.x, ch = blockIdx.y;

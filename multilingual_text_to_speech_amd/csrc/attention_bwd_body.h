@@ -41,7 +41,6 @@ constexpr int BG_LD = 34;     // g tile row (32 taps + pad)
 
 template <int NP = BNP_MAX>
 __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& p, float* sm, const int b, const int ch) {
-    step_prio();
     const int tid = threadIdx.x, lane = tid & 63, nwaves = ATB_THREADS / 64;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int L = p.L, A = p.A, Dm = p.Dm, ksz = p.ksz, pad = (ksz - 1) / 2;

@@ -16,19 +16,10 @@ int mtts_fail(const char* fmt, ...) {
 MTTS_API const char* mtts_last_error(void) { return g_mtts_err; }
 MTTS_API int mtts_version(void) { return 100; }
 
-// Bitmask of the timing-experiment switches this library was compiled with (each of them produces WRONG results by design):
-//   1 = MTTS_DBG_SKIP_GEN_STEPS, 2 = MTTS_DBG_SKIP_WGRAD.  0 for every production build; bindings must refuse anything else
+// Bitmask of compile-time switches that make a build produce WRONG results by design (timing experiments).  The product sources have
+// none (round 4 removed the last two); the entry stays so that bindings keep refusing a library that reports anything but 0
 // (multilingual_text_to_speech_amd._C.lib() does unless MTTS_ALLOW_DEBUG_LIB=1).
-MTTS_API int mtts_build_flags(void) {
-    int f = 0;
-#ifdef MTTS_DBG_SKIP_GEN_STEPS
-    f |= 1;
-#endif
-#ifdef MTTS_DBG_SKIP_WGRAD
-    f |= 2;
-#endif
-    return f;
-}
+MTTS_API int mtts_build_flags(void) { return 0; }
 
 // sizeof() of the ABI structs, in header order, so that bindings can verify their mirrors.
 MTTS_API int mtts_sizeof_struct(int which) {
@@ -95,17 +86,12 @@ StreamCtx* ctx_locked(hipStream_t s) {
     return c;
 }
 
-// which: 0 = side stream (generator chain), 1 = weight-gradient stream.  MTTS_SIDE_PRIO / MTTS_WGRAD_PRIO = "hi" | "mid" override the
-// least priority both get by default (tuning knob, scripts/ab_multi.sh).
-hipStream_t low_priority_stream(int which) {
+// Helper streams get the least priority (higher ones were measured with no effect on the train step, round 2).
+hipStream_t low_priority_stream() {
     int lo = 0, hi = 0;
     if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;      // lo = least priority (numerically largest)
-    int prio = lo;
-    const char* e = getenv(which == 0 ? "MTTS_SIDE_PRIO" : "MTTS_WGRAD_PRIO");
-    if (e && e[0] == 'h') prio = hi;
-    else if (e && e[0] == 'm') prio = (lo + hi) / 2;
     hipStream_t st = nullptr;
-    if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio) != hipSuccess) st = nullptr;
+    if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, lo) != hipSuccess) st = nullptr;
     return st;
 }
 }  // namespace
@@ -114,7 +100,7 @@ hipStream_t low_priority_stream(int which) {
 hipStream_t side_stream(hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_mu);
     StreamCtx* c = ctx_locked(s);
-    if (!c->side) c->side = low_priority_stream(0);
+    if (!c->side) c->side = low_priority_stream();
     return c->side;
 }
 
@@ -122,7 +108,7 @@ hipStream_t side_stream(hipStream_t s) {
 hipStream_t wgrad_stream(hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_mu);
     StreamCtx* c = ctx_locked(s);
-    if (!c->wgrad) c->wgrad = low_priority_stream(1);
+    if (!c->wgrad) c->wgrad = low_priority_stream();
     return c->wgrad;
 }
 

@@ -29,16 +29,6 @@ int mtts_fail(const char* fmt, ...);
         if (!(cond)) return mtts_fail(__VA_ARGS__);                                  \
     } while (0)
 
-// Wave priority of the latency-critical step kernels (experiment, compiled out by default).  A step kernel shares its CU with
-// long-running GEMM workgroups of the helper streams; raising its waves' issue priority (s_setprio 3) was measured
-// on one box with scripts/ab_build.sh: 89.6-90.3 ms per train step with it, 88.6-89.5 without - no gain, so it stays off.
-// -DMTTS_STEP_PRIO builds with it.
-__device__ __forceinline__ void step_prio() {
-#ifdef MTTS_STEP_PRIO
-    __builtin_amdgcn_s_setprio(3);
-#endif
-}
-
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 

@@ -87,9 +87,6 @@ static LstmStepArgs gen_step_args(const DecoderArgs& a, int t) {
 
 // recurrent steps [c0, c1) of the generator LSTM on their own (side-stream chain / tail of the fused schedule)
 static int gen_steps(const DecoderArgs& a, int c0, int c1, hipStream_t s) {
-#ifdef MTTS_DBG_SKIP_GEN_STEPS        // timing experiment only (wrong results): what chain A costs without chain B's step kernels
-    return 0;
-#endif
     const int B = a.B, H = a.H;
     const long BH = (long)B * H, B4H = 4 * BH;
     const bool use_ls = gen_uses_lstep(a);

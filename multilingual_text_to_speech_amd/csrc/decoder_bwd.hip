@@ -258,9 +258,6 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
         GemmArgs q; memset(&q, 0, sizeof(q));
         q.taps = 1; q.batch = 1; q.zt = 1; q.alpha = 1.f; q.mask_scale = 1.f; q.nosplit = 2; q.transA = 1; q.transB = 1;
         q.A = dY; q.lda = ldy; q.M = Mw; q.B = X; q.ldb = ldx; q.N = Nw; q.C = dW; q.ldc = ldw; q.K = rows; q.Kc = rows; q.beta = beta;
-#ifdef MTTS_DBG_SKIP_WGRAD            // timing experiment only (wrong gradients): what the third stream's weight-gradient GEMMs cost the step
-        return 0;
-#endif
         return mtts_gemm_ex(&q, sw);
     };
     {
@@ -296,9 +293,7 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
             k.dgates_out = g.dG_gen + t * B4H; k.ld_dgates = 4 * H;
             k.dg_pack_out = g.dG_gen_p ? g.dG_gen_p + t * Bp4H : nullptr;
             bwd_reg(a, k, a.gen_hmask, a.gen_cmask, t);
-#ifndef MTTS_DBG_SKIP_GEN_STEPS        // timing experiment only (wrong results): chain A's cost without chain B's step kernels
             MTTS_TRY(skinny_launch(k, sb));
-#endif
             if (t > 0) {
                 SkinnyArgs q; memset(&q, 0, sizeof(q));
                 q.nseg = 1; q.B = B; q.N = H; q.ksplit = ksb;
@@ -306,9 +301,7 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
                 if (g.dG_gen_p) { q.seg[0].x = g.dG_gen_p + t * Bp4H; q.seg[0].xpack = 1; }
                 if (g.gen_w_hh_Tp) { q.seg[0].w = g.gen_w_hh_Tp; q.seg[0].wpack = 1; }
                 q.out = g.part_gen; q.ldo = H; q.out_ks = BH;
-#ifndef MTTS_DBG_SKIP_GEN_STEPS
                 MTTS_TRY(skinny_launch(q, sb));
-#endif
             }
         }
         // input gradients of the generator LSTM for this chunk: dHA = dG_gen W_ih[:, :H];  dctx_all[1:] += dG_gen W_ih[:, H:]

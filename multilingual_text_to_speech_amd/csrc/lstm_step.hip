@@ -136,7 +136,6 @@ struct LsGates {
 
 template <int PREC, int NB>      // NB: k-blocks per K-slice held in registers (the smallest instantiation that fits is launched)
 __device__ __forceinline__ void lstm_gates_body(const LsGates& p, const int bid, char* sm) {
-    step_prio();
     constexpr int NPL = PREC ? 1 : 3;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -275,7 +274,6 @@ struct LsCell {
 constexpr int LC_MAXCT = 4;      // query column tiles per wave: A <= 4 waves x 4 x 16 = 256
 
 __device__ __forceinline__ void lstm_cell_q_body(const LsCell& p, float (&hs)[16][17]) {
-    step_prio();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ut = blockIdx.x, rt = blockIdx.y;
     const int r = tid >> 4, uu = tid & 15;
@@ -481,7 +479,6 @@ __device__ __forceinline__ void lf_cell_epilogue(const LsCell& c, const LfCellOp
 
 template <int PREC, int NRT, int DEPTH>
 __global__ __launch_bounds__(LS_THREADS, 4) void lstm_fused_kernel(LsFused p) {
-    step_prio();
     static_assert(DEPTH == 4 || DEPTH == 2, "the LDS double buffer follows the parity of the slot index");
     constexpr int RPW = 32 * NRT;                           // rows per workgroup
     // PREC 0: fp32 operands, exact products on v_mfma_f32_16x16x4_f32.  PREC 1: bf16 operands (the bf16 path).  PREC 2: fp32 operands
@@ -685,7 +682,6 @@ template <int PREC, int NRT> struct Lf2Geom {
 
 template <int PREC, int NRT>
 __global__ __launch_bounds__(LS_THREADS, 2) void lstm_fused2_kernel(LsFused p) {
-    step_prio();
     static_assert(PREC == 1 || PREC == 2, "plane products only (fp32 MFMA: lstm_fused_kernel<0, ..>)");
     using G = Lf2Geom<PREC, NRT>;
     // 128-k blocks in flight (global -> registers): weights DW, activations DX.  The activations are consumed one block EARLIER than the

@@ -269,7 +269,6 @@ __device__ __forceinline__ void bwd_cell(const SkinnyArgs& p, const float (&red)
 template <int MT, int DEPTH = 4, int PK = 0, int PLAIN = 0>
 __device__ __forceinline__ void skinny_body(const SkinnyArgs& p, float (&red)[NW][MT * 16][17], const int cb, const int row_tile,
                                             const int ks) {
-    step_prio();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
