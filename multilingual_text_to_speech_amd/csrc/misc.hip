@@ -145,8 +145,14 @@ __global__ void colsum_final_kernel(const float* __restrict__ ws, float* __restr
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= cols) return;
     float s = 0.f;
-#pragma unroll 8
-    for (int k = 0; k < nch; ++k) s += ws[(long)k * cols + c];
+    for (int k0 = 0; k0 < nch; k0 += 16) {          // sixteen slabs per memory round trip, added in slab order
+        float ps[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) ps[j] = ws[(long)min(k0 + j, nch - 1) * cols + c];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (k0 + j < nch) s += ps[j];
+    }
     out[c] = s;
 }
 

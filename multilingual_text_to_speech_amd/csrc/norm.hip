@@ -11,6 +11,11 @@
 #include "common.h"
 
 constexpr int NCHUNK_MAX = 128;
+// Rows a thread requests before it touches the first value (statistics passes 8, backward passes 4 x (x, dy, keep flag)): written
+// row by row every iteration of these column loops was one memory round trip for 4-5 requests per thread - the round-4 trace had
+// the backward apply pass at 136 us and the backward reduction at 89 us for 253 / 175 MB (floors 63 / 44 us at the copy rate).
+constexpr int BN_U = 8;
+constexpr int BN_UB = 4;
 
 
 __device__ __forceinline__ int bn_chunks(int R) {
@@ -27,7 +32,14 @@ __global__ void bn_sum_kernel(BnArgs p) {
     const int r0 = blockIdx.y * rows_per, r1 = min(p.R, r0 + rows_per);
     float s = 0.f;
     if (c < p.C)
-        for (int r = r0 + threadIdx.y; r < r1; r += 4) s += p.x[(long)r * p.C + c];
+        for (int r = r0 + threadIdx.y; r < r1; r += 4 * BN_U) {      // BN_U rows REQUESTED per round trip, added in row order
+            float v[BN_U];
+#pragma unroll
+            for (int u = 0; u < BN_U; ++u) v[u] = p.x[(long)min(r + 4 * u, r1 - 1) * p.C + c];
+#pragma unroll
+            for (int u = 0; u < BN_U; ++u)
+                if (r + 4 * u < r1) s += v[u];
+        }
     red[threadIdx.y][threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.y == 0 && c < p.C)
@@ -44,9 +56,23 @@ __global__ void bn_var_kernel(BnArgs p) {
     float s = 0.f;
     if (c < p.C) {
         float m = 0.f;
-        for (int k = 0; k < nch; ++k) m += p.ws[(long)k * p.C + c];
+        for (int k0 = 0; k0 < nch; k0 += 16) {      // sixteen slabs per memory round trip, added in slab order (see bn_finalize_kernel)
+            float pm[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) pm[j] = p.ws[(long)min(k0 + j, nch - 1) * p.C + c];
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (k0 + j < nch) m += pm[j];
+        }
         m /= (float)p.R;
-        for (int r = r0 + threadIdx.y; r < r1; r += 4) { float d = p.x[(long)r * p.C + c] - m; s += d * d; }
+        for (int r = r0 + threadIdx.y; r < r1; r += 4 * BN_U) {
+            float v[BN_U];
+#pragma unroll
+            for (int u = 0; u < BN_U; ++u) v[u] = p.x[(long)min(r + 4 * u, r1 - 1) * p.C + c];
+#pragma unroll
+            for (int u = 0; u < BN_U; ++u)
+                if (r + 4 * u < r1) { const float d = v[u] - m; s += d * d; }
+        }
     }
     red[threadIdx.y][threadIdx.x] = s;
     __syncthreads();
@@ -59,7 +85,19 @@ __global__ void bn_finalize_kernel(BnArgs p, int nch) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= p.C) return;
     float m = 0.f, v = 0.f;
-    for (int k = 0; k < nch; ++k) { m += p.ws[(long)k * p.C + c]; v += p.ws[(long)(NCHUNK_MAX + k) * p.C + c]; }
+    // the partial slabs are REQUESTED sixteen at a time and added in slab order (same sums as a plain loop, which the compiler runs
+    // as one memory round trip per slab: 33 us per launch at 128 slabs for a kernel of two workgroups - round-4 trace)
+    for (int k0 = 0; k0 < nch; k0 += 16) {
+        float pm[16], pv[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int k = min(k0 + j, nch - 1);
+            pm[j] = p.ws[(long)k * p.C + c]; pv[j] = p.ws[(long)(NCHUNK_MAX + k) * p.C + c];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (k0 + j < nch) { m += pm[j]; v += pv[j]; }
+    }
     m /= (float)p.R;
     const float var_b = v / (float)p.R;
     p.save_mean[c] = m;
@@ -137,6 +175,30 @@ __device__ __forceinline__ float bn_dz(const BnArgs& p, long r, int c, float& xh
     return dz;
 }
 
+// Plain (non-highway) blocks: per-column constants in registers, operands of BN_UB rows requested together.
+struct BnCol { float mean, rstd, gamma, beta; };
+struct BnRows { float x[BN_UB], dy[BN_UB]; int keep[BN_UB]; };
+__device__ __forceinline__ void bn_rows_load(const BnArgs& p, int r, int r1, int c, BnRows& w) {
+    const uint8_t* mk = p.mask ? p.mask : reinterpret_cast<const uint8_t*>(p.x);      // absent mask: any readable bytes, ignored below
+#pragma unroll
+    for (int u = 0; u < BN_UB; ++u) {
+        const long i = (long)min(r + 4 * u, r1 - 1) * p.C + c;
+        w.x[u] = p.x[i]; w.dy[u] = p.dy[i]; w.keep[u] = (int)mk[i];
+    }
+}
+__device__ __forceinline__ float bn_dz_plain(const BnArgs& p, const BnCol& k, float x, float dy, int keep, float& xhat) {
+    xhat = (x - k.mean) * k.rstd;
+    const float z = xhat * k.gamma + k.beta;
+    const float a = apply_act(p.act, z);
+    float da = dy;
+    if (p.mask) da = keep ? da * p.mask_scale : 0.f;
+    float dz = da;
+    if (p.act == MTTS_ACT_RELU) dz = z > 0.f ? da : 0.f;
+    else if (p.act == MTTS_ACT_TANH) dz = da * (1.f - a * a);
+    else if (p.act == MTTS_ACT_SIGMOID) dz = da * a * (1.f - a);
+    return dz;
+}
+
 // bwd pass 1: partial sums of dz and dz*xhat per channel -> ws[0..nch), ws[NCHUNK_MAX..)
 __global__ void bn_bwd_reduce_kernel(BnArgs p) {
     __shared__ float red[2][4][64];
@@ -145,11 +207,20 @@ __global__ void bn_bwd_reduce_kernel(BnArgs p) {
     const int rows_per = (p.R + nch - 1) / nch;
     const int r0 = blockIdx.y * rows_per, r1 = min(p.R, r0 + rows_per);
     float s1 = 0.f, s2 = 0.f;
-    if (c < p.C)
+    if (c < p.C && !p.hw_groups) {
+        const BnCol k = {p.save_mean[c], p.save_rstd[c], p.gamma[c], p.beta[c]};
+        for (int r = r0 + threadIdx.y; r < r1; r += 4 * BN_UB) {
+            BnRows w; bn_rows_load(p, r, r1, c, w);
+#pragma unroll
+            for (int u = 0; u < BN_UB; ++u)
+                if (r + 4 * u < r1) { float xh; const float dz = bn_dz_plain(p, k, w.x[u], w.dy[u], w.keep[u], xh); s1 += dz; s2 += dz * xh; }
+        }
+    } else if (c < p.C) {
         for (int r = r0 + threadIdx.y; r < r1; r += 4) {
             float xh; const float dz = bn_dz(p, r, c, xh);
             s1 += dz; s2 += dz * xh;
         }
+    }
     red[0][threadIdx.y][threadIdx.x] = s1; red[1][threadIdx.y][threadIdx.x] = s2;
     __syncthreads();
     if (threadIdx.y == 0 && c < p.C) {
@@ -166,13 +237,36 @@ __global__ void bn_bwd_apply_kernel(BnArgs p, int nch) {
     const int rows_per = (p.R + nchy - 1) / nchy;
     const int r0 = blockIdx.y * rows_per, r1 = min(p.R, r0 + rows_per);
     float sdz = 0.f, sdzx = 0.f;
-    for (int k = 0; k < nch; ++k) { sdz += p.ws[(long)k * p.C + c]; sdzx += p.ws[(long)(NCHUNK_MAX + k) * p.C + c]; }
+    for (int k0 = 0; k0 < nch; k0 += 16) {          // sixteen slabs per memory round trip, added in slab order (see bn_finalize_kernel)
+        float p1[16], p2[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int k = min(k0 + j, nch - 1);
+            p1[j] = p.ws[(long)k * p.C + c]; p2[j] = p.ws[(long)(NCHUNK_MAX + k) * p.C + c];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (k0 + j < nch) { sdz += p1[j]; sdzx += p2[j]; }
+    }
     if (blockIdx.y == 0 && threadIdx.y == 0) {
         if (p.dgamma) p.dgamma[c] = sdzx;
         if (p.dbeta) p.dbeta[c] = sdz;
     }
     const float g = p.gamma[c], rs = p.save_rstd[c];
     const float invR = 1.f / (float)p.R;
+    if (!p.hw_groups) {
+        const BnCol k = {p.save_mean[c], rs, g, p.beta[c]};
+        for (int r = r0 + threadIdx.y; r < r1; r += 4 * BN_UB) {
+            BnRows w; bn_rows_load(p, r, r1, c, w);
+#pragma unroll
+            for (int u = 0; u < BN_UB; ++u)
+                if (r + 4 * u < r1) {
+                    float xh; const float dz = bn_dz_plain(p, k, w.x[u], w.dy[u], w.keep[u], xh);
+                    p.dx[(long)(r + 4 * u) * p.C + c] = p.training ? g * rs * (dz - sdz * invR - xh * sdzx * invR) : g * rs * dz;
+                }
+        }
+        return;
+    }
     for (int r = r0 + threadIdx.y; r < r1; r += 4) {
         float xh; const float dz = bn_dz(p, r, c, xh);
         float dxv;
