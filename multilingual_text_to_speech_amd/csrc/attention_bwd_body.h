@@ -78,31 +78,50 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& p, float* sm, c
         const int d = min(tid + j * ATB_THREADS, Dm - 1);
         float g = p.dctx[(long)b * Dm + d];
         float pp[NP];
+        const char* pb = reinterpret_cast<const char*>(p.part + (long)b * p.part_ld);
+        const unsigned pstep = (unsigned)p.part_ks * 4u;
+        unsigned po = (unsigned)d * 4u;
 #pragma unroll
-        for (int k = 0; k < NP; ++k) pp[k] = (k < p.n_part) ? p.part[(long)k * p.part_ks + (long)b * p.part_ld + d] : 0.f;
+        for (int k = 0; k < NP; ++k) { pp[k] = (k < p.n_part) ? *reinterpret_cast<const float*>(pb + po) : 0.f; po += pstep; }
 #pragma unroll
         for (int k = 0; k < NP; ++k) g += pp[k];
         dcx[j] = g;
         cx[j] = p.ctx[(long)b * Dm + d];
     }
+    // Addresses of the burst = wave-uniform base + 32-bit per-lane byte offset (round 4: the kernel issues ~1 100 vector instructions
+    // per wave at four waves per SIMD; a third of them were 64-bit address arithmetic and run-time integer divisions).
     float memr[BNR_MAX][BND_MAX];
+    {
+        unsigned mo[BND_MAX];
 #pragma unroll
-    for (int j = 0; j < BNR_MAX; ++j) {
-        const int l = min(l0 + wave + j * nwaves, L - 1);
-        const float* mem = p.memory + ((long)b * L + l) * Dm;
+        for (int k = 0; k < BND_MAX; ++k) mo[k] = (unsigned)min(lane + 64 * k, Dm - 1) * 4u;
 #pragma unroll
-        for (int k = 0; k < BND_MAX; ++k) memr[j][k] = mem[min(lane + 64 * k, Dm - 1)];
+        for (int j = 0; j < BNR_MAX; ++j) {
+            const int l = min(l0 + wave + j * nwaves, L - 1);                          // wave-uniform
+            const char* mem = reinterpret_cast<const char*>(p.memory + ((long)b * L + l) * Dm);
+#pragma unroll
+            for (int k = 0; k < BND_MAX; ++k) memr[j][k] = *reinterpret_cast<const float*>(mem + mo[k]);
+        }
     }
     // operands in the MFMA accumulator layout: rows 16*mt + 4*q4 + r, column 16*wave + i16
     const int a_own = min(16 * wave + i16, A - 1);
     float mtD[2][4], dmtD[2][4];
+    {
+        const char* mtb = reinterpret_cast<const char*>(p.Mt + (long)b * L * A);
+        const char* dmb = reinterpret_cast<const char*>(p.dMt + (long)b * L * A);
+        const unsigned rowb = (unsigned)A * 4u, omax = (unsigned)((L - 1) * A + a_own) * 4u;
+        unsigned o = (unsigned)((l0 + 4 * q4) * A + a_own) * 4u;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const long off = ((long)b * L + min(l0 + 16 * mt + 4 * q4 + r, L - 1)) * A + a_own;
-            mtD[mt][r] = p.Mt[off]; dmtD[mt][r] = p.dMt[off];
+            for (int r = 0; r < 4; ++r) {
+                const unsigned oc = min(o, omax);
+                mtD[mt][r] = *reinterpret_cast<const float*>(mtb + oc); dmtD[mt][r] = *reinterpret_cast<const float*>(dmb + oc);
+                o += rowb;
+            }
+            o += 12u * rowb;                                                           // next 16-row tile
         }
+    }
     // The v / bias slabs of this (sample, chunk) have ONE writer per launch: no-return float atomics at L2 give the same result as
     // load + add + store without a load in the entry burst.  (Not so for dMt and the filter-bank slab: a million single-dword atomics per
     // launch are L2-rate bound - 15.6 against 12.6 us per launch, scripts/mb/mb_attn_bwd.hip.)
@@ -112,10 +131,6 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& p, float* sm, c
     if (tid < L) { w[tid] = w_r; dex[tid] = dal_r + dco_r; cumw[pad + tid] = cum_r; }
     if (tid < pad) cumw[tid] = 0.f;
     if (tid < 64 - pad) cumw[pad + L + tid] = 0.f;
-    for (int i = tid; i < A * (32 - ksz); i += ATB_THREADS) {      // zero taps ksz..31
-        const int a = i / (32 - ksz), jj = ksz + i % (32 - ksz);
-        Up[a * BUP_LD + jj] = 0.f; UT[jj * DS_LD + a] = 0.f;
-    }
     float sdot = 0.f;
 #pragma unroll
     for (int j = 0; j < BNX_MAX; ++j) {
@@ -133,9 +148,14 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& p, float* sm, c
     ATB_STAMP(1);                                         // loads landed, operands staged in LDS
     // the filter bank (the same 16 KB for every workgroup and step: L2 hits) is requested now and staged behind the dw stage, which
     // covers its latency; in the entry burst its 8 registers per thread pushed the 128-VGPR fused launch into spills
+    // thread (channel ua = tid >> 2, taps 8 (tid & 3) .. + 7): no division by the tap count, and the zero taps ksz..31 come with it
     float us[BNU_MAX];
+    const int ua = tid >> 2, uj = (tid & 3) * 8;
+    {
+        const int u0 = min(ua, A - 1) * ksz + uj;
 #pragma unroll
-    for (int j = 0; j < BNU_MAX; ++j) us[j] = p.U[min(tid + j * ATB_THREADS, AK - 1)];
+        for (int j = 0; j < BNU_MAX; ++j) us[j] = p.U[min(u0 + j, AK - 1)];
+    }
     float S = 0.f;                                        // softmax-backward scalar: sum_d dctx ctx + sum_l w (dalign + dcum)
 #pragma unroll
     for (int i = 0; i < ATB_THREADS / 64; ++i) S += red[i];
@@ -159,10 +179,13 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& p, float* sm, c
         acc = wave_total_hi(acc);
         if (lane == 63 && r < BROWS) de[r] = (r < nl) ? w[l0 + r] * (dex[l0 + r] + acc - S) : 0.f;
     }
+    if (ua < A) {
 #pragma unroll
-    for (int j = 0; j < BNU_MAX; ++j) {
-        const int i = tid + j * ATB_THREADS;
-        if (i < AK) { const int a = i / ksz, jj = i - a * ksz; Up[a * BUP_LD + jj] = us[j]; UT[jj * DS_LD + a] = us[j]; }
+        for (int j = 0; j < BNU_MAX; ++j) {
+            const int jj = uj + j;
+            const float u = jj < ksz ? us[j] : 0.f;
+            Up[ua * BUP_LD + jj] = u; UT[jj * DS_LD + ua] = u;
+        }
     }
     // dU slab in the accumulator layout of the dU contraction (rows a = 16*wave + 4*q4 + r, columns tap = 16*nt + i16): requested here,
     // two stages ahead of its use, so that the entry burst stays inside the register budget

@@ -79,6 +79,17 @@ __device__ __forceinline__ float apply_act(int act, float v) {
     }
 }
 
+// (row, col) of the flat index of a grid-stride loop over a [rows, cols] array WITHOUT a division per element: two 64-bit divisions
+// per thread at the start, then additions with one carry.  (`row = i / cols` on a 64-bit index is ~100 vector instructions per
+// element - gemm_splitk_reduce and bn_apply were bound by it, not by their memory traffic; round 4.)
+struct GridRC {
+    long row, dr; int col, dc, cols;
+    __device__ __forceinline__ GridRC(long i0, long stride, int cols_) {
+        cols = cols_; row = i0 / cols; col = (int)(i0 - row * cols); dr = stride / cols; dc = (int)(stride - dr * cols);
+    }
+    __device__ __forceinline__ void next() { col += dc; row += dr; if (col >= cols) { col -= cols; ++row; } }
+};
+
 // ---- internal cross-file entry points (host) ----
 int gemm_plain(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, bool tA,
                bool tB, float alpha, float beta, const float* bias, int act, hipStream_t s);

@@ -145,10 +145,19 @@ __global__ void gemm_splitk_reduce(GemmArgs p, const float* __restrict__ ws, int
     const float* bias = p.bias ? p.bias + (long)zb * p.bias_z : nullptr;
     const long MN = (long)p.M * p.N;
     const float* W = ws + (long)z * S * MN;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < MN; i += (long)gridDim.x * blockDim.x) {
-        const long row = i / p.N; const int col = (int)(i - row * p.N);
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+    GridRC rc(i0, stride, p.N);
+    for (long i = i0; i < MN; i += stride, rc.next()) {
+        const long row = rc.row; const int col = rc.col;
         float a = 0.f;
-        for (int s = 0; s < S; ++s) a += W[s * MN + i];
+        for (int s0 = 0; s0 < S; s0 += 8) {          // eight partial slabs per memory round trip, added in slab order
+            float ps[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ps[j] = W[(long)min(s0 + j, S - 1) * MN + i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (s0 + j < S) a += ps[j];
+        }
         float v = p.alpha * a + (bias ? bias[col] : 0.f);
         float* cp = C + row * p.ldc + col;
         if (p.beta != 0.f) v += p.beta * (*cp);

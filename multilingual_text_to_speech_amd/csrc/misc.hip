@@ -6,8 +6,10 @@
 __global__ void embedding_fwd_kernel(const float* __restrict__ table, const int64_t* __restrict__ ids, float* __restrict__ out,
                                      int rows, int D, int ldo, int col0, long vocab, int* __restrict__ err) {
     const long total = (long)rows * D;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long r = i / D; const int d = (int)(i - r * D);
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+    GridRC rc(i0, stride, D);
+    for (long i = i0; i < total; i += stride, rc.next()) {
+        const long r = rc.row; const int d = rc.col;
         const int64_t id = ids[r];
         const bool ok = id >= 0 && id < vocab;
         if (!ok && d == 0 && err) atomicOr(err, 1);
@@ -18,8 +20,10 @@ __global__ void embedding_fwd_kernel(const float* __restrict__ table, const int6
 __global__ void embedding_bwd_kernel(const float* __restrict__ dout, const int64_t* __restrict__ ids, float* __restrict__ dtable,
                                      int rows, int D, int ldo, int col0, int padding_idx, long vocab) {
     const long total = (long)rows * D;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long r = i / D; const int d = (int)(i - r * D);
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+    GridRC rc(i0, stride, D);
+    for (long i = i0; i < total; i += stride, rc.next()) {
+        const long r = rc.row; const int d = rc.col;
         const int64_t id = ids[r];
         if (id == padding_idx || id < 0 || id >= vocab) continue;
         atomicAdd(dtable + id * D + d, dout[r * ldo + col0 + d]);
@@ -28,8 +32,10 @@ __global__ void embedding_bwd_kernel(const float* __restrict__ dout, const int64
 
 __global__ void copy2d_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols, int ldi, int ldo) {
     const long total = (long)rows * cols;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long r = i / cols; const int c = (int)(i - r * cols);
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+    GridRC rc(i0, stride, cols);
+    for (long i = i0; i < total; i += stride, rc.next()) {
+        const long r = rc.row; const int c = rc.col;
         out[r * ldo + c] = in[r * ldi + c];
     }
 }
@@ -227,8 +233,10 @@ MTTS_API int mtts_pack_rows(const float* src, int ld, int rows, int K, float* ds
 __global__ void add3_kernel(float* __restrict__ out, int ldo, const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
                             const float* __restrict__ c3, int ldc, int rows, int cols, int accumulate) {
     const long total = (long)rows * cols;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long r = i / cols; const int c = (int)(i - r * cols);
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+    GridRC rc(i0, stride, cols);
+    for (long i = i0; i < total; i += stride, rc.next()) {
+        const long r = rc.row; const int c = rc.col;
         float v = accumulate ? out[r * ldo + c] : 0.f;
         if (a) v += a[r * lda + c];
         if (b) v += b[r * ldb + c];

@@ -128,8 +128,10 @@ __device__ __forceinline__ float bn_drop(const BnArgs& p, long r, int c, float a
 __global__ void bn_apply_kernel(BnArgs p) {
     const int Cy = p.hw_groups ? p.C / 2 : p.C;
     const long total = (long)p.R * Cy;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long r = i / Cy; const int cy = (int)(i - r * Cy);
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+    GridRC rc(i0, stride, Cy);
+    for (long i = i0; i < total; i += stride, rc.next()) {
+        const long r = rc.row; const int cy = rc.col;
         if (!p.hw_groups) {
             p.y[i] = bn_drop(p, r, cy, apply_act(p.act, bn_z(p, r, cy)));
         } else {
@@ -280,8 +282,10 @@ __global__ void bn_bwd_apply_kernel(BnArgs p, int nch) {
 __global__ void hw_dresid_kernel(BnArgs p) {
     const int Cy = p.C / 2;
     const long total = (long)p.R * Cy;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long r = i / Cy; const int cy = (int)(i - r * Cy);
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+    GridRC rc(i0, stride, Cy);
+    for (long i = i0; i < total; i += stride, rc.next()) {
+        const long r = rc.row; const int cy = rc.col;
         const int Cg = Cy / p.hw_groups; const int g = cy / Cg, cc = cy - g * Cg;
         const int c1 = g * 2 * Cg + cc;
         const float h1 = bn_drop(p, r, c1, apply_act(p.act, bn_z(p, r, c1)));
