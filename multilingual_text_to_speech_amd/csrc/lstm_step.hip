@@ -274,7 +274,8 @@ struct LsCell {
 constexpr int LC_MAXCT = 4;      // query column tiles per wave: A <= 4 waves x 4 x 16 = 256
 
 __device__ __forceinline__ void lstm_cell_q_body(const LsCell& p, float (&hs)[16][17]) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ut = blockIdx.x, rt = blockIdx.y;
     const int r = tid >> 4, uu = tid & 15;
     const int row = 16 * rt + r, u = 16 * ut + uu;
@@ -910,7 +911,8 @@ __device__ unsigned long long g_pn_stamps[8];
 #endif
 __global__ __launch_bounds__(512) void prenet2_kernel(Prenet2 p) {
     extern __shared__ __attribute__((aligned(16))) float psm[];      // y1 tile [16][P + 4], then the K-half partial sums [4][16][17]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // known wave-uniform: tile bases stay on the scalar unit
     const int i16 = lane & 15, q4 = lane >> 4;
     const int row0 = blockIdx.x * 16, cg = blockIdx.y;
     const int P = p.P, ldh = P + 4, nct = P >> 4, nk2 = P >> 4;
