@@ -150,14 +150,7 @@ __global__ void gemm_splitk_reduce(GemmArgs p, const float* __restrict__ ws, int
     for (long i = i0; i < MN; i += stride, rc.next()) {
         const long row = rc.row; const int col = rc.col;
         float a = 0.f;
-        for (int s0 = 0; s0 < S; s0 += 8) {          // eight partial slabs per memory round trip, added in slab order
-            float ps[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) ps[j] = W[(long)min(s0 + j, S - 1) * MN + i];
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (s0 + j < S) a += ps[j];
-        }
+        for (int s = 0; s < S; ++s) a += W[s * MN + i];       // S is 2..8: a batch of clamped requests would re-read the last slab
         float v = p.alpha * a + (bias ? bias[col] : 0.f);
         float* cp = C + row * p.ldc + col;
         if (p.beta != 0.f) v += p.beta * (*cp);
