@@ -33,6 +33,21 @@ static inline size_t att_lds_bytes(int A, int L, int ksz) {
     return sizeof(float) * ((((size_t)3 * A + 2 * L + ksz - 1 + (size_t)A * ksz + 3) & ~(size_t)3) + 4 * ATT_THREADS);
 }
 
+// floor(a / b) for 0 <= a <= 2048, 1 <= b <= 2048 without the integer-division sequence (~25 vector instructions): float reciprocal
+// + one correction step each way
+__device__ __forceinline__ int small_div(int a, int b) {
+    int q = (int)(((float)a + 0.5f) * __builtin_amdgcn_rcpf((float)b));
+    q -= (q * b > a);
+    q += ((q + 1) * b <= a);
+    return q;
+}
+// tanh with the hardware reciprocal (1 ulp) instead of the IEEE division sequence (10 instructions): the energies of the large-batch
+// kernel evaluate it 4 NTE times per lane
+__device__ __forceinline__ float tanh_rcp_(float x) {
+    const float e = __expf(-2.0f * fabsf(x));
+    return copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // fast kernel: all global loads up front; energies reduced with DPP; the location filter bank runs on MFMA
 //   loc[l, a] = sum_k cumwin[l][k] * U[a][k]   (rows of this workgroup x A x 32 taps  ->  v_mfma_f32_16x16x4_f32)
@@ -59,72 +74,84 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_kernel(AttnStepArgs p) 
     const int LA4 = (L * A) >> 2;
 
     // ---- geometry of this workgroup's shares
-    const int dc = (((Dm + p.nch - 1) / p.nch) + 3) & ~3;
+    // (round 4, as in the large-batch kernel below: no run-time integer division on the vector pipe, addresses = wave-uniform base +
+    //  32-bit per-lane byte offset advanced by additions, every request unconditional, hardware reciprocal in the energies' tanh: at
+    //  batch 1 - four workgroups - this launch was 15.8 us of 4 000 instructions per wave)
+    const int dc = ((int)small_div(Dm + p.nch - 1, p.nch) + 3) & ~3;
     const int d0 = ch * dc, d1 = min(Dm, d0 + dc);
     const int nc4 = max(0, (d1 - d0) >> 2);
-    const int ng = nc4 > 0 ? max(1, ATT_THREADS / nc4) : 1;
-    const int cg = nc4 > 0 ? tid / nc4 : ng, c4 = nc4 > 0 ? tid % nc4 : 0;
-    const int lc = (L + p.nch - 1) / p.nch;
+    const int ng = nc4 > 0 ? max(1, small_div(ATT_THREADS, nc4)) : 1;
+    const int cg = nc4 > 0 ? small_div(tid, nc4) : ng, c4 = nc4 > 0 ? tid - cg * nc4 : 0;
+    const int lc = small_div(L + p.nch - 1, p.nch);
     const int l0 = ch * lc, l1 = min(L, l0 + lc);
     const int i16 = lane & 15, q4 = lane >> 4;
+    const int log2A = A == 128 ? 7 : 6;
 
     // ---- burst of independent loads
     const int len = min(p.lengths[b], L);
     // query partials: thread (group g = tid / A, channel a = tid % A) takes slabs g, g + ngrp, ...
-    const int q_ngrp = ATT_THREADS / A, q_g = tid / A, q_a = tid - q_g * A;
+    const int q_ngrp = ATT_THREADS >> log2A, q_g = tid >> log2A, q_a = tid & (A - 1);
     float qp[KQ_PER];
+    {
+        const char* qb = reinterpret_cast<const char*>(p.qpart + (long)b * A);
+        const unsigned q_ks = (unsigned)p.q_ks * 4u;
+        const unsigned qo_max = (unsigned)(p.kq - 1) * q_ks + (unsigned)q_a * 4u, qo_step = (unsigned)q_ngrp * q_ks;
+        unsigned qo = (unsigned)q_g * q_ks + (unsigned)q_a * 4u;
 #pragma unroll
-    for (int k = 0; k < KQ_PER; ++k) {
-        const int kk = q_g + k * q_ngrp;
-        qp[k] = (kk < p.kq) ? p.qpart[(long)kk * p.q_ks + (long)b * A + q_a] : 0.f;
+        for (int k = 0; k < KQ_PER; ++k) { qp[k] = *reinterpret_cast<const float*>(qb + min(qo, qo_max)); qo += qo_step; }
     }
     const float v_r = p.v[min(tid, A - 1)];
     const float bias_r = p.bias[min(tid, A - 1)];
     const float cum_r = p.cum_in[(long)b * L + min(tid, L - 1)];
     float4 pl4[NE4_MAX];
     {
-        const float4* PLb = reinterpret_cast<const float4*>(p.PL + (long)b * L * A);
+        const char* PLb = reinterpret_cast<const char*>(p.PL + (long)b * L * A);
+        const unsigned po_max = (unsigned)(LA4 - 1) * 16u;
+        unsigned po = (unsigned)tid * 16u;
 #pragma unroll
-        for (int j = 0; j < NE4_MAX; ++j) pl4[j] = PLb[min(tid + j * ATT_THREADS, LA4 - 1)];
+        for (int j = 0; j < NE4_MAX; ++j) { pl4[j] = *reinterpret_cast<const float4*>(PLb + min(po, po_max)); po += ATT_THREADS * 16u; }
     }
     float4 mem4[NC_MAX];
     {
-        const float* mem = p.memory + (long)b * L * Dm + d0 + c4 * 4;
+        const char* mb = reinterpret_cast<const char*>(p.memory + (long)b * L * Dm + (nc4 > 0 ? d0 : 0));
+        const unsigned eo_max = (unsigned)((L - 1) * Dm + c4 * 4) * 4u, eo_step = (unsigned)(ng * Dm) * 4u;
+        unsigned eo = (unsigned)(cg * Dm + c4 * 4) * 4u;
 #pragma unroll
-        for (int j = 0; j < NC_MAX; ++j) {
-            const int l = min(cg + j * ng, L - 1);
-            mem4[j] = (nc4 > 0) ? *reinterpret_cast<const float4*>(mem + (long)l * Dm) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int j = 0; j < NC_MAX; ++j) { mem4[j] = *reinterpret_cast<const float4*>(mb + min(eo, eo_max)); eo += eo_step; }
     }
     float mtD[NMT][4], us[NU_MAX];
     const int a_own = min(16 * wave + i16, A - 1);
+    // filter bank: thread (channel ua = tid >> 2, taps 8 (tid & 3) .. + 7)
+    const int ua = tid >> 2, uj = (tid & 3) * 8;
     if (p.PL_next) {
+        const char* mtb = reinterpret_cast<const char*>(p.Mt + (long)b * L * A);
+        const unsigned rowb = (unsigned)A * 4u, omax = (unsigned)((L - 1) * A + a_own) * 4u;
+        unsigned o = (unsigned)((l0 + 4 * q4) * A + a_own) * 4u;
 #pragma unroll
-        for (int mt = 0; mt < NMT; ++mt)
+        for (int mt = 0; mt < NMT; ++mt) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int l = min(l0 + 16 * mt + 4 * q4 + r, L - 1);
-                mtD[mt][r] = p.Mt[((long)b * L + l) * A + a_own];
-            }
+            for (int r = 0; r < 4; ++r) { mtD[mt][r] = *reinterpret_cast<const float*>(mtb + min(o, omax)); o += rowb; }
+            o += 12u * rowb;
+        }
+        const int u0 = min(ua, A - 1) * ksz + uj, umax = A * ksz - 1;
 #pragma unroll
-        for (int j = 0; j < NU_MAX; ++j) us[j] = p.U[min(tid + j * ATT_THREADS, A * ksz - 1)];
+        for (int j = 0; j < NU_MAX; ++j) us[j] = p.U[min(u0 + j, umax)];
     }
 
     // ---- q partial sums, v, bias, filter bank -> LDS
     {
         float qs = 0.f;
 #pragma unroll
-        for (int k = 0; k < KQ_PER; ++k) qs += qp[k];
+        for (int k = 0; k < KQ_PER; ++k) qs += (q_g + k * q_ngrp < p.kq) ? qp[k] : 0.f;
         part[tid] = qs;
     }
     if (tid < A) { vv[tid] = v_r; bias[tid] = bias_r; }
     if (p.PL_next) {
+        if (ua < A) {
 #pragma unroll
-        for (int j = 0; j < NU_MAX; ++j) {
-            const int i = tid + j * ATT_THREADS;
-            if (i < A * ksz) { const int a = i / ksz, jj = i - a * ksz; Up[a * UP_LD + jj] = us[j]; }
+            for (int j = 0; j < NU_MAX; ++j) Up[ua * UP_LD + uj + j] = (uj + j < ksz) ? us[j] : 0.f;
         }
-        for (int i = tid; i < A * (UP_LD - ksz); i += ATT_THREADS) { const int a = i / (UP_LD - ksz), jj = ksz + i % (UP_LD - ksz); Up[a * UP_LD + jj] = 0.f; }
+        if (tid < A) *reinterpret_cast<float4*>(Up + tid * UP_LD + 32) = make_float4(0.f, 0.f, 0.f, 0.f);      // pad floats of the row
     }
     __syncthreads();
     if (tid < A) {
@@ -143,8 +170,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_kernel(AttnStepArgs p) 
 #pragma unroll
         for (int j = 0; j < NE4_MAX; ++j) {
             const int i4 = tid + j * ATT_THREADS;
-            float e = v4v.x * tanhf_(q4v.x + pl4[j].x) + v4v.y * tanhf_(q4v.y + pl4[j].y) + v4v.z * tanhf_(q4v.z + pl4[j].z) +
-                      v4v.w * tanhf_(q4v.w + pl4[j].w);
+            float e = v4v.x * tanh_rcp_(q4v.x + pl4[j].x) + v4v.y * tanh_rcp_(q4v.y + pl4[j].y) + v4v.z * tanh_rcp_(q4v.z + pl4[j].z) +
+                      v4v.w * tanh_rcp_(q4v.w + pl4[j].w);
             e = group_sum<G>(e);
             if ((lane % G) == 0 && i4 < LA4) w[i4 / G] = e;
         }
@@ -232,21 +259,6 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_step_kernel(AttnStepArgs p) 
 // Wave w = (column tile w % (A / 16), row group w / (A / 16)) owns the row tiles {group + ngroups j}; the partial energies of a
 // column tile are reduced over its 16 lanes (DPP) and summed over the column tiles in a fixed order by the softmax wave.
 // ------------------------------------------------------------------------------------------------------------
-// floor(a / b) for 0 <= a <= 2048, 1 <= b <= 2048 without the integer-division sequence (~25 vector instructions): float reciprocal
-// + one correction step each way
-__device__ __forceinline__ int small_div(int a, int b) {
-    int q = (int)(((float)a + 0.5f) * __builtin_amdgcn_rcpf((float)b));
-    q -= (q * b > a);
-    q += ((q + 1) * b <= a);
-    return q;
-}
-// tanh with the hardware reciprocal (1 ulp) instead of the IEEE division sequence (10 instructions): the energies of the large-batch
-// kernel evaluate it 4 NTE times per lane
-__device__ __forceinline__ float tanh_rcp_(float x) {
-    const float e = __expf(-2.0f * fabsf(x));
-    return copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x);
-}
-
 constexpr int ATT_BIG = 1024;        // threads
 constexpr int ATT_BIG_NCM = 9;       // memory float4 per thread
 constexpr int ATT_BIG_ES = 272;      // row of the partial-energy buffer (>= 16 * 16 positions + pad)
