@@ -357,6 +357,128 @@ __global__ __launch_bounds__(256) void lstm_cell_q_kernel(LsCell p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// V: the whole LSTM step of a batch of ONE or TWO rows in ONE launch (single-utterance synthesis, the reference's synthesize.py mode:
+// Decoder.inference, modules/tacotron2.py:229-242 with layers.py:18-47 and attention.py:68).  With one or two rows the step is a
+// matrix-VECTOR product: the K-split pair G + C spends it on 64-row MFMA tiles and on the exact 3-way split of every weight fragment
+// (14.6 + 4.7 us per LSTM at batch 1 for a 26 MB weight stream, profiles/r04_inference_small_batches.txt).  Here a workgroup owns 16
+// LSTM units = four 16-column groups of the packed weight (the fp32 layout of lstm_pack_kernel, read as it is); wave w = (column group
+// w & 3, k-block parity w >> 2) streams its half of the group's k-blocks as float4 pairs (lane 16 q + i: column i, k = 32 kb + 8 q .. + 7)
+// against the rows' activations (the 16 lanes of a q read the same 32 bytes: one request) on plain fp32 FMA; the four k quads of a
+// column are summed across the lanes, the two k-block parities through LDS in a fixed order; then the cell of lstm_cell_q_body for
+// (row, unit) and the query partials q_part[unit group][B][A] (the same slabs as the other paths: the attention kernel sums H / 16).
+// Inference only (no saved gates, no training dropout): the launcher takes it when gates_out is NULL.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int LV_MAXB = 2;       // rows in registers; with 4 / 8 rows the requests in flight per wave no longer cover the latency (batch 5: 110 vs 77 us per frame)
+struct LsGemv {
+    const float* x0; const float* x1; const float* x2;
+    int K0, K1, K2, ld0, ld1, ld2;
+    const float* wp; int nkb;
+    LsCell c;             // part / KS unused
+};
+
+template <int NB, int UNR>      // NB rows in registers (B <= NB), UNR k-blocks requested together
+__global__ __launch_bounds__(LS_THREADS) void lstm_gemv_kernel(LsGemv p) {
+    __shared__ float gs[8][16][NB];          // [wave][column of the group][row]
+    __shared__ float hs[NB][16];
+    __shared__ float qs[4][NB][128];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ut = blockIdx.x;
+    const int grp = wave & 3, kh = wave >> 2;
+    const int i = lane & 15, q = lane >> 4;
+    const LsCell& c = p.c;
+    const int B = c.B, H = c.H, N = 4 * H;
+
+    // ---- cell / query operands first (threads (row b = tid >> 4, unit uu = tid & 15) and (channel a, unit quad ug))
+    const int cb = tid >> 4, cu = tid & 15;
+    const bool cell_thread = cb < B;
+    const int cbr = min(cb, B - 1), u = 16 * ut + cu;
+    const long hi = (long)cbr * H + u;
+    const float4 bias4 = *reinterpret_cast<const float4*>((c.bias_u ? c.bias_u : c.c_prev) + (c.bias_u ? 4 * u : 0));
+    const float4 pre4 = *reinterpret_cast<const float4*>((c.pre ? c.pre : c.c_prev) + (c.pre ? (long)cbr * c.ldpre + 4 * u : 0));
+    const float cp = c.c_prev[hi];
+    const float hp = (c.h_prev ? c.h_prev : c.c_prev)[hi];
+    const int A = c.qpart ? c.A : 0;
+    const int qa = tid & 127, qg = tid >> 7;                       // A <= 128: channel qa, units 4 qg .. + 3 of the group
+    const float4 wq4 = *reinterpret_cast<const float4*>((A ? c.wq : c.c_prev) + (A ? (long)min(qa, A - 1) * H + 16 * ut + 4 * qg : 0));
+
+    // ---- gate products of this wave: column group grp, k-blocks kb = kh, kh + 2, ...
+    float acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = 0.f;
+    const long jw = (long)(ut >> 1) * 8 + 4 * (ut & 1) + grp;
+    const float4* wb = reinterpret_cast<const float4*>(p.wp) + jw * p.nkb * 128 + lane;      // + (kb * 2 + h) * 64
+    const int nk0 = p.K0 >> 5, nk1 = p.K1 >> 5;
+    for (int kb0 = kh; kb0 < p.nkb; kb0 += 2 * UNR) {
+        float4 w4[UNR][2], x4[UNR][NB][2];
+#pragma unroll
+        for (int un = 0; un < UNR; ++un) {
+            const int kb = min(kb0 + 2 * un, p.nkb - 1);              // wave-uniform; blocks past the end re-read the last one (not added)
+            const bool in0 = kb < nk0, in1 = kb < nk0 + nk1;
+            const float* xs = in0 ? p.x0 : (in1 ? p.x1 : p.x2);
+            const int ld = in0 ? p.ld0 : (in1 ? p.ld1 : p.ld2);
+            const int kk = 32 * (in0 ? kb : (in1 ? kb - nk0 : kb - nk0 - nk1)) + 8 * q;
+            w4[un][0] = wb[(long)kb * 128]; w4[un][1] = wb[(long)kb * 128 + 64];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const float* xr = xs + (long)min(b, B - 1) * ld + kk;
+                x4[un][b][0] = *reinterpret_cast<const float4*>(xr); x4[un][b][1] = *reinterpret_cast<const float4*>(xr + 4);
+            }
+        }
+#pragma unroll
+        for (int un = 0; un < UNR; ++un) {
+            if (kb0 + 2 * un < p.nkb) {                              // wave-uniform
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    float a = acc[b];
+                    a += w4[un][0].x * x4[un][b][0].x; a += w4[un][0].y * x4[un][b][0].y; a += w4[un][0].z * x4[un][b][0].z; a += w4[un][0].w * x4[un][b][0].w;
+                    a += w4[un][1].x * x4[un][b][1].x; a += w4[un][1].y * x4[un][b][1].y; a += w4[un][1].z * x4[un][b][1].z; a += w4[un][1].w * x4[un][b][1].w;
+                    acc[b] = a;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {              // the four k quads of a column: lanes i, i + 16, i + 32, i + 48
+        acc[b] += __shfl_xor(acc[b], 16, 64);
+        acc[b] += __shfl_xor(acc[b], 32, 64);
+        if (q == 0) gs[wave][i][b] = acc[b];
+    }
+    __syncthreads();
+
+    // ---- cell (lstm_cell_q_body's arithmetic): unit cu of the group = column group cu >> 2, columns 4 (cu & 3) + gate
+    if (cell_thread) {
+        const int g = cu >> 2, c0 = 4 * (cu & 3);
+        float gi = gs[g][c0 + 0][cb] + gs[g + 4][c0 + 0][cb], gf = gs[g][c0 + 1][cb] + gs[g + 4][c0 + 1][cb];
+        float gg_ = gs[g][c0 + 2][cb] + gs[g + 4][c0 + 2][cb], go = gs[g][c0 + 3][cb] + gs[g + 4][c0 + 3][cb];
+        if (c.bias_u) { gi += bias4.x; gf += bias4.y; gg_ += bias4.z; go += bias4.w; }
+        if (c.pre) { gi += pre4.x; gf += pre4.y; gg_ += pre4.z; go += pre4.w; }
+        const float ig = sigmoidf_(gi), fg = sigmoidf_(gf), gg = tanhf_(gg_), og = sigmoidf_(go);
+        const float cn = fg * cp + ig * gg;
+        const float hn = og * tanhf_(cn);
+        const float hpv = c.h_prev ? hp : 0.f;
+        float ho = hn, co = cn;
+        if (c.zone == 2) { ho = c.zh * hpv + (1.f - c.zh) * hn; co = c.zc * cp + (1.f - c.zc) * cn; }
+        c.h_out[hi] = ho;
+        c.c_out[hi] = co;
+        hs[cb][cu] = ho;
+    }
+    if (!A) return;
+    __syncthreads();
+    // ---- query partials of the group: q_part[ut][b][a] = sum over its 16 units of h[b][u] W_q[a][u]; four unit quads through LDS
+    if (qa < A) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+            if (b < B) qs[qg][b][qa] = hs[b][4 * qg] * wq4.x + hs[b][4 * qg + 1] * wq4.y + hs[b][4 * qg + 2] * wq4.z + hs[b][4 * qg + 3] * wq4.w;
+    }
+    __syncthreads();
+    for (int e = tid; e < B * A; e += LS_THREADS) {
+        const int b = e / A, a = e - b * A;
+        c.qpart[((long)ut * B + b) * A + a] = ((qs[0][b][a] + qs[1][b][a]) + qs[2][b][a]) + qs[3][b][a];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // F: the whole LSTM step of a LARGE batch (B > 64) in ONE launch - gate GEMM over the full K, cell, query partials.
 // With more than 64 rows there is enough work per launch without splitting K, and the K-split form pays for it: at batch 240 the
 // partial slabs of the two decoder LSTMs are 150 MB of write + read traffic per step (456 MB measured per decoder step against 122 MB
@@ -1183,6 +1305,18 @@ int lstm_step_launch(const LstmStepArgs& a, hipStream_t s) {
             else hipLaunchKernelGGL((lstm_fused_kernel<0, 1, 4>), grid, dim3(LS_THREADS), 0, s, f);
         }
         MTTS_CHECK_LAUNCH("lstm_fused_kernel");
+        return 0;
+    }
+    // one or two rows, inference (no saved gates, no training masks), a lone chain: the GEMV-shaped step (lstm_gemv_kernel)
+    if (a.B <= LV_MAXB && a.precision == 0 && !a.gates_out && !a.hmask && !a.cmask && a.zone != 1 && a.nb_max != 4 && (a.H & 31) == 0 &&
+        (!a.qpart || a.A == 64 || a.A == 128)) {
+        LsGemv v; memset(&v, 0, sizeof(v));
+        v.x0 = g.x0; v.x1 = g.x1; v.x2 = g.x2; v.K0 = g.K0; v.K1 = g.K1; v.K2 = g.K2; v.ld0 = g.ld0; v.ld1 = g.ld1; v.ld2 = g.ld2;
+        v.wp = reinterpret_cast<const float*>(g.wp); v.nkb = g.nkb; v.c = c;
+        const dim3 grid(a.H / 16), blk(LS_THREADS);
+        if (a.B <= 1) hipLaunchKernelGGL((lstm_gemv_kernel<1, 8>), grid, blk, 0, s, v);
+        else hipLaunchKernelGGL((lstm_gemv_kernel<2, 4>), grid, blk, 0, s, v);
+        MTTS_CHECK_LAUNCH("lstm_gemv_kernel");
         return 0;
     }
     MTTS_TRY(ls_set_attrs());
