@@ -12,7 +12,7 @@ from multilingual_text_to_speech_amd._C import check, lib, ptr, stream_ptr
 pytestmark = pytest.mark.gpu
 
 
-def run_step(B, H, Ks, A, precision, zone=0, seed=0, with_pre=True, with_q=True, nb_max=0):
+def run_step(B, H, Ks, A, precision, zone=0, seed=0, with_pre=True, with_q=True, nb_max=0, inference=False):
     g = torch.Generator().manual_seed(seed)
     dev = 'cuda'
     xs = [torch.randn(B, K, generator=g).to(dev) for K in Ks]
@@ -45,9 +45,11 @@ def run_step(B, H, Ks, A, precision, zone=0, seed=0, with_pre=True, with_q=True,
     gates = torch.full((B, 4 * H), float('nan'), device=dev)
     qpart = torch.full((H // 16, B, A), float('nan'), device=dev)
     a.partials, a.pre, a.ldpre, a.bias_u = ptr(part), ptr(pre_u), 4 * H, ptr(bias_u)
-    a.h_prev, a.c_prev, a.h_out, a.c_out, a.gates_out = ptr(h_prev), ptr(c_prev), ptr(h_out), ptr(c_out), ptr(gates)
+    a.h_prev, a.c_prev, a.h_out, a.c_out, a.gates_out = ptr(h_prev), ptr(c_prev), ptr(h_out), ptr(c_out), (None if inference else ptr(gates))
     a.zone = zone
-    if zone == 0:
+    if zone == 0 and inference:
+        pass                                     # eval mode of the dropout cell: no mask, no saved gates
+    elif zone == 0:
         a.hmask, a.hscale = ptr(hmask), 1.0 / 0.9
     elif zone == 1:
         a.hmask, a.cmask = ptr(hmask), ptr(cmask)
@@ -70,7 +72,9 @@ def run_step(B, H, Ks, A, precision, zone=0, seed=0, with_pre=True, with_q=True,
     i_, f_, g_, o_ = torch.sigmoid(i_), torch.sigmoid(f_), torch.tanh(g_), torch.sigmoid(o_)
     cn = f_ * d(c_prev) + i_ * g_
     hn = o_ * torch.tanh(cn)
-    if zone == 0:
+    if zone == 0 and inference:
+        ho, co = hn, cn
+    elif zone == 0:
         ho, co = hn * d(hmask) / 0.9, cn
     elif zone == 1:
         ho = torch.where(hmask.bool(), hn, d(h_prev)); co = torch.where(cmask.bool(), cn, d(c_prev))
@@ -80,7 +84,8 @@ def run_step(B, H, Ks, A, precision, zone=0, seed=0, with_pre=True, with_q=True,
     assert (h_out.double() - ho).abs().max().item() <= tol, ('h', (h_out.double() - ho).abs().max().item())
     assert (c_out.double() - co).abs().max().item() <= tol * max(1.0, co.abs().max().item())
     ref_gates = torch.stack((i_, f_, g_, o_), 1).reshape(B, 4 * H)
-    assert (gates.double() - ref_gates).abs().max().item() <= tol
+    if not inference:
+        assert (gates.double() - ref_gates).abs().max().item() <= tol
     if with_q:
         q = qpart.double().sum(0)
         ref_q = h_out.double() @ d(wq).t()
@@ -106,6 +111,17 @@ def test_lstm_step_shapes(Ks, H, A):
 @pytest.mark.parametrize('zone', [1, 2])
 def test_lstm_step_zoneout(zone):
     run_step(33, 256, [64, 256], 64, 0, zone=zone, seed=11)
+
+
+@pytest.mark.parametrize('B', [1, 2])
+@pytest.mark.parametrize('zone', [0, 2])
+def test_lstm_step_one_or_two_rows_at_inference(B, zone):
+    """lstm_gemv_kernel: the step of one / two rows without saved gates and training masks (single-utterance synthesis) - both decoder
+    LSTMs' operand shapes (three K segments: [prenet | context | h] and [h | context | h]), eval-mode dropout cell and eval-mode zoneout,
+    with and without the hoisted addend / the query partials."""
+    run_step(B, 1024, [256, 288, 1024], 128, 0, zone=zone, seed=40 + B, inference=True)
+    run_step(B, 1024, [1024, 544, 1024], 128, 0, zone=zone, seed=50 + B, inference=True, with_pre=False)
+    run_step(B, 256, [64, 256], 64, 0, zone=zone, seed=60 + B, inference=True, with_q=False)
 
 
 def test_lstm_step_without_addend_and_query():
