@@ -207,7 +207,11 @@ int mtts_pack_rows(const float* src, int ld, int rows, int K, float* dst, void* 
  * precision 0: fp32 operands, every product as six bf16 MFMA terms of exact 3-way splits (fp32-accurate);
  * precision 1: operands rounded to bf16 (weights stored as bf16 in the packed copy), fp32 accumulation and cell state;
  * precision 2 (batches above 64 rows only: the fused step kernel; the decoder uses it above 128 rows): fp32 operands, the weights stored as three pre-split bf16 planes
- *              (6 bytes per element), the same six-term products without a per-launch weight split. */
+ *              (6 bytes per element), the same six-term products without a per-launch weight split.
+ * Other forms behind the same entry (the launcher picks by shape): batches above 64 rows run the whole step as ONE launch (fused
+ * kernels, no partial slabs); one or two rows at inference (gates_out, hmask, cmask NULL, zone != 1, precision 0, nb_max != 4) run a
+ * GEMV-shaped launch on plain fp32 FMA (single-utterance synthesis, reference synthesize.py / Decoder.inference
+ * modules/tacotron2.py:229-242).  `partials` may stay unused; results agree within fp32 rounding, not bit for bit across forms. */
 typedef struct LstmPackArgs {
     const float* w[3];     /* up to 3 K-segments of the [4H, K_s] weight (row stride ldw[s]); K_s % 32 == 0 */
     int K[3];
