@@ -52,6 +52,29 @@ def scan(body):
     return n_loads, waits0, short, seq
 
 
+def stats(body):
+    """Instruction statistics of the straight-line listing: total, vector ALU, scalar ALU, MFMA, LDS, quarter-rate integer multiplies /
+    64-bit multiply-adds, IEEE divisions, SGPR-spill lane moves."""
+    ops = [l.split()[0] for l in body if l.startswith('\t') and l.split() and not l.split()[0].startswith(('.', ';'))]
+    return dict(instr=len(ops), valu=sum(o.startswith('v_') for o in ops), salu=sum(o.startswith('s_') for o in ops),
+                mfma=sum('mfma' in o for o in ops), lds=sum(o.startswith('ds_') for o in ops),
+                mul=sum(o.startswith(('v_mul_lo', 'v_mul_hi', 'v_mad_u64', 'v_mad_i64')) for o in ops), div=sum(o == 'v_div_scale_f32' for o in ops),
+                lane=sum(o in ('v_readlane_b32', 'v_writelane_b32') for o in ops))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == '--table':
+    # python scripts/asm_wait_scan.py --table a.s b.s ...: one line per kernel with instruction statistics + the wait summary
+    print(f'{"kernel":64s} {"instr":>6s} {"valu":>5s} {"salu":>5s} {"mfma":>5s} {"lds":>4s} {"mul64":>5s} {"div":>4s} {"lane":>5s} | {"loads":>5s} {"wait0":>5s} {"short":>5s} {"burst":>5s}')
+    for path in sys.argv[2:]:
+        for name, body in kernels(path):
+            if not any(l.split()[:1] == ['s_endpgm'] for l in body):
+                continue
+            st = stats(body)
+            n_loads, waits0, short, seq = scan(body)
+            print(f'{name[:64]:64s} {st["instr"]:6d} {st["valu"]:5d} {st["salu"]:5d} {st["mfma"]:5d} {st["lds"]:4d} {st["mul"]:5d} {st["div"]:4d} {st["lane"]:5d} | '
+                  f'{n_loads:5d} {waits0:5d} {short:5d} {seq[0][0] if seq else 0:5d}')
+    sys.exit(0)
+
 if __name__ == '__main__':
     path = sys.argv[1]
     pat = sys.argv[2] if len(sys.argv) > 2 else ''
