@@ -77,6 +77,7 @@ def train_step(model, crit, opt, buckets, batch, hp, teacher_forcing=1.0):
         buckets.all_reduce()
     if hasattr(opt, '_tables'):
         opt.step(max_norm=hp.gradient_clipping)          # fused clip_grad_norm_ + Adam (mtts_clip_adam_step)
+        opt.poll_skipped()                               # non-blocking: counts / warns about steps the device-side guard skipped
     else:
         torch.nn.utils.clip_grad_norm_(model.parameters(), hp.gradient_clipping)
         opt.step()

@@ -274,9 +274,12 @@ typedef struct AttnStepArgs {
     const float* qpart;    /* [kq][B][A] partial query projections (summed here) */
     int kq;
     long q_ks;
-    const float* PL;       /* [B,L,A] = M + bias + loc(cum_in) */
-    float* PL_next;        /* [B,L,A] for cum_out (nullable) */
-    const float* Mt;       /* [B,L,A] memory transform */
+    const float* PL;       /* [B,L,A] = M + bias + loc(cum_in).  TWO FORMS (pick with mtts_attn_step_form and do not mix them between the
+                              steps of one decode): form 0 (B < 128, or a shape the large-batch kernel does not take) READS PL and WRITES
+                              PL_next; form 1 (attn_step_big_kernel: B >= 128, nch 1 or 2) IGNORES PL, recomputes it
+                              in registers from Mt / bias / U / cum_in and does NOT write PL_next - Mt, U and bias are then required. */
+    float* PL_next;        /* [B,L,A] for cum_out (nullable; form 0 only) */
+    const float* Mt;       /* [B,L,A] memory transform (form 1: required) */
     const float* U;        /* [A,ksz] */
     const float* bias;     /* [A] */
     const float* v;        /* [A] energy weights */
@@ -297,6 +300,8 @@ typedef struct AttnStepArgs {
 } AttnStepArgs;
 
 int mtts_attn_step_fwd(const AttnStepArgs* args, void* stream);
+/* 1 when mtts_attn_step_fwd runs the large-batch kernel for this shape (PL unused, PL_next not written), else 0 */
+int mtts_attn_step_form(int B, int L, int A, int Dm, int ksz, int kq, int nch);
 
 /* ---- whole decoder loop, forward ----------------------------------------------------------------------------
  * Replaces Decoder._decode (modules/tacotron2.py:148-209) incl. _target_init (:126-133), the attention reset
@@ -710,6 +715,10 @@ int mtts_prof_end(float* total_ms, int* count);
 float mtts_prof_empty_ms(void);
 
 const char* mtts_last_error(void);
+/* ABI version.  101 (round 5) is NOT layout-compatible with 100: AdamArgs gained `guard`, LstmPackArgs lost `plain_rows`, AttnBwdArgs
+ * lost `hsum_out` / `hsum_cols`, DecoderGradArgs lost three fields, the mtts_ksplit_* exports are gone, LstmStepArgs.precision takes 2
+ * (pre-split planes), DecoderArgs gained the long-input fields of the persistent decoder.  Bindings that do not generate their structs
+ * from this header must check mtts_version() and mtts_sizeof_struct(). */
 int mtts_version(void);
 /* Bitmask of compile-time switches that make a build compute WRONG results on purpose (timing experiments).  The product sources
  * have none left (round 4); always 0 - bindings keep refusing anything else. */

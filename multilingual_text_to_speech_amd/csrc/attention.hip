@@ -620,6 +620,10 @@ int attn_step_launch(const AttnStepArgs& p, hipStream_t s) {
     return 0;
 }
 
+MTTS_API int mtts_attn_step_form(int B, int L, int A, int Dm, int ksz, int kq, int nch) {
+    return att_big_ok(B, L, A, Dm, ksz, kq, nch) ? 1 : 0;
+}
+
 MTTS_API int mtts_attn_step_fwd(const AttnStepArgs* args, void* stream) {
     return attn_step_launch(*args, (hipStream_t)stream);
 }

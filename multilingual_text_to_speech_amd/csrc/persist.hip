@@ -1042,9 +1042,12 @@ namespace {
 struct PsDevice {
     std::mutex mu;
     int cus = -1;                                   // multiProcessorCount, -1 = not queried yet
-    std::map<const void*, int> ready;               // kernel -> 1 ok / 0 does not fit (attribute set + occupancy checked)
+    std::map<std::pair<const void*, size_t>, int> ready;   // (kernel, dynamic LDS bytes) -> 1 ok / 0 does not fit (occupancy checked for THAT request)
+    std::map<const void*, size_t> lds_attr;         // kernel -> largest MaxDynamicSharedMemorySize set so far (the attribute is per function, not per launch)
+    std::mutex launch_mu;                           // held across serialize -> launch -> record of one persistent launch (two host threads, two streams)
     hipEvent_t last_ev = nullptr; hipStream_t last_stream = nullptr; bool have_last = false;
-    std::map<const void*, unsigned*> err_of;        // workspace -> error word its kernels report to
+    std::map<const void*, std::pair<unsigned*, unsigned long>> err_of;   // workspace -> (error word its kernels report to, sequence number of the last launch)
+    unsigned long err_seq = 0;
 };
 PsDevice g_ps_dev[64];
 PsDevice& ps_dev() { int d = 0; (void)hipGetDevice(&d); return g_ps_dev[d & 63]; }
@@ -1059,18 +1062,26 @@ bool ps_device_ok() {
     return D.cus >= PS_WGS;
 }
 
-// dynamic-LDS attribute + co-residency of PS_WGS workgroups of `fn` on the current device, cached per (device, kernel)
+// dynamic-LDS attribute + co-residency of PS_WGS workgroups of `fn` on the current device, cached per (device, kernel, LDS request):
+// one kernel instance serves several LDS sizes (pdec_lds depends on Dm and on the position tiles), so the attribute is raised whenever a
+// larger request than any before arrives and the occupancy verdict is kept per request.
 bool ps_kernel_ready(const void* fn, int threads, size_t lds) {
     PsDevice& D = ps_dev();
     std::lock_guard<std::mutex> lk(D.mu);
-    auto it = D.ready.find(fn);
+    const auto key = std::make_pair(fn, lds);
+    auto it = D.ready.find(key);
     if (it != D.ready.end()) return it->second != 0;
     int ok = 0, per_cu = 0;
-    if (D.cus >= PS_WGS && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) == hipSuccess && (long)per_cu * D.cus >= PS_WGS)
+    bool attr_ok = D.cus >= PS_WGS;
+    auto la = D.lds_attr.find(fn);
+    if (attr_ok && (la == D.lds_attr.end() || la->second < lds)) {
+        attr_ok = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+        if (attr_ok) D.lds_attr[fn] = lds;
+    }
+    if (attr_ok && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) == hipSuccess && (long)per_cu * D.cus >= PS_WGS)
         ok = 1;
     (void)hipGetLastError();
-    D.ready[fn] = ok;
+    D.ready[key] = ok;
     return ok != 0;
 }
 
@@ -1093,8 +1104,12 @@ unsigned* ps_err_word(const DecoderArgs& a) {
     unsigned* e = a.persist_err ? (unsigned*)a.persist_err : (unsigned*)((char*)a.persist_ws + PS_ERR_OFF);
     PsDevice& D = ps_dev();
     std::lock_guard<std::mutex> lk(D.mu);
-    if (D.err_of.size() > 64) D.err_of.clear();      // callers allocate a workspace per decode: remember the recent ones only
-    D.err_of[a.persist_ws] = e;
+    D.err_of[a.persist_ws] = std::make_pair(e, ++D.err_seq);
+    while (D.err_of.size() > 64) {                   // callers allocate a workspace per decode: forget the LEAST recently launched one only
+        auto oldest = D.err_of.begin();
+        for (auto i = D.err_of.begin(); i != D.err_of.end(); ++i) if (i->second.second < oldest->second.second) oldest = i;
+        D.err_of.erase(oldest);
+    }
     return e;
 }
 }  // namespace
@@ -1177,6 +1192,7 @@ int pgen_launch(const DecoderArgs& a, int t0, int t1, hipStream_t s) {
     p.sync.cnt = (unsigned*)ws; p.sync.err = ps_err_word(a);
     p.xp = (float*)(ws + ps_ws_gen_off());
     p.prof = g_ps_prof;
+    std::lock_guard<std::mutex> launch_lk(ps_dev().launch_mu);      // serialize -> launch -> record is one critical section
     MTTS_TRY(ps_serialize(s));
     MTTS_CHECK_HIP(hipMemsetAsync(ws, 0, PS_ERR_OFF, s));           // counters (the error word is sticky until the host reads it)
     const PsInst k = pgen_instance(a.B, a.H, a.precision);
@@ -1228,6 +1244,7 @@ int pdec_launch(const DecoderArgs& a, int t0, int t1, hipStream_t s) {
     p.sync.cnt = (unsigned*)ws; p.sync.err = ps_err_word(a);
     p.xp = (float*)(ws + ps_ws_att_off(a.H));
     p.eg = (unsigned long long*)(ws + ps_ws_eg_off(a.H, a.Dm));
+    std::lock_guard<std::mutex> launch_lk(ps_dev().launch_mu);
     MTTS_TRY(ps_serialize(s));
     MTTS_CHECK_HIP(hipMemsetAsync(ws, 0, PS_ERR_OFF, s));
     MTTS_CHECK_HIP(hipMemsetAsync(p.eg, 0, (size_t)64 * 4 * PD_LMAX * 8, s));
@@ -1259,7 +1276,7 @@ MTTS_API int mtts_decoder_persist_status(const void* persist_ws, void* stream) {
         PsDevice& D = ps_dev();
         std::lock_guard<std::mutex> lk(D.mu);
         auto it = D.err_of.find(persist_ws);
-        if (it != D.err_of.end()) src = it->second;
+        if (it != D.err_of.end()) src = it->second.first;
     }
     unsigned v = 0;
     if (hipMemcpyAsync(&v, src, 4, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return -1;

@@ -83,13 +83,46 @@ class FusedAdam(torch.optim.Adam):
 
     One table spans every parameter that has a gradient (global norm / clip coefficient); the update runs once per
     (parameter group, bias-correction step) so per-group learning rates and parameters that skipped earlier steps keep
-    torch's semantics."""
+    torch's semantics.
+
+    Skip semantics (differs from the reference, on purpose): when the gradient norm is not finite, or this GPU's device error word is
+    set, the update is skipped ON THE DEVICE (clip coefficient -1 in `norm[1]`, mtts.h AdamArgs.guard) - the weights and moments stay
+    untouched while `state['step']` and any LR schedule advance.  The reference's clip_grad_norm_ + Adam would write NaNs into every
+    weight instead.  `poll_skipped()` surfaces it without stalling the stream: `skipped_steps` counts them and a warning names the
+    first one; a data-parallel rank that skips while others update is caught by the device-error poll of the same step."""
 
     CHUNK = 1 << 16
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self._tables = {}
+        self.skipped_steps = 0
+        self._skip_poll = None
+
+    def poll_skipped(self):
+        """Non-blocking: enqueue a copy of [grad_norm, clip_coefficient] of the step just issued into pinned memory and account for
+        what the PREVIOUS poll fetched (one step late, like kernels.poll_device_errors).  Returns the number of skipped steps so far."""
+        norm = self._tables.get('norm')
+        if norm is None:
+            return self.skipped_steps
+        st = self._skip_poll
+        if st is None:
+            st = self._skip_poll = dict(host=torch.zeros(2, dtype=torch.float32).pin_memory(), event=None)
+        if st['event'] is not None:
+            if not st['event'].query():
+                return self.skipped_steps
+            st['event'] = None
+            if float(st['host'][1]) < 0:
+                self.skipped_steps += 1
+                if self.skipped_steps == 1 or self.skipped_steps % 100 == 0:
+                    import warnings
+                    warnings.warn(f'FusedAdam: {self.skipped_steps} optimizer step(s) skipped on the device (gradient norm '
+                                  f'{float(st["host"][0])} not finite, or a device error word was set); weights unchanged')
+        with torch.cuda.device(norm.device):
+            st['host'].copy_(norm, non_blocking=True)
+            st['event'] = torch.cuda.Event()
+            st['event'].record()
+        return self.skipped_steps
 
     def load_state_dict(self, state_dict):
         """torch.optim.Adam's state_dict, including one saved by the REFERENCE's two-group optimizer (train.py:261-270): its first

@@ -40,7 +40,7 @@ BF16_SITES = frozenset()
 
 
 def _r(x, site):
-    return x.to(torch.bfloat16).to(torch.float32) if site in BF16_SITES else x
+    return x.to(torch.bfloat16).to(x.dtype) if site in BF16_SITES else x
 
 
 # Backward of the bf16-operand mode.  The product's BATCHED backward GEMMs round their operands as well (dY, and the W / X they multiply it
@@ -53,7 +53,7 @@ BF16_BWD_WGRAD_ONLY = frozenset()
 
 
 def _rb(x):
-    return x.to(torch.bfloat16).to(torch.float32)
+    return x.to(torch.bfloat16).to(x.dtype)          # dtype-generic: the fp64 run of tests/test_gpu_more.py rounds the same operands
 
 
 class _RoundedLinear(torch.autograd.Function):
@@ -285,7 +285,7 @@ def grouped_encoder(sd, prefix, cfg, x, x_langs, masks, training, generated, sta
     x = x.reshape(bs, cout, -1).transpose(1, 2)
     if single:
         # reference modules/encoder.py:213-219 (normaliser uses only the first batch element's row sums)
-        xr = torch.zeros(1, x.shape[1], x.shape[2])
+        xr = x.new_zeros(1, x.shape[1], x.shape[2])
         norm = x_langs / x_langs.sum(2, keepdim=True)[0]
         for l in range(G):
             xr[0] = xr[0] + norm[0, :, l].reshape(-1, 1) * x[l]
@@ -477,7 +477,7 @@ def tacotron_forward(sd, cfg, text, text_length, target, target_length, speakers
     post = postnet(sd, cfg, pre, masks, training, stats)
     tmask = lengths_to_mask(target_length, target.size(2))
     stop = stop.masked_fill(~tmask, 1000)
-    tm = tmask.unsqueeze(1).float()
+    tm = tmask.unsqueeze(1).to(pre.dtype)
     return dict(post=post * tm, pre=pre * tm, stop=stop, alignment=align, speaker_prediction=spk_pred,
                 encoder_output=encoded, bn_stats=stats)
 
@@ -490,11 +490,11 @@ def guided_attention(alignments, input_lengths, target_lengths, g):
     """TacotronLoss._guided_attention, reference modules/tacotron2.py:443-457."""
     weights = torch.zeros_like(alignments)
     for i, (f, l) in enumerate(zip(target_lengths.tolist(), input_lengths.tolist())):
-        gf = torch.arange(f, dtype=torch.float)[:, None]
-        gl = torch.arange(l, dtype=torch.float)[None, :]
+        gf = torch.arange(f, dtype=alignments.dtype)[:, None]
+        gl = torch.arange(l, dtype=alignments.dtype)[None, :]
         weights[i, :f, :l] = 1 - torch.exp(-(gl / l - gf / f) ** 2 / (2 * g ** 2))
     loss = torch.sum(weights * alignments, dim=(1, 2))
-    return torch.mean(loss / target_lengths.float())
+    return torch.mean(loss / target_lengths.to(loss.dtype))
 
 
 def tacotron_loss(cfg, out, source_length, target_length, mel_target, stop_target, speakers, g, g_steps=1):
@@ -504,7 +504,7 @@ def tacotron_loss(cfg, out, source_length, target_length, mel_target, stop_targe
         'mel_pre': 2 * F.mse_loss(out['pre'], mel_target),
         'mel_pos': F.mse_loss(out['post'], mel_target),
         'stop_token': F.binary_cross_entropy_with_logits(out['stop'], stop_target,
-                                                         pos_weight=torch.tensor([100.0])) / (M + 2),
+                                                         pos_weight=torch.tensor([100.0], dtype=out['stop'].dtype)) / (M + 2),
     }
     if cfg['reversal_classifier']:
         ml = int(torch.max(source_length))

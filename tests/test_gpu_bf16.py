@@ -112,4 +112,6 @@ def test_bf16_gradients_match_the_oracle_with_bf16_rounded_operands(preset, B, L
     (relative L2 per tensor <= tests.test_gpu_more.BF16_GRAD_TOL) - replaces the cosine >= 0.98 bound against the fp32 fixtures,
     which a wrong-but-plausible backward kernel passes."""
     from tests.test_gpu_more import run_train_step_case
-    run_train_step_case(preset, B, L, T, {}, bf16=True)
+    # generated encoder: the per-tensor bound is an order looser (1.5e-1, 14 batch-normed generated blocks); the fp64 run of the
+    # same-rounding oracle shows that spread between two CORRECT evaluations and bounds the product by it (run_train_step_case)
+    run_train_step_case(preset, B, L, T, {}, bf16=True, fp64_spread=preset == 'generated_switching')

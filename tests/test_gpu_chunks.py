@@ -79,10 +79,20 @@ def test_large_batch_step_kernels_forward_match_oracle(preset, B, L, T, over):
     run_train_step_case(preset, B, L, T, over, check_grads=False)
 
 
-def test_benchmark_shape_forward_matches_oracle():
+def test_benchmark_shape_train_step_matches_oracle_with_every_gradient():
     """The benchmark's own shape - shared_training, batch 64, 120 characters -> 600 frames (13 chunks), train mode with all
-    dropout draws injected - forward only: mel outputs and alignments against the CPU oracle."""
-    run_train_step_case('shared_training', 64, 120, 600, {}, check_grads=False)
+    dropout draws injected: mel outputs, alignments, loss AND the gradient of every parameter against the CPU oracle's autograd
+    (reference modules/tacotron2.py:180-198 and its backward).  Pins together what the smaller cases pin apart: the 64-row
+    attention-backward + h-column launch at L = 120 (512 workgroups), 13 chunks of beta = 1 weight-gradient accumulation on the third
+    stream, 600 steps of back-propagation through time on the six-term products, the persistent forward's saved state."""
+    run_train_step_case('shared_training', 64, 120, 600, {})
+
+
+def test_roofline_b240_shape_train_step_gradients_match_oracle():
+    """generated_switching at batch 240 x 120 characters (the `roofline_b240` shape; 48 per language group, 15 row tiles), 6 frames:
+    the large-batch forward schedule (lstm_fused_kernel, attn_step_big_kernel) feeding the backward's multi-tile paths - every
+    parameter gradient against the oracle's autograd."""
+    run_train_step_case('generated_switching', 240, 120, 6, {})
 
 
 @pytest.mark.parametrize('chunk', ['2', '5'])
