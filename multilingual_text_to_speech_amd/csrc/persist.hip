@@ -693,11 +693,19 @@ struct PsDec {
 };
 
 constexpr unsigned PS_SENTINEL = 0xffffffffu;      // a NaN pattern no arithmetic produces
-constexpr int PD_LMAX = 128;         // encoder positions (8 waves x 16 rows)
-constexpr int PD_NCM = 9;            // memory float4 per thread in the context phase
+constexpr int PD_LMAX = 128;         // encoder positions of one position tile (8 waves x 16 rows)
+constexpr int PD_LT_MAX = 3;         // position tiles a sample workgroup can take: inputs of up to 384 characters (reference data: max 304)
+constexpr int PD_NCM = 9;            // memory float4 per thread and position tile in the context phase
 
-template <int RT, int PREC>
+// LT = position tiles of 128 encoder positions.  LT == 1 (L <= 128) is the fast instantiation: the sample's Mt slice sits in LDS and
+// the h-part fragments of the next gates are requested inside the attention step.  LT > 1 (round 5: the reference attends over any L,
+// modules/attention.py:39-45; real CSS10 batches exceed 128 characters): LDS has no room for LT x 16 KiB of Mt beside the weight slice,
+// so every lane re-requests the 8 x LT Mt values it needs (L2-resident: 40 KiB per workgroup at L = 320) together with the query
+// weights, the energies / softmax / context stages loop over the tiles, the memory rows of the context are LT x 9 float4 per thread,
+// and the early h-part requests are off (their registers hold the memory rows).
+template <int RT, int PREC, int LT = 1>
 __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void pdec_kernel(PsDec p) {
+    constexpr int LM = PD_LMAX * LT;      // positions the LDS / granule rows are sized for
     extern __shared__ __attribute__((aligned(16))) char psm[];
     const int tid = threadIdx.x, lane = tid & 63, c = blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -706,17 +714,17 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     // ---- LDS carve
     float4* wl = reinterpret_cast<float4*>(psm);                                       // [nkb][2][64] float4
     float* red = reinterpret_cast<float*>(psm + (size_t)nkb * (PREC ? 1024 : 2048));      // [8][64][16] (phase 1) / scratch (phase 2)
-    float* Mt_s = red + 8 * 64 * 16;                                                    // [PD_LMAX][32]
-    float* cumw = Mt_s + PD_LMAX * 32;                                                  // [PD_LMAX + 64] cumulative alignment with zero halo
-    uint4* Upl = reinterpret_cast<uint4*>(cumw + PD_LMAX + 64);                         // [2 col tiles][3 planes][64 lanes]
+    float* Mt_s = red + 8 * 64 * 16;                                                    // [PD_LMAX][32] (LT == 1 only)
+    float* cumw = Mt_s + (LT == 1 ? PD_LMAX * 32 : 0);                                  // [LM + 64] cumulative alignment with zero halo
+    uint4* Upl = reinterpret_cast<uint4*>(cumw + LM + 64);                              // [2 col tiles][3 planes][64 lanes]
     float* vb = reinterpret_cast<float*>(Upl + 2 * 3 * 64);                             // v[32], bias[32]
     volatile unsigned* eflag = reinterpret_cast<volatile unsigned*>(vb + 64);           // [4] workgroup-uniform decision of thread 0 (early h-part loads)
     // phase-2 scratch inside `red`
     float* hs = red;                                   // [H] query operand: the sample's h row
     float* qs = hs + 1024;                             // [32]
-    float* es = qs + 32;                               // [4][PD_LMAX] partial energies of the four slices
-    float* wsm = es + 4 * PD_LMAX;                     // [PD_LMAX] alignment weights
-    float* ctxp = wsm + PD_LMAX;                       // [ng][Dq] context partial sums
+    float* es = qs + 32;                               // [4][LM] partial energies of the four slices
+    float* wsm = es + 4 * LM;                          // [LM] alignment weights
+    float* ctxp = wsm + LM;                            // [ng][Dq] context partial sums
 #ifdef PS_PROF
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(vb + 68);
 #endif
@@ -739,8 +747,8 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const int per = PREC ? 64 : 128;                                // 16-byte quanta per k-block (bf16-packed / fp32-packed weights)
         const float4* src = reinterpret_cast<const float4*>(p.w_packed) + (size_t)c * nkb * per;
         for (int i = tid; i < nkb * per; i += PS_THREADS) wl[i] = src[i];
-        for (int i = tid; i < L * 32; i += PS_THREADS) { const int l = i >> 5, a = i & 31; Mt_s[i] = p.Mt[((size_t)sbc * L + l) * A + 32 * sj + a]; }
-        for (int i = tid; i < PD_LMAX + 64; i += PS_THREADS) {
+        if (LT == 1) for (int i = tid; i < L * 32; i += PS_THREADS) { const int l = i >> 5, a = i & 31; Mt_s[i] = p.Mt[((size_t)sbc * L + l) * A + 32 * sj + a]; }
+        for (int i = tid; i < LM + 64; i += PS_THREADS) {
             const int l = i - pad;
             cumw[i] = (has_sample && l >= 0 && l < L) ? p.cum[((size_t)p.t0 * B + sb) * L + l] : 0.f;
         }
@@ -817,7 +825,9 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         }
         PD_STAMP(2);
         ps_bar_arrive(p.sync, ++epoch);
-        float4 wq4[16]; float4 mem4[PD_NCM];
+        constexpr int NMEM = PD_NCM * (LT < 2 ? LT : 2);      // memory rows per thread requested ahead; LT == 3: the third tile's rows are requested inside the context stage
+        float4 wq4[16]; float4 mem4[NMEM];
+        float mtr[LT > 1 ? LT : 1][2][4];      // LT > 1: the lane's Mt values of the energy stage (position tile, channel tile, row)
         // operands of phase 2 that do not depend on h_{t+1}.  Query weights: requested behind the arrive, landing while the barrier
         // completes (streamed from L2 every step: neither LDS nor the register file has 128 KiB to spare beside phase 1):
         // lane (a = tid >> 4, l16 = tid & 15) takes k = 64 i + 4 l16 .. + 4, i.e. 256 contiguous bytes per channel and load
@@ -825,16 +835,42 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             const float* wq = p.w_query + (size_t)(32 * sj + (tid >> 4)) * H + 4 * (tid & 15);
 #pragma unroll
             for (int i = 0; i < 16; ++i) wq4[i] = *reinterpret_cast<const float4*>(wq + 64 * i);
+            if (LT > 1) {
+                // one descriptor over the sample's [L][A] slice, ONE per-lane offset, the position tile in the scalar offset, (row, channel
+                // tile) as immediates: 8 LT requests without 8 LT loop-invariant 64-bit addresses held in registers across the step loop.
+                // Positions >= L are beyond num_records and read as zero without touching memory (their energies are never used).
+                const __amdgpu_buffer_rsrc_t mt_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Mt + (size_t)sbc * L * A), 0, L * A * 4, 0x00020000);
+                const unsigned mt_v = (unsigned)(((4 * (lane >> 4)) * A + 32 * sj + (lane & 15)) * 4);
+#pragma unroll
+                for (int it = 0; it < LT; ++it) {
+                    const unsigned mt_s = (unsigned)(16 * (wave + 8 * it) * A * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int ct = 0; ct < 2; ++ct)
+                            mtr[it][ct][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(mt_r, mt_v + (unsigned)((r * A + 16 * ct) * 4), mt_s, 0));
+                }
+            }
         }
         // memory columns of the context: requested after the query (they are needed three stages later; keeping them out of the query's
         // register budget leaves room for the early h-part fragments)
         auto pd_prefetch_mem = [&]() {
             const int c4 = tid % nc4, lg = tid / nc4;
-            const float* mem = p.memory + (size_t)sbc * L * Dm + d0 + 4 * c4;
+            if (LT == 1) {
+                const float* mem = p.memory + (size_t)sbc * L * Dm + d0 + 4 * c4;
 #pragma unroll
-            for (int i = 0; i < PD_NCM; ++i) {
-                const int l = min(lg + i * ng, L - 1);
-                mem4[i] = *reinterpret_cast<const float4*>(mem + (size_t)l * Dm);
+                for (int i = 0; i < NMEM; ++i) {
+                    const int l = min(lg + i * ng, L - 1);
+                    mem4[i] = *reinterpret_cast<const float4*>(mem + (size_t)l * Dm);
+                }
+            } else {      // descriptor over the sample's [L][Dm] rows: one per-lane offset, the row group in the scalar offset; rows >= L read as zero
+                const __amdgpu_buffer_rsrc_t mem_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.memory + (size_t)sbc * L * Dm), 0, L * Dm * 4, 0x00020000);
+                const unsigned mem_v = (unsigned)((lg * Dm + d0 + 4 * c4) * 4), mem_step = (unsigned)(ng * Dm * 4);
+#pragma unroll
+                for (int i = 0; i < NMEM; ++i) {
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(mem_r, mem_v, (unsigned)i * mem_step, 0);
+                    mem4[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+                }
             }
         };
         if (cellthr) {
@@ -889,12 +925,14 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                     if (p.q_all) p.q_all[((size_t)t * B + sb) * A + 32 * sj + (tid >> 4)] = acc;
                 }
             }
+            if (LT > 1) __builtin_amdgcn_sched_barrier(0);      // keep the memory rows' registers behind the query weights' (no hoisting above the query)
             pd_prefetch_mem();
             __syncthreads();
             PD_STAMP(4);
             // ---- location features (MFMA, exact split) + partial energies: wave w <-> positions [16 w, 16 w + 16)
-            {
-                const int i16 = lane & 15, q4 = lane >> 4, l0 = 16 * wave;
+#pragma unroll
+            for (int it = 0; it < LT; ++it) {
+                const int i16 = lane & 15, q4 = lane >> 4, l0 = 16 * (wave + 8 * it);
                 float f[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] = cumw[l0 + i16 + 8 * q4 + e];
@@ -914,7 +952,7 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int l = min(l0 + 4 * q4 + r, PD_LMAX - 1);
-                        e4[r] += va * tanhf_(qa + Mt_s[l * 32 + a] + loc[r]);
+                        e4[r] += va * tanhf_(qa + (LT == 1 ? Mt_s[l * 32 + a] : mtr[it][ct][r]) + loc[r]);
                     }
                 }
 #pragma unroll
@@ -922,17 +960,18 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                     const float e = row16_sum(e4[r]);
                     const int l = l0 + 4 * q4 + r;
                     if (i16 == 0 && l < L) {
-                        es[sj * PD_LMAX + l] = e;
-                        __hip_atomic_store(p.eg + ((size_t)(sb * 4 + sj)) * PD_LMAX + l, ((unsigned long long)epoch << 32) | __float_as_uint(e), PS_RLX, PS_AGENT);
+                        es[sj * LM + l] = e;
+                        __hip_atomic_store(p.eg + ((size_t)(sb * 4 + sj)) * LM + l, ((unsigned long long)epoch << 32) | __float_as_uint(e), PS_RLX, PS_AGENT);
                     }
                 }
+                if (LT > 1) __builtin_amdgcn_sched_barrier(0);      // one position tile at a time (register budget)
             }
             PD_STAMP(5);
             // ---- the other three slices' partial energies (tagged granules: the data is the flag)
-            if (tid < 3 * PD_LMAX) {
-                const int o = tid / PD_LMAX, l = tid - o * PD_LMAX, j2 = o + (o >= sj ? 1 : 0);
+            for (int idx = tid; idx < 3 * LM; idx += PS_THREADS) {
+                const int o = idx / LM, l = idx - o * LM, j2 = o + (o >= sj ? 1 : 0);
                 if (l < L) {
-                    unsigned long long* gp = p.eg + ((size_t)(sb * 4 + j2)) * PD_LMAX + l;
+                    unsigned long long* gp = p.eg + ((size_t)(sb * 4 + j2)) * LM + l;
                     unsigned long long x = __hip_atomic_load(gp, PS_RLX, PS_AGENT);
                     unsigned spins = 0;
                     while ((unsigned)(x >> 32) != epoch) {
@@ -940,37 +979,37 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                         x = __hip_atomic_load(gp, PS_RLX, PS_AGENT);
                         if (++spins > PS_SPIN_MAX) { __hip_atomic_store(p.sync.err, 2u, PS_RLX, PS_AGENT); break; }
                     }
-                    es[j2 * PD_LMAX + l] = __uint_as_float((unsigned)x);
+                    es[j2 * LM + l] = __uint_as_float((unsigned)x);
                 }
             }
             // Early h-part loads: by now the grid barrier of the h hand-off has normally completed (it trails the polled row by about
             // one energy stage); thread 0 looks ONCE, without waiting.  If it has, every wave requests its first three h-part k-blocks
             // of the next step's gates here - they travel while the softmax and the context run - and the barrier's wait is skipped.
-            if (tid == 0) eflag[0] = (p.early_h && t + 1 < p.t1 && (!p.poll_h || __hip_atomic_load(p.sync.cnt, PS_RLX, PS_AGENT) >= epoch * 8u)) ? 1u : 0u;
+            if (tid == 0) eflag[0] = (LT == 1 && p.early_h && t + 1 < p.t1 && (!p.poll_h || __hip_atomic_load(p.sync.cnt, PS_RLX, PS_AGENT) >= epoch * 8u)) ? 1u : 0u;
             __syncthreads();
             PD_STAMP(6);
-            early = eflag[0] != 0u;
-            if (early) gates_h_prefetch(t + 1);
+            early = LT == 1 && eflag[0] != 0u;
+            if (LT == 1) { if (early) gates_h_prefetch(t + 1); }
             // ---- masked softmax over the positions, cumulative alignment.  EVERY wave computes it (the others would idle at the barrier
             //      below), wave 0 stores: with the DPP reductions of common.h inside an `if (wave == 0)` region this compiler rejects the
             //      kernel ("Illegal instruction detected: Operand has incorrect register class", ROCm 7.2), and the shuffle butterflies
             //      they replace were ~1.4 k of this stage's 3.3 k cycles
             {
-                float e0[2], mx = -INFINITY;
+                float e0[2 * LT], mx = -INFINITY;
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
+                for (int k = 0; k < 2 * LT; ++k) {
                     const int l = lane + 64 * k;
-                    e0[k] = (l < L) ? ((es[l] + es[PD_LMAX + l]) + (es[2 * PD_LMAX + l] + es[3 * PD_LMAX + l])) : 0.f;
+                    e0[k] = (l < L) ? ((es[l] + es[LM + l]) + (es[2 * LM + l] + es[3 * LM + l])) : 0.f;
                     if (l < len) mx = fmaxf(mx, e0[k]);
                 }
                 mx = wave_max(mx);
                 float sum = 0.f;
 #pragma unroll
-                for (int k = 0; k < 2; ++k) { const int l = lane + 64 * k; e0[k] = (l < len) ? __expf(e0[k] - mx) : 0.f; sum += e0[k]; }
+                for (int k = 0; k < 2 * LT; ++k) { const int l = lane + 64 * k; e0[k] = (l < len) ? __expf(e0[k] - mx) : 0.f; sum += e0[k]; }
                 sum = wave_sum(sum);
                 const float inv = 1.f / sum;
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
+                for (int k = 0; k < 2 * LT; ++k) {
                     const int l = lane + 64 * k;
                     if (l < L && wave == 0) {
                         const float wl_ = e0[k] * inv, cn = cumw[pad + l] + wl_;
@@ -985,10 +1024,27 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 const int c4 = tid % nc4, lg = tid / nc4;
                 float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int i = 0; i < PD_NCM; ++i) {
+                for (int i = 0; i < NMEM; ++i) {
                     const int l = lg + i * ng;
                     const float wl_ = (lg < ng && l < L) ? wsm[l] : 0.f;
                     s4.x += wl_ * mem4[i].x; s4.y += wl_ * mem4[i].y; s4.z += wl_ * mem4[i].z; s4.w += wl_ * mem4[i].w;
+                }
+                if (LT > 2) {      // rows of the third position tile (inputs above 256 characters): one more round trip, in index order
+                    __builtin_amdgcn_sched_barrier(0);      // the requests below reuse the registers of the rows consumed above
+                    const __amdgpu_buffer_rsrc_t mem_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.memory + (size_t)sbc * L * Dm), 0, L * Dm * 4, 0x00020000);
+                    const unsigned mem_v = (unsigned)((lg * Dm + d0 + 4 * c4) * 4), mem_step = (unsigned)(ng * Dm * 4);
+                    float4 m3[PD_NCM];
+#pragma unroll
+                    for (int i = 0; i < PD_NCM; ++i) {
+                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(mem_r, mem_v, (unsigned)(NMEM + i) * mem_step, 0);
+                        m3[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+                    }
+#pragma unroll
+                    for (int i = 0; i < PD_NCM; ++i) {
+                        const int l = lg + (NMEM + i) * ng;
+                        const float wl_ = (lg < ng && l < L) ? wsm[l] : 0.f;
+                        s4.x += wl_ * m3[i].x; s4.y += wl_ * m3[i].y; s4.z += wl_ * m3[i].z; s4.w += wl_ * m3[i].w;
+                    }
                 }
                 if (lg < ng) *reinterpret_cast<float4*>(ctxp + (lg * nc4 + c4) * 4) = s4;
             }
@@ -997,7 +1053,7 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             // stores queued behind the early h-part loads
             if (sj == 0 && wave == PS_THREADS / 64 - 1) {
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
+                for (int k = 0; k < 2 * LT; ++k) {
                     const int l = lane + 64 * k;
                     if (l < L) { p.align[((size_t)t * B + sb) * L + l] = wsm[l]; p.cum[((size_t)(t + 1) * B + sb) * L + l] = cumw[pad + l]; }
                 }
@@ -1128,7 +1184,7 @@ static long ps_ws_eg_off(int H, int Dm) { return ps_ws_att_off(H) + 2L * 64 * (D
 // bytes of the exchange / synchronisation workspace a decoder call hands to the persistent kernels (DecoderArgs.persist_ws)
 MTTS_API long mtts_decoder_persist_ws_bytes(int B, int L, int H, int Dm, int A) {
     (void)B; (void)A; (void)L;
-    return ps_ws_eg_off(H, Dm) + 64L * 4 * PD_LMAX * 8 + 1024;
+    return ps_ws_eg_off(H, Dm) + 64L * 4 * (PD_LMAX * PD_LT_MAX) * 8 + 1024;
 }
 
 unsigned long long* g_ps_prof = nullptr;      // timeline buffer of the micro-benchmark harness (NULL in the library)
@@ -1150,19 +1206,24 @@ PsInst pgen_instance(int B, int H, int precision) {
     }
     return k;
 }
-size_t pdec_lds(int H, int Dm, int precision) {
-    size_t lds = (size_t)((Dm + H) / 32) * (precision ? 1024 : 2048) + 8 * 64 * 16 * 4 + PD_LMAX * 32 * 4 + (PD_LMAX + 64) * 4 + 2 * 3 * 64 * 16 + 64 * 4 + 16;
+size_t pdec_lds(int H, int Dm, int precision, int LT) {
+    size_t lds = (size_t)((Dm + H) / 32) * (precision ? 1024 : 2048) + 8 * 64 * 16 * 4 + (LT == 1 ? PD_LMAX * 32 * 4 : 0) + (PD_LMAX * LT + 64) * 4 + 2 * 3 * 64 * 16 + 64 * 4 + 16;
 #ifdef PS_PROF
     lds += 300 * 8;
 #endif
     return lds;
 }
-PsInst pdec_instance(int B, int H, int Dm, int precision) {
-    const int RT = (B + 15) / 16;
-    PsInst k{nullptr, PS_THREADS, pdec_lds(H, Dm, precision)};
-    if (precision) k.fn = RT == 1 ? (const void*)pdec_kernel<1, 1> : RT == 2 ? (const void*)pdec_kernel<2, 1> : RT == 3 ? (const void*)pdec_kernel<3, 1> : (const void*)pdec_kernel<4, 1>;
-    else k.fn = RT == 1 ? (const void*)pdec_kernel<1, 0> : RT == 2 ? (const void*)pdec_kernel<2, 0> : RT == 3 ? (const void*)pdec_kernel<3, 0> : (const void*)pdec_kernel<4, 0>;
-    return k;
+typedef void (*PdecFn)(PsDec);
+// kernel instance by (row tiles, precision, position tiles)
+PdecFn pdec_fn(int RT, int precision, int LT) {
+#define PDEC_ROW(PR, LTT) { pdec_kernel<1, PR, LTT>, pdec_kernel<2, PR, LTT>, pdec_kernel<3, PR, LTT>, pdec_kernel<4, PR, LTT> }
+    static const PdecFn table[2][PD_LT_MAX][4] = {{PDEC_ROW(0, 1), PDEC_ROW(0, 2), PDEC_ROW(0, 3)}, {PDEC_ROW(1, 1), PDEC_ROW(1, 2), PDEC_ROW(1, 3)}};
+#undef PDEC_ROW
+    return table[precision ? 1 : 0][LT - 1][RT - 1];
+}
+PsInst pdec_instance(int B, int L, int H, int Dm, int precision) {
+    const int RT = (B + 15) / 16, LT = (L + PD_LMAX - 1) / PD_LMAX;
+    return PsInst{(const void*)pdec_fn(RT, precision, LT), PS_THREADS, pdec_lds(H, Dm, precision, LT)};
 }
 }  // namespace
 
@@ -1212,15 +1273,18 @@ int pgen_launch(const DecoderArgs& a, int t0, int t1, hipStream_t s) {
 }
 
 bool pdec_supported(const DecoderArgs& a) {
-    if (!(persist_enabled() && a.fast && (a.precision == 0 || a.precision == 1) && a.H == 4 * PS_WGS && a.A == 128 && a.B >= 1 && a.B <= 64 && a.L >= 1 && a.L <= PD_LMAX &&
+    if (!(persist_enabled() && a.fast && (a.precision == 0 || a.precision == 1) && a.H == 4 * PS_WGS && a.A == 128 && a.B >= 1 && a.B <= 64 && a.L >= 1 && a.L <= PD_LMAX * PD_LT_MAX &&
           a.persist_ws && a.att_w2p && a.att_bias_u && a.att_w_pre_u && a.pre_att && (a.Dm & 31) == 0 && a.Dm / 32 <= 24 &&
           (a.ksz & 1) == 1 && a.ksz <= 32 && a.persist_ws_bytes >= mtts_decoder_persist_ws_bytes(a.B, a.L, a.H, a.Dm, a.A)))
         return false;
     static const bool off = [] { const char* e = getenv("MTTS_PDEC"); return e && e[0] == '0'; }();
     if (off) return false;
     const int nc4 = a.Dm / 16, ng = PS_THREADS / nc4;
-    if (!(nc4 >= 1 && ng >= 1 && (a.L + ng - 1) / ng <= PD_NCM)) return false;
-    const PsInst k = pdec_instance(a.B, a.H, a.Dm, a.precision);
+    const int LT = (a.L + PD_LMAX - 1) / PD_LMAX;
+    static const int lt_max = [] { const char* e = getenv("MTTS_PDEC_LT"); return e ? atoi(e) : PD_LT_MAX; }();      // MTTS_PDEC_LT=1: long inputs take the per-step schedule (A/B)
+    if (LT > lt_max) return false;
+    if (!(nc4 >= 1 && ng >= 1 && (a.L + ng - 1) / ng <= PD_NCM * LT)) return false;
+    const PsInst k = pdec_instance(a.B, a.L, a.H, a.Dm, a.precision);
     return ps_kernel_ready(k.fn, k.threads, k.lds);
 }
 
@@ -1247,22 +1311,20 @@ int pdec_launch(const DecoderArgs& a, int t0, int t1, hipStream_t s) {
     std::lock_guard<std::mutex> launch_lk(ps_dev().launch_mu);
     MTTS_TRY(ps_serialize(s));
     MTTS_CHECK_HIP(hipMemsetAsync(ws, 0, PS_ERR_OFF, s));
-    MTTS_CHECK_HIP(hipMemsetAsync(p.eg, 0, (size_t)64 * 4 * PD_LMAX * 8, s));
+    const int LT = (a.L + PD_LMAX - 1) / PD_LMAX;
+    MTTS_CHECK_HIP(hipMemsetAsync(p.eg, 0, (size_t)64 * 4 * (PD_LMAX * LT) * 8, s));
     static const bool poll_on = [] { const char* e = getenv("MTTS_PDEC_POLL"); return !(e && e[0] == '0'); }();
     p.poll_h = (poll_on && !g_pdec_poll_off) ? 1 : 0;
     static const bool early_on = [] { const char* e = getenv("MTTS_PDEC_EARLY"); return !(e && e[0] == '0'); }();
     p.early_h = (early_on && !g_pdec_early_off) ? 1 : 0;
     if (p.poll_h)       // h rows of the steps this launch produces: sentinel until their owner's store lands
         MTTS_CHECK_HIP(hipMemsetAsync(a.h_att + (size_t)(t0 + 1) * a.B * a.H, 0xff, (size_t)(t1 - t0) * a.B * a.H * sizeof(float), s));
-    const size_t lds = pdec_lds(a.H, a.Dm, a.precision);
+    const size_t lds = pdec_lds(a.H, a.Dm, a.precision, LT);
 #ifdef PS_PROF
     MTTS_CHECK_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_ps_prof_dev), &g_ps_prof, sizeof(g_ps_prof), 0, hipMemcpyHostToDevice, s));
 #endif
     const int RT = (a.B + 15) / 16;
-#define PDEC_GO(R, PR) hipLaunchKernelGGL((pdec_kernel<R, PR>), dim3(PS_WGS), dim3(PS_THREADS), lds, s, p);
-    if (a.precision) { if (RT == 1) PDEC_GO(1, 1) else if (RT == 2) PDEC_GO(2, 1) else if (RT == 3) PDEC_GO(3, 1) else PDEC_GO(4, 1) }
-    else { if (RT == 1) PDEC_GO(1, 0) else if (RT == 2) PDEC_GO(2, 0) else if (RT == 3) PDEC_GO(3, 0) else PDEC_GO(4, 0) }
-#undef PDEC_GO
+    hipLaunchKernelGGL(pdec_fn(RT, a.precision, LT), dim3(PS_WGS), dim3(PS_THREADS), lds, s, p);
     MTTS_CHECK_LAUNCH("pdec_kernel");
     return ps_launched(s);
 }
