@@ -78,6 +78,51 @@ def test_persistent_kernels_shape_edges_gradients_match_oracle(preset, B, L, T):
     run_train_step_case(preset, B, L, T, {}, seed=10 if B == 63 else 9)
 
 
+# Round 5: inputs ABOVE 128 characters through the persistent attention decoder (pdec_kernel<RT, PREC, LT>, LT = 2 / 3 position tiles:
+# Mt values re-requested per step through a buffer descriptor, energies / softmax / context looping over the tiles, the third tile's
+# memory rows requested inside the context stage).  The reference attends over any length (modules/attention.py:39-45); its own
+# validation set has inputs of up to 304 characters.  L = 129 / 257: first position of a new tile; 200: the bench leg
+# `roofline_L200`; 304: the reference's maximum; 384: the kernel's limit; ragged lengths inside the batch; both memory widths; every
+# parameter gradient against the oracle's autograd (the backward consumes the saved alignments / cumulative alignments / queries).
+@pytest.mark.parametrize('preset,B,L,T', [('shared_training', 5, 129, 5), ('shared_training', 18, 200, 6), ('shared_training', 4, 304, 4),
+                                          ('generated_switching', 10, 257, 4), ('shared_training', 3, 384, 3)])
+def test_persistent_decoder_long_inputs_gradients_match_oracle(preset, B, L, T):
+    from tests.test_gpu_more import run_train_step_case
+    run_train_step_case(preset, B, L, T, {})
+
+
+def test_persistent_decoder_long_inputs_full_batch_forward_matches_oracle():
+    """Batch 64 (four row tiles) x 200 characters with ragged lengths, 8 frames, forward: the `roofline_L200` configuration."""
+    from tests.test_gpu_more import run_train_step_case
+    run_train_step_case('shared_training', 64, 200, 8, {}, check_grads=False)
+
+
+_CHILD_LONG = _CHILD.replace('B, L, T = 64, 40, 61', 'B, L, T = 48, 200, 30')
+
+
+def test_long_input_persistent_equals_per_step_schedule_and_is_taken(tmp_path):
+    """L = 200: the persistent kernels (default) against the per-step launch schedule that inputs above 128 characters took until
+    round 4 (MTTS_PDEC_LT=1 restores it) - the same arithmetic in another summation order; and the bf16 instantiation runs."""
+    def run(name, env_add):
+        path = str(tmp_path / f'{name}.pt')
+        r = subprocess.run([sys.executable, '-c', _CHILD_LONG % {'root': ROOT}, path], env=dict(os.environ, **env_add), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return torch.load(path)
+    persistent = run('persistent', {})
+    steps = run('steps', {'MTTS_PDEC_LT': '1'})
+    for k, v in persistent.items():
+        assert torch.isfinite(v).all(), k
+        ref = steps[k]
+        rel = ((v.double() - ref.double()).norm() / ref.double().norm().clamp_min(1e-30)).item()
+        assert 0 < rel <= 2e-5 or torch.equal(v, ref) and k == 'stop', f'{k}: persistent vs per-step launches at L = 200, relative L2 {rel:.3e}'
+
+
+def test_bf16_persistent_decoder_long_input_matches_same_rounding_oracle():
+    """bf16 instantiation (pdec_kernel<RT, 1, 2>) at L = 150 against the oracle with the same operand rounding."""
+    from tests.test_gpu_more import run_train_step_case
+    run_train_step_case('shared_training', 16, 150, 10, {}, check_grads=False, bf16=True)
+
+
 def test_two_persistent_decodes_in_flight_from_two_streams():
     """A persistent kernel needs every workgroup of its grid resident; two of them dispatched at once from two streams could each hold
     a part of the chip and starve the other until the bounded spins give up.  The library orders a persistent launch behind the
