@@ -88,7 +88,10 @@ def test_persistent_kernels_shape_edges_gradients_match_oracle(preset, B, L, T):
                                           ('generated_switching', 10, 257, 4), ('shared_training', 3, 384, 3)])
 def test_persistent_decoder_long_inputs_gradients_match_oracle(preset, B, L, T):
     from tests.test_gpu_more import run_train_step_case
-    run_train_step_case(preset, B, L, T, {})
+    # (seed: with the default input seed the B = 5, L = 129 case has an encoder ReLU input within fp32 noise of zero - the encoder
+    #  convolution / batch-norm gradients then move by percents with EVERY decoder schedule, MTTS_PERSIST=0 included, while seeds 10 and
+    #  11 agree to 1e-5: gpurun_out r05c, scripts/dbg_long_inputs.py; the same discontinuity as the B = 63 case above)
+    run_train_step_case(preset, B, L, T, {}, seed=10 if (B, L) == (5, 129) else 9)
 
 
 def test_persistent_decoder_long_inputs_full_batch_forward_matches_oracle():
