@@ -714,6 +714,11 @@ int mtts_prof_end(float* total_ms, int* count);
  * between, subtracted by bench.py from the kernel brackets */
 float mtts_prof_empty_ms(void);
 
+/* launches of the pre-split GEMM core (pack passes + gemm_planes_kernel, csrc/gemm_planes.h) in this process: mtts_gemm_ex takes it
+ * for plain GEMMs above a size threshold (MTTS_GEMM_PLANES=0: never; MTTS_PLANES_MIN_GFLOP / _BF16: the threshold).  Tests use the
+ * count to see which core ran. */
+long mtts_gemm_planes_count(void);
+
 const char* mtts_last_error(void);
 /* ABI version.  101 (round 5) is NOT layout-compatible with 100: AdamArgs gained `guard`, LstmPackArgs lost `plain_rows`, AttnBwdArgs
  * lost `hsum_out` / `hsum_cols`, DecoderGradArgs lost three fields, the mtts_ksplit_* exports are gone, LstmStepArgs.precision takes 2

@@ -45,7 +45,10 @@ def decoder_bwd(ctx, dspec, dstop, dalign):
 
     import os
     ksb = int(os.environ.get('MTTS_KSB', cfg.get('ksb', 4)))                 # tuning knobs (scripts/sweep_bwd.sh)
-    nch = int(os.environ.get('MTTS_NCH_BWD', cfg.get('nch_bwd', 4)))
+    # workgroups per sample of the attention-step backward: 4 fill the chip at batch 64; inputs above 128 characters get one per 32
+    # positions so that they stay on the MFMA kernel (attn_bwd_fast_ok: <= 32 own rows per workgroup) instead of the generic one,
+    # whose LDS request also ends at L ~ 310
+    nch = int(os.environ.get('MTTS_NCH_BWD', cfg.get('nch_bwd', max(4, (L + 31) // 32))))
     # K-split of the ctx-column input gradient: as many slabs as keep the launch within ONE wave of workgroups (256 CUs)
     ksc = int(os.environ.get('MTTS_KSC', cfg.get('ksb_ctx', max(1, min(8, 256 // ((Dm + 15) // 16))))))
     g.ksb, g.nch, g.ksb_ctx = ksb, nch, ksc

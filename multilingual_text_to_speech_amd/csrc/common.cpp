@@ -148,6 +148,31 @@ float* workspace_for(hipStream_t s, size_t* bytes) {
     return nullptr;
 }
 
+// Pack buffer of the pre-split GEMM core (gemm_planes.h) for launches on `s`: grow-only, one per (device, stream) - helper streams get
+// their own, their GEMMs run beside the caller's.  Owned by the library (hipMalloc): its size follows the largest operand pair seen.
+namespace {
+struct PlanesBuf { int device; hipStream_t stream; char* ptr; size_t bytes; };
+std::vector<PlanesBuf> g_planes;
+}
+char* planes_buffer(hipStream_t s, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    const int dev = current_device();
+    PlanesBuf* e = nullptr;
+    for (PlanesBuf& b : g_planes) if (b.device == dev && b.stream == s) { e = &b; break; }
+    if (!e) { g_planes.push_back(PlanesBuf{dev, s, nullptr, 0}); e = &g_planes.back(); }
+    if (e->bytes >= bytes) return e->ptr;
+    if (e->ptr) {                                    // kernels of earlier launches may still read the old buffer
+        if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        (void)hipFree(e->ptr);
+        e->ptr = nullptr; e->bytes = 0;
+    }
+    const size_t want = ((bytes + bytes / 4) + ((size_t)64 << 20) - 1) & ~(((size_t)64 << 20) - 1);
+    void* q = nullptr;
+    if (hipMalloc(&q, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    e->ptr = (char*)q; e->bytes = want;
+    return e->ptr;
+}
+
 MTTS_API int mtts_set_workspace(void* ptr, size_t bytes) {
     std::lock_guard<std::mutex> lk(g_mu);
     const int dev = current_device();

@@ -33,6 +33,21 @@
 
 
 constexpr int BM = 128, BN = 128, BK = 32;
+
+// Linear tile index (already XCD-contiguous: every XCD walks a contiguous run of indices) -> tile coordinates.  Row-major order made
+// the 32 workgroups an XCD runs at a time cover one tile ROW: one A panel and 32 B panels - the whole B operand passes through every
+// XCD's 4 MiB L2 once per tile row.  Column strips of four tiles, row-major inside a strip: the same 32 workgroups cover 8 x 4 tiles
+// (8 A panels, 4 B panels), and a strip's four B panels stay L2-resident while its A panels stream by (38400 x 4096: exactly one
+// strip per XCD).  Measured on the K loop of the pre-split core: 1.42 -> 1.31 us per step (scripts/mb/mb_gemm_planes.hip).  Results
+// do not depend on the order (every tile is computed by one workgroup either way).
+__device__ __forceinline__ void gemm_tile_block(int id, int ntx, int nty, int& tile_m, int& tile_n) {
+    constexpr int W = 4;
+    const int nfull = ntx / W, per_strip = W * nty;
+    int strip = id / per_strip, rem = id - strip * per_strip, w = W;
+    if (strip >= nfull) { strip = nfull; rem = id - nfull * per_strip; w = ntx - W * nfull; }
+    tile_m = rem / w;
+    tile_n = strip * W + (rem - tile_m * w);
+}
 constexpr int KC_LD = BK + 4;     // 36 floats: conflict-free ds_read_b128 (36*i mod 64 distinct over 16 rows)
 constexpr int MC_LD = BM + 4;
 
@@ -297,7 +312,8 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(GemmArgs p, float* g
         const int q = nt / 8, r = nt % 8, xcd = id % 8, idx = id / 8;
         id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tile_m = id / ntx, tile_n = id % ntx;
+    int tile_m, tile_n;
+    gemm_tile_block(id, ntx, nty, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int z = blockIdx.z;
@@ -566,7 +582,8 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(GemmArgs p, float* g_
         const int q = nt / 8, r = nt % 8, xcd = id % 8, idx = id / 8;
         id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tile_m = id / ntx, tile_n = id % ntx;
+    int tile_m, tile_n;
+    gemm_tile_block(id, ntx, nty, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int z = blockIdx.z;
@@ -776,7 +793,8 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs p, float* g_ws)
         const int q = nt / 8, r = nt % 8, xcd = id % 8, idx = id / 8;
         id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tile_m = id / ntx, tile_n = id % ntx;
+    int tile_m, tile_n;
+    gemm_tile_block(id, ntx, nty, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int z = blockIdx.z;
@@ -898,6 +916,8 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmArgs p, float* g_ws)
         }
 }
 
+#include "gemm_planes.h"
+
 static int g_default_precision = 0;
 MTTS_API int mtts_set_precision(int precision) {
     MTTS_REQUIRE(precision == 0 || precision == 1, "mtts_set_precision: 0 (fp32) or 1 (bf16)");
@@ -981,7 +1001,18 @@ MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
         else if (p.shift_mode == 1 && !p.transA && p.Kc % BK == 0 && p.transB && (p.b_tap & 3) == 0) pipe = 2;
         else if (p.shift_mode == 2 && p.transA && p.transB && p.taps == 1 && p.seq_len >= BK) pipe = 3;
     }
-    if (pipe >= 0) {
+    // big plain GEMMs: operands split / rounded ONCE by a pack pass, K loop without vector arithmetic (gemm_planes.h)
+    bool planes = false;
+    if (!exact_f32 && planes_wanted(p, p.precision == 1)) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+        if (cap == hipStreamCaptureStatusNone) {
+            if (p.precision == 1) MTTS_TRY(planes_gemm<true>(p, grid, ws, s, &planes));
+            else MTTS_TRY(planes_gemm<false>(p, grid, ws, s, &planes));
+        }
+    }
+    if (planes) {
+    } else if (pipe >= 0) {
         const size_t ldsp = 2 * PP_OPERAND_B;
         if (pipe == 1) hipLaunchKernelGGL((gemm_pipe_kernel<false, false, 1>), grid, dim3(256), ldsp, s, p, ws);
         else if (pipe == 2) hipLaunchKernelGGL((gemm_pipe_kernel<false, true, 2>), grid, dim3(256), ldsp, s, p, ws);

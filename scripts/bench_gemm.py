@@ -1,11 +1,16 @@
-"""Time mtts_gemm_ex on the decoder's big shapes (NT forward, NN dgrad, TT wgrad): python scripts/bench_gemm.py"""
+"""Time mtts_gemm_ex on the decoder's big shapes (NT forward, NN dgrad, TT wgrad): python scripts/bench_gemm.py [bf16]
+(per call, pack passes of the pre-split core included; MTTS_GEMM_PLANES=0 for the cores that split on the fly)"""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
-from multilingual_text_to_speech_amd import kernels as K
+from multilingual_text_to_speech_amd import kernels as K, _C
 dev = torch.device('cuda')
+if len(sys.argv) > 1 and sys.argv[1] == 'bf16':
+    _C.set_precision('bf16')
 R = 38400
-cases = [('fwd  y=xW^T', 4096, 4096, 4096), ('fwd  y=xW^T', R, 4096, 1536), ('fwd  y=xW^T', R, 512, 2560), ('fwd  y=xW^T', 3072, 4096, 1536),
-         ('dgrad dx=dyW', R, 1536, 4096), ('dgrad dx=dyW', 3072, 1024, 4096), ('wgrad dW=dy^Tx', 4096, 1536, R), ('wgrad dW=dy^Tx', 4096, 1024, R)]
+cases = [('fwd  y=xW^T', 4096, 4096, 4096), ('fwd  y=xW^T', R, 4096, 1536), ('fwd  y=xW^T', R, 4096, 256), ('fwd  y=xW^T', R, 512, 2560), ('fwd  y=xW^T', 3072, 4096, 1536),
+         ('dgrad dx=dyW', R, 1536, 4096), ('dgrad dx=dyW', 3072, 1024, 4096), ('wgrad dW=dy^Tx', 4096, 1536, R), ('wgrad dW=dy^Tx', 4096, 1024, R),
+         # per-chunk weight gradients of the decoder backward (48 steps x 64 rows)
+         ('wgrad dW=dy^Tx', 4096, 1024, 3072), ('wgrad dW=dy^Tx', 4096, 544, 3072), ('wgrad dW=dy^Tx', 4096, 256, 3072)]
 for name, M, N, Kd in cases:
     if name.startswith('fwd'):
         A, B = torch.randn(M, Kd, device=dev), torch.randn(N, Kd, device=dev) * 0.1
@@ -31,3 +36,4 @@ for name, M, N, Kd in cases:
     r = ref()
     err = ((C.double() - r).abs().max() / r.abs().max()).item()
     print('%-15s M=%5d N=%5d K=%5d  %.3f ms  %6.1f TFLOP/s  max|err|/max|ref| %.2e' % (name, M, N, Kd, ms, 2.0 * M * N * Kd / ms * 1e-9, err))
+print('pre-split core launches:', int(_C.lib().mtts_gemm_planes_count()))

@@ -122,20 +122,86 @@ for shape in SHAPES:
 for case in CONV_CASES:
     for name, t in zip(('y', 'dx', 'dw'), _conv_case(case, 29)[3:]):
         out[(case, name)] = t.cpu()
+from multilingual_text_to_speech_amd import _C
+out['planes_launches'] = int(_C.lib().mtts_gemm_planes_count())
 torch.save(out, sys.argv[1])
 '''
 
 
 def test_pipelined_core_returns_the_bits_of_the_phase_alternating_core(tmp_path):
+    """... and so does the core on PRE-SPLIT operands (round 5, csrc/gemm_planes.h: pack pass + gemm_planes_kernel), which a third
+    child runs on every plain shape (MTTS_PLANES_MIN_GFLOP=0 lifts its size threshold): the same exact split, the same six terms in
+    the same order, the same K order and split-K partition."""
     outs = {}
-    for mode, env_add in (('pipe', {'MTTS_GEMM_PIPE': '1'}), ('split', {'MTTS_GEMM_PIPE': '0'})):
+    for mode, env_add in (('pipe', {'MTTS_GEMM_PIPE': '1', 'MTTS_GEMM_PLANES': '0'}), ('split', {'MTTS_GEMM_PIPE': '0', 'MTTS_GEMM_PLANES': '0'}),
+                          ('planes', {'MTTS_PLANES_MIN_GFLOP': '0', 'MTTS_GEMM_PLANES': '2'})):
         path = str(tmp_path / f'gemm_{mode}.pt')
         env = dict(os.environ, **env_add)
         r = subprocess.run([sys.executable, '-c', _CHILD % {'root': ROOT}, path], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         outs[mode] = torch.load(path)
-    assert outs['pipe'].keys() == outs['split'].keys() and len(outs['pipe']) >= 40
+    assert outs['pipe'].keys() == outs['split'].keys() == outs['planes'].keys() and len(outs['pipe']) >= 40
+    assert outs['planes']['planes_launches'] >= 24 and outs['pipe']['planes_launches'] == 0
     for key, c in outs['split'].items():
+        if key == 'planes_launches':
+            continue
         assert torch.equal(outs['pipe'][key], c), f'{key}: pipelined and phase-alternating cores differ'
+        assert torch.equal(outs['planes'][key], c), f'{key}: pre-split and phase-alternating cores differ'
+
+
+# production shapes at the DEFAULT size threshold (the hoisted decoder projections, a per-chunk weight gradient, an input gradient), K
+# that is not a multiple of 32 (zero-filled tail of the last record), an odd row count, every storage variant
+PLANES_SHAPES = [((38400, 4096, 1568), 'nt'), ((4096, 1568, 3072), 'tn'), ((3072, 1568, 4096), 'nn'), ((4096, 1024, 3072), 'tt'),
+                 ((3077, 2052, 1000), 'nt'), ((2052, 1000, 3100), 'tn'), ((38400, 81, 1568), 'nt')]
+
+_CHILD_PLANES = r'''
+import sys, torch
+sys.path.insert(0, %(root)r)
+from tests.test_gpu_gemm_pipe import PLANES_SHAPES, _run
+from multilingual_text_to_speech_amd import _C
+out = {}
+for shape, variant in PLANES_SHAPES:
+    bias = torch.randn(shape[1], device='cuda', generator=torch.Generator(device='cuda').manual_seed(3))
+    out[(shape, variant)] = _run(*shape, variant, seed=31, alpha=0.75, beta=0.5, bias=bias, act=2)[2].cpu()
+out['planes_launches'] = int(_C.lib().mtts_gemm_planes_count())
+torch.save(out, sys.argv[1])
+'''
+
+
+def test_presplit_core_at_production_shapes_returns_the_bits_of_the_pipelined_core(tmp_path):
+    outs = {}
+    for mode, env_add in (('planes', {'MTTS_GEMM_PLANES': '2'}), ('pipe', {'MTTS_GEMM_PLANES': '0'})):
+        path = str(tmp_path / f'gemm_{mode}.pt')
+        r = subprocess.run([sys.executable, '-c', _CHILD_PLANES % {'root': ROOT}, path], env=dict(os.environ, **env_add), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs[mode] = torch.load(path)
+    assert outs['planes']['planes_launches'] >= len(PLANES_SHAPES) - 1 and outs['pipe']['planes_launches'] == 0, outs['planes']['planes_launches']
+    for key, c in outs['pipe'].items():
+        if key != 'planes_launches':
+            assert torch.equal(outs['planes'][key], c), f'{key}: pre-split core differs from the pipelined / phase-alternating core'
+
+
+@pytest.mark.parametrize('shape,variant', [((4096, 4096, 1568), 'nt'), ((4096, 1568, 3072), 'tn'), ((1000, 2052, 3100), 'tt'), ((3077, 1028, 1000), 'nn')])
+def test_presplit_core_bf16_equals_the_fp64_product_of_the_rounded_operands(shape, variant, monkeypatch):
+    """bf16 mode of the pre-split core (one RNE-rounded plane, records of three K blocks): fp32 accumulation of exact bf16 x bf16
+    products - as close to the fp64 product of the rounded operands as an fp32 matmul of the same rounded operands is (the error left
+    is the fp32 summation's, which grows with K: 6e-7 * sum |a b| at K = 1568)."""
+    from multilingual_text_to_speech_amd import _C
+    M, N, K = shape
+    before = int(_C.lib().mtts_gemm_planes_count())
+    _C.set_precision('bf16')
+    try:
+        A, B, C = _run(M, N, K, variant, seed=17)
+    finally:
+        _C.set_precision('fp32')
+    assert int(_C.lib().mtts_gemm_planes_count()) == before + 1
+    Ar, Br = A.to(torch.bfloat16).double(), B.to(torch.bfloat16).double()
+    ref = Ar @ Br.t()
+    scale = Ar.abs() @ Br.abs().t()
+    err = ((C.double() - ref).abs() / scale).max().item()
+    err_torch = (((A.to(torch.bfloat16).float() @ B.to(torch.bfloat16).float().t()).double() - ref).abs() / scale).max().item()
+    assert err <= 2.0 * err_torch + 2.0 ** -24, f'{variant} {shape}: {err:.3e} (torch fp32 on the rounded operands: {err_torch:.3e})'
+    unrounded = ((C.double() - A.double() @ B.double().t()).abs() / scale).max().item()
+    assert unrounded > 1e-4, 'operands were not rounded to bf16: this is not the bf16 path'
 
 

@@ -88,10 +88,11 @@ def test_persistent_kernels_shape_edges_gradients_match_oracle(preset, B, L, T):
                                           ('generated_switching', 10, 257, 4), ('shared_training', 3, 384, 3)])
 def test_persistent_decoder_long_inputs_gradients_match_oracle(preset, B, L, T):
     from tests.test_gpu_more import run_train_step_case
-    # (seed: with the default input seed the B = 5, L = 129 case has an encoder ReLU input within fp32 noise of zero - the encoder
-    #  convolution / batch-norm gradients then move by percents with EVERY decoder schedule, MTTS_PERSIST=0 included, while seeds 10 and
-    #  11 agree to 1e-5: gpurun_out r05c, scripts/dbg_long_inputs.py; the same discontinuity as the B = 63 case above)
-    run_train_step_case(preset, B, L, T, {}, seed=10 if (B, L) == (5, 129) else 9)
+    # (seed: long inputs have B x L x 512 x 3 ReLU units in the encoder; with some input seeds one of them sits within fp32 noise of zero
+    #  and takes different signs on the CPU and the GPU - the encoder convolution / batch-norm gradients (and only those) then move by
+    #  percents with EVERY decoder schedule, MTTS_PERSIST=0 included: seed 9 at L = 129 / 304 / 384, seed 10 at L = 304, while seeds 11 and
+    #  12 agree to 1e-5 everywhere (profiles/r05_dbg_long_inputs.txt, scripts/dbg_long_inputs.py; the discontinuity of the B = 63 case above))
+    run_train_step_case(preset, B, L, T, {}, seed=11 if L in (129, 304, 384) else 9)
 
 
 def test_persistent_decoder_long_inputs_full_batch_forward_matches_oracle():
