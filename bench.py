@@ -386,6 +386,50 @@ def measure_traffic(preset, B, dtype='f32', timeout=240):
             'method': f'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), decode of {TRAFFIC_T[1]} minus {TRAFFIC_T[0]} frames'}, None
 
 
+def measure_mfma(preset, B, dtype='f32', timeout=240):
+    """Matrix-pipe occupancy of the forward decoder's kernels from ONE rocprofv3 PMC pass (SQ_VALU_MFMA_BUSY_CYCLES: matrix-pipe busy
+    cycles summed over the chip's 1024 SIMDs) over the traffic-probe child.  Per kernel: busy cycles / (1024 SIMDs x duration x 2.4 GHz)
+    = fraction of the matrix peak at the nominal clock (bf16 MFMA 2.5 PF dense / fp32 MFMA 157 TF: the counter counts pipe cycles
+    whatever the operand type).  North star: 'rocprof HBM GB/s AND MFMA utilisation against chip peak'."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which('rocprofv3') is None:
+        return None, 'rocprofv3 not found'
+    d = tempfile.mkdtemp(prefix='mtts_pmc_', dir='/tmp')
+    try:
+        cmd = ['rocprofv3', '--kernel-trace', '--pmc', 'SQ_VALU_MFMA_BUSY_CYCLES', '-d', d, '-o', 'p', '--output-format', 'csv', '--',
+               sys.executable, os.path.abspath(__file__), '--traffic-probe', '--preset', preset, '--batch', str(B), '--dtype', dtype]
+        r = subprocess.run(cmd, cwd='/tmp', env={**os.environ, 'TMPDIR': '/tmp'}, capture_output=True, text=True, timeout=timeout)
+        cfiles = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
+        tfiles = glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True)
+        if r.returncode != 0 or not cfiles or not tfiles:
+            return None, f'rocprofv3 MFMA pass failed (rc {r.returncode}): {(r.stderr or r.stdout)[-200:]}'
+        busy, dur = collections.defaultdict(float), collections.defaultdict(float)
+        name_of = lambda n: n.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
+        with open(cfiles[0], newline='') as f:
+            for row in csv.DictReader(f):
+                if row['Counter_Name'] == 'SQ_VALU_MFMA_BUSY_CYCLES':
+                    busy[name_of(row['Kernel_Name'])] += float(row['Counter_Value'])
+        with open(tfiles[0], newline='') as f:
+            for row in csv.DictReader(f):
+                dur[name_of(row['Kernel_Name'])] += float(row['End_Timestamp']) - float(row['Start_Timestamp'])
+        top = sorted(dur.items(), key=lambda kv: -kv[1])[:6]
+        total_ns = sum(dur.values())
+        per_kernel = {k: {'share_of_kernel_time': round(v / total_ns, 3), 'mfma_frac_of_peak': round(busy.get(k, 0.0) / (1024.0 * v * 2.4), 4)}
+                      for k, v in top if v > 0}
+        overall = sum(busy.values()) / (1024.0 * total_ns * 2.4)
+        return {'mfma_frac_of_peak': round(overall, 4), 'kernels': per_kernel,
+                'method': 'rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES over the decoder-forward probe: busy cycles / (1024 SIMDs x kernel time x 2.4 GHz)'}, None
+    except Exception as exc:       # reporting only
+        return None, repr(exc)[:200]
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def recorded_reference_baseline():
     """The reference itself, timed in the build container (scripts/cpu_reference_baseline.py -> profiles/cpu_reference.json)."""
     try:
@@ -659,6 +703,12 @@ def main():
                     roof['traffic_frac'] = round(traffic['bytes_per_step'] / (roof['us_per_step'] * 1e-6) / 8e12, 4)
             except Exception as exc:
                 roof['traffic_detail'] = {'error': repr(exc)[:200]}
+            try:      # matrix-pipe occupancy of the same decoder forward (one more PMC pass)
+                mfma, why = measure_mfma(args.preset, B, args.dtype)
+                roof['mfma_busy'] = mfma['mfma_frac_of_peak'] if mfma else None
+                roof['mfma_detail'] = mfma if mfma else {'error': why}
+            except Exception as exc:
+                roof['mfma_detail'] = {'error': repr(exc)[:200]}
             # batch 240 = the valid batch next to the north star's 256 on ONE GPU; batch 40 = what one rank of BASELINE configs[3]
             # (global batch 320 over 8 GPUs, bf16) actually sees
             for key, nb, dt_ in (('roofline_b240', 240, 'f32'), ('roofline_b240_bf16', 240, 'bf16'), ('roofline_b40_bf16', 40, 'bf16')):

@@ -4,13 +4,6 @@
 
 constexpr int ATB_THREADS = 512;
 
-// micro-benchmark builds only (scripts/mb/mb_attn_bwd.hip, -DATB_PROF): workgroup 0 / thread 0 stamps the shader clock per stage
-#ifdef ATB_PROF
-__device__ unsigned long long g_atb_stamps[16];
-#define ATB_STAMP(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_atb_stamps[k] = __builtin_readcyclecounter(); } while (0)
-#else
-#define ATB_STAMP(k) do { } while (0)
-#endif
 
 __device__ __forceinline__ float block_sum(float v, float* red, int tid) {
     v = wave_sum(v);
@@ -64,7 +57,6 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& p, float* sm, c
     float* dsL = UT + 32 * DS_LD;        // [BROWS][DS_LD]
     float* gL = Up;                      // [2][BROWS][BG_LD]  g tiles of the two K halves; U[a][tap] is dead after the PL recompute
     const long slab = (long)b * p.nch + ch;
-    ATB_STAMP(0);
 
     // ---- burst of independent loads
     const int ac = min(tid, A - 1), lcl = min(tid, L - 1);
@@ -145,7 +137,6 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& p, float* sm, c
     sdot = wave_total_hi(sdot);
     if (lane == 63) red[wave] = sdot;
     __syncthreads();
-    ATB_STAMP(1);                                         // loads landed, operands staged in LDS
     // the filter bank (the same 16 KB for every workgroup and step: L2 hits) is requested now and staged behind the dw stage, which
     // covers its latency; in the entry burst its 8 registers per thread pushed the 128-VGPR fused launch into spills
     // thread (channel ua = tid >> 2, taps 8 (tid & 3) .. + 7): no division by the tap count, and the zero taps ksz..31 come with it
@@ -159,7 +150,6 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& p, float* sm, c
     float S = 0.f;                                        // softmax-backward scalar: sum_d dctx ctx + sum_l w (dalign + dcum)
 #pragma unroll
     for (int i = 0; i < ATB_THREADS / 64; ++i) S += red[i];
-    ATB_STAMP(2);
 
     // ---- dw for the own rows (wave per row, memory rows already in registers), de = w (dw - S); padded rows -> 0
     float dwr[BNR_MAX];                                   // select instead of branch on the Dm tail: one LDS read per k, no exec-mask regions
@@ -201,7 +191,6 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& p, float* sm, c
             }
     }
     __syncthreads();
-    ATB_STAMP(3);                                         // dw / de of the own rows
 
     // ---- PL recompute on MFMA, ds = de * v * (1 - tanh^2), dMt accumulation, dq / dv column sums
     if (16 * wave < A) {
@@ -239,7 +228,6 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& p, float* sm, c
         if (q4 == 0 && a < A) { accq[a] = sq; accv[a] = sv; }
     }
     __syncthreads();
-    ATB_STAMP(4);                                         // PL recompute (MFMA), tanh, ds, dMt read-modify-write, column sums
     if (tid < A) {
         atomicAdd(p.dq + (long)b * A + tid, accq[tid]);
         atomicAdd(p.dbias_slab + slab * A + tid, accq[tid]);
@@ -272,7 +260,6 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& p, float* sm, c
             }
     }
 
-    ATB_STAMP(5);                                         // dq atomics, slab updates, dU contraction + slab read-modify-write
     // ---- g[row, tap] = sum_a ds[row, a] * U[a][tap]; dcum window: dcum[row + tap] += g.  4 tiles x 2 K-halves over 8 waves; the tiles go to
     //      LDS and the anti-diagonals are summed in a fixed order (round 4: LDS float atomics here cost 2 us per launch and made the sum
     //      order-dependent)
@@ -295,7 +282,6 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& p, float* sm, c
         }
     }
     __syncthreads();
-    ATB_STAMP(6);                                         // g contraction
     {   // window position i = row + tap: 8 lanes per position, rows = sub + 8 k
         const int i = tid >> 3, sub = tid & 7;
         float sg = 0.f;
@@ -312,7 +298,6 @@ __device__ __forceinline__ void attn_bwd_body(const AttnBwdArgs& p, float* sm, c
         if (sub == 0 && i < nl + ksz - 1 && m >= 0 && m < L) atomicAdd(p.dcum_in + (long)b * L + m, sg);
     }
     if (tid >= l0 && tid < l1) atomicAdd(p.dcum_in + (long)b * L + tid, dco_r);     // carry: cum_out = cum_in + w
-    ATB_STAMP(7);                                         // global dcum atomics issued
 }
 
 

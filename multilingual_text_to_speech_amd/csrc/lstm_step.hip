@@ -640,12 +640,7 @@ __global__ __launch_bounds__(LS_THREADS, 4) void lstm_fused_kernel(LsFused p) {
         if (kg < p.K0) { xsrc = p.x0; ld = p.ld0; }
         else if (kg < p.K0 + p.K1) { xsrc = p.x1; ld = p.ld1; kg -= p.K0; }
         else { xsrc = p.x2; ld = p.ld2; kg -= p.K0 + p.K1; }
-#ifndef LF_NO_X          // (scripts/mb/mb_lstm_fused.hip: stream knock-outs of the timing harness)
         xg[slot] = *reinterpret_cast<const float4*>(xsrc + (long)grow * ld + kg + 4 * sch);
-#endif
-#ifdef LF_NO_W
-        return;
-#endif
         const float4* ws = reinterpret_cast<const float4*>(p.wp) + ((long)cgrp * p.nkb + kb) * (64 * NWF) + lane;
 #pragma unroll
         for (int f = 0; f < NWF; ++f) wa[slot][f] = ws[64 * f];
@@ -665,14 +660,6 @@ __global__ __launch_bounds__(LS_THREADS, 4) void lstm_fused_kernel(LsFused p) {
     // Every load of the stream is UNCONDITIONAL (blocks past the end re-read the last block and are never multiplied): with loads or
     // their uses under a condition the compiler's wait-count bookkeeping gives up and waits for vmcnt(0) before every block.
     const int last = p.nkb - 1;
-#if defined(LF_NO_X) || defined(LF_NO_W)
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
-        xg[d] = make_float4(1.f, 2.f, 3.f, 4.f);
-#pragma unroll
-        for (int f = 0; f < NWF; ++f) wa[d][f] = make_float4(1.f, 2.f, 3.f, 4.f);
-    }
-#endif
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) issue(min(d, last), d);
     __builtin_amdgcn_sched_barrier(0);
@@ -688,11 +675,6 @@ __global__ __launch_bounds__(LS_THREADS, 4) void lstm_fused_kernel(LsFused p) {
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt) { acc[rt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[rt][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     auto use = [&](int d, int buf) {                        // block in weight slot d x the staged activation block in xs[buf]
-#ifdef LF_NO_MFMA
-#pragma unroll
-        for (int rt = 0; rt < NRT; ++rt) acc[rt][0][0] += xs[buf][0][rh * (16 * NRT) + 16 * rt + i16][q4] + wa[d][0].y + wa[d][NWF - 1].z;
-        return;
-#endif
         if (PREC == 2) {
             Frag8 wb[3];
 #pragma unroll
@@ -765,10 +747,6 @@ __global__ __launch_bounds__(LS_THREADS, 4) void lstm_fused_kernel(LsFused p) {
             __syncthreads();
         }
 
-#ifdef LF_NO_EPI
-    if (row0 + i16 < B) c.h_out[(long)(row0 + i16) * H + 16 * ug + 4 * ct + q4] = acc[0][0][0] + acc[0][1][1] + acc[NRT - 1][0][2] + acc[NRT - 1][1][3];
-    return;
-#endif
     // ---- cell of the wave's own tile, h tile, query partials
     f32x4 gsum[NRT];
 #pragma unroll
@@ -848,15 +826,10 @@ __global__ __launch_bounds__(LS_THREADS, 2) void lstm_fused2_kernel(LsFused p) {
             if (kg < p.K0) { xsrc = p.x0; ld = p.ld0; }
             else if (kg < p.K0 + p.K1) { xsrc = p.x1; ld = p.ld1; kg -= p.K0; }
             else { xsrc = p.x2; ld = p.ld2; kg -= p.K0 + p.K1; }
-#ifndef LF_NO_X          // (scripts/mb/mb_lstm_fused.hip: stream knock-outs of the timing harness)
             xg[slot][j] = *reinterpret_cast<const float4*>(xsrc + (long)grow * ld + kg + 4 * sch);
-#endif
         }
     };
     auto issue_w = [&](int it, int slot) {
-#ifdef LF_NO_W
-        return;
-#endif
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
             const float4* ws = reinterpret_cast<const float4*>(p.wp) + ((long)(ug * 4 + 2 * ctp + cc) * p.nkb + min(4 * it + kq, last)) * (64 * NPLX) + lane;
@@ -886,18 +859,6 @@ __global__ __launch_bounds__(LS_THREADS, 2) void lstm_fused2_kernel(LsFused p) {
             }
         }
     };
-#if defined(LF_NO_X) || defined(LF_NO_W)
-#pragma unroll
-    for (int d = 0; d < DX; ++d)
-#pragma unroll
-        for (int j = 0; j < NXG; ++j) xg[d][j] = make_float4(1.f, 2.f, 3.f, 4.f);
-#pragma unroll
-    for (int d = 0; d < DW; ++d)
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-            for (int f = 0; f < NPLX; ++f) wa[d][cc][f] = make_float4(1.f, 2.f, 3.f, 4.f);
-#endif
 #pragma unroll
     for (int d = 0; d < DX; ++d) issue_x(d, d);
 #pragma unroll
@@ -938,9 +899,6 @@ __global__ __launch_bounds__(LS_THREADS, 2) void lstm_fused2_kernel(LsFused p) {
         for (int rt = 0; rt < RT; ++rt) {
             if (rt + 1 < RT) load_a(u & 1, rt + 1, a[(rt + 1) & 1]);
             Frag8 (&ar)[NPLX] = a[rt & 1];
-#ifdef LF_NO_MFMA
-            acc[rt][0][0] += __uint_as_float(ar[0].u[0] ^ ar[NPLX - 1].u[3]) + __uint_as_float(wb[0][0].u[1]) + __uint_as_float(wb[1][NPLX - 1].u[2]);
-#else
             if (PREC == 2) {       // six terms, small ones first (the order of gemm.hip / lstm_gates_body); the two column groups alternate
 #define LF2_MM(PA, PB) acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[PA].v, wb[0][PB].v, acc[rt][0], 0, 0, 0); \
                        acc[rt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[PA].v, wb[1][PB].v, acc[rt][1], 0, 0, 0);
@@ -950,10 +908,7 @@ __global__ __launch_bounds__(LS_THREADS, 2) void lstm_fused2_kernel(LsFused p) {
                 acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[0].v, wb[0][0].v, acc[rt][0], 0, 0, 0);
                 acc[rt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[0].v, wb[1][0].v, acc[rt][1], 0, 0, 0);
             }
-#endif
-#ifndef LF_NO_STAGE
             if (rt == (RT > 2 ? 1 : 0) && stage_next) stage(it + 1, (u + 1) % DX, (u + 1) & 1);
-#endif
         }
     };
     // block it lives in weight slot it % DW, activation slot it % DX and LDS buffer it & 1 (all static in the body unrolled UNR times).
@@ -983,10 +938,6 @@ __global__ __launch_bounds__(LS_THREADS, 2) void lstm_fused2_kernel(LsFused p) {
             __syncthreads();
         }
 
-#ifdef LF_NO_EPI
-    if (row0 + i16 < B) c.h_out[(long)(row0 + i16) * H + 16 * ug + 4 * ct + q4] = acc[0][0][0] + acc[0][1][1] + acc[RT - 1][0][2] + acc[RT - 1][1][3];
-    return;
-#endif
     // ---- the four k quarters meet (the loop's last barrier has retired every read of the activation planes: their space now holds
     //      the partial tiles): part[kq][column group][row][16]
 #pragma unroll
@@ -1025,12 +976,6 @@ constexpr int PN_MAXK1 = 6;      // 16-wide k-chunks of layer 1: Kin <= 96
 constexpr int PN_NCG = 4;        // column groups of layer 2 (grid.y): more workgroups for a 22-MFLOP problem
 constexpr int PN_MAXK2 = 8;      // layer-2 k-chunks per wave: the 8 waves are 4 column tiles x 2 K-halves, P <= 256
 
-#ifdef PN_PROF           // micro-benchmark builds only (scripts/mb/mb_prenet2.hip): workgroup (0, 0) / thread 0 stamps the shader clock per stage
-__device__ unsigned long long g_pn_stamps[8];
-#define PN_STAMP(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_pn_stamps[k] = __builtin_readcyclecounter(); } while (0)
-#else
-#define PN_STAMP(k) do { } while (0)
-#endif
 __global__ __launch_bounds__(512) void prenet2_kernel(Prenet2 p) {
     extern __shared__ __attribute__((aligned(16))) float psm[];      // y1 tile [16][P + 4], then the K-half partial sums [4][16][17]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1047,7 +992,6 @@ __global__ __launch_bounds__(512) void prenet2_kernel(Prenet2 p) {
     const bool t2_ok = (wave & 3) < tpg && t2 < nct;
     const int t2c = min(t2, nct - 1);
     const int kc_lo = kh * ((nk2 + 1) >> 1), kc_hi = kh ? nk2 : ((nk2 + 1) >> 1);
-    PN_STAMP(0);
     // ---- EVERY global operand of both layers is requested here, before any arithmetic: one memory round trip (weights come
     //      from the Infinity Cache at best: eight other kernels ran since the previous step), then ~2.5 us of MFMA.
     //      Weights are in MFMA tile order ([column tile][k chunk][lane][4], mtts_pack_weight): one coalesced 1 KiB read per wave
@@ -1088,7 +1032,6 @@ __global__ __launch_bounds__(512) void prenet2_kernel(Prenet2 p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) keep2[r] = (int)m2p[p.m2 ? (long)min(row0 + 4 * q4 + r, p.B - 1) * P + 16 * t2c + i16 : 0];
     // ---- layer 1 (every workgroup of a row tile computes all of it: 0.65 MFLOP)
-    PN_STAMP(1);                                         // loads issued
     f32x4 acc[PN_MAXCT];
 #pragma unroll
     for (int c = 0; c < PN_MAXCT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1121,7 +1064,6 @@ __global__ __launch_bounds__(512) void prenet2_kernel(Prenet2 p) {
         }
     }
     __syncthreads();
-    PN_STAMP(2);                                         // layer 1 done (operands landed, MFMA, epilogue, LDS)
     // ---- layer 2: this wave's (column tile, K-half)
     f32x4 acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1134,7 +1076,6 @@ __global__ __launch_bounds__(512) void prenet2_kernel(Prenet2 p) {
             for (int s2 = 0; s2 < 4; ++s2) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], bv[s2], acc2, 0, 0, 0);
         }
     }
-    PN_STAMP(3);                                         // layer 2 products
     __syncthreads();                                    // all reads of the y1 tile are done: reuse the buffer for the K-half exchange
     float* red = psm + (wave & 3) * (16 * 17);
     if (kh == 1) {
@@ -1153,7 +1094,6 @@ __global__ __launch_bounds__(512) void prenet2_kernel(Prenet2 p) {
             p.y2[(long)row * P + col] = v;
         }
     }
-    PN_STAMP(4);                                         // K-half exchange + epilogue stores issued
 }
 
 // Returns -1 when the shape is outside the kernel's bounds (the caller then runs the layers one by one), 0 on success.

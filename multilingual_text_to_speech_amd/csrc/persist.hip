@@ -371,7 +371,6 @@ struct PsGen {
     PsCellCfg cell;
     float* xp;                  // [2][64 rows][H] exchange (XP layout)
     PsSync sync;
-    unsigned long long* prof;   // NULL in production
 };
 
 template <int RT, int PREC>
@@ -437,19 +436,6 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 // ---------------------------------------------------------------------------------------------------------------------------
 struct PsBar2 { unsigned* cnt; unsigned* err; };      // cnt[(g * 8 + x) * 32]: counter x of row group g
 
-#ifdef PS_PROF
-#define PS_PROF_WORDS (2 * PS_PROF)
-#else
-#define PS_PROF_WORDS 0
-#endif
-#ifdef PS_PROF
-__device__ unsigned long long* g_ps_prof_dev = nullptr;
-#endif
-#ifdef PS_PROF      // micro-benchmark builds only: workgroup 0 stamps the shader clock into LDS (no VMEM traffic), dumped at exit
-#define PS_STAMP(buf, slot, who) do { if (blockIdx.x == 0 && (who) && (slot) < PS_PROF) (buf)[slot] = __builtin_readcyclecounter(); } while (0)
-#else
-#define PS_STAMP(buf, slot, who) do { } while (0)
-#endif
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // pgen7: DATAFLOW form of the generator recurrence.  Workgroup = 8 MULTIPLIER waves + one SERVICE wave per 16-row group (12 waves):
@@ -476,9 +462,6 @@ __global__ __launch_bounds__(PS4_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
     volatile unsigned* done = reinterpret_cast<volatile unsigned*>(red + NG * 8 * 256);   // [4]  multiplier waves finished, per group (monotonic)
     volatile unsigned* seen = done + 4;                                                // [4]  publish number that has landed, per group
     volatile unsigned* lerr = done + 8;
-#ifdef PS_PROF
-    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(const_cast<unsigned*>(done) + 16);
-#endif
     const PsBar2 bar{p.sync.cnt, p.sync.err};
     if (tid < 12) done[tid] = 0;
     __syncthreads();
@@ -538,7 +521,6 @@ __global__ __launch_bounds__(PS4_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
                     if (*lerr != 0 || ++spins > (PS_SPIN_MAX << 2)) { if (lane == 0) { *lerr = 1; __hip_atomic_store(bar.err, 2u, PS_RLX, PS_AGENT); } return; }
                 }
             }
-            PS_STAMP(stamps, 512 + 4 * s + 0, g == 0 && lane == 0);
             const float* redg = red + g * (8 * 256);
             float4 g4 = bias4;
 #pragma unroll
@@ -558,12 +540,10 @@ __global__ __launch_bounds__(PS4_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
             c_state = co; h_state = ho;
             const float4 h4 = ps_quad_gather(h_state);
             if (valid && uu == 0) ps_st16_sc1(xregion(g, (t + 1) & 1), ps_xp_off(rl, 4 * c, nkb), h4);      // ONE 16-byte fp32 quantum (the consumers split)
-            PS_STAMP(stamps, 512 + 4 * s + 1, g == 0 && lane == 0);
             if (s + 1 < n_steps) {      // exchange first: drain the write-through stores, arrive; the saved state follows
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 arrive((unsigned)(s + 2));
             }
-            PS_STAMP(stamps, 512 + 4 * s + 2, g == 0 && lane == 0);
             if (valid) {
                 const size_t o = ((size_t)(t + 1) * B + row) * H + u;
                 if (uu == 0) *reinterpret_cast<float4*>(p.h + o) = h4;
@@ -574,11 +554,7 @@ __global__ __launch_bounds__(PS4_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
                 }
             }
             if (s + 1 < n_steps && !land((unsigned)(s + 2))) return;
-            PS_STAMP(stamps, 512 + 4 * s + 3, g == 0 && lane == 0);
         }
-#ifdef PS_PROF
-        if (p.prof && blockIdx.x == 0 && g == 0) for (int i = 512 + lane; i < PS_PROF; i += 64) p.prof[i] = stamps[i];
-#endif
         return;
     }
 
@@ -623,7 +599,6 @@ __global__ __launch_bounds__(PS4_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
         const unsigned pubn = (unsigned)(in / NG + 1);
         const bool early = has_next && seen[gn] >= pubn;
         const __amdgpu_buffer_rsrc_t nxr = xregion(gn, tn & 1);
-        PS_STAMP(stamps, 2 * i, tid == 64 * 5);
         f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < NBW; ++j) {
@@ -643,15 +618,11 @@ __global__ __launch_bounds__(PS4_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
         for (int r = 0; r < 4; ++r) rw[(4 * q4 + r) * 16 + i16] = acc0[r] + acc1[r];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_fetch_add(const_cast<unsigned*>(done) + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        PS_STAMP(stamps, 2 * i + 1, tid == 64 * 5);
         if (has_next && !early) {
             if (!wait_seen(gn, pubn)) return;
             issue_all(nxr);
         }
     }
-#ifdef PS_PROF
-    if (p.prof && blockIdx.x == 0 && wave == 5) for (int i = lane; i < 512; i += 64) p.prof[i] = stamps[i];
-#endif
 }
 
 
@@ -725,10 +696,6 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     float* es = qs + 32;                               // [4][LM] partial energies of the four slices
     float* wsm = es + 4 * LM;                          // [LM] alignment weights
     float* ctxp = wsm + LM;                            // [ng][Dq] context partial sums
-#ifdef PS_PROF
-    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(vb + 68);
-#endif
-#define PD_STAMP(k) PS_STAMP(stamps, 10 * (t - p.t0) + (k), tid == 0 && (t - p.t0) < 30)
 
     // ---- roles
     const int row = tid >> 2, uu = tid & 3, u = 4 * c + uu;          // column role: cell thread (row, unit), tid < 4 B
@@ -808,10 +775,8 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         const float4 pre4 = *reinterpret_cast<const float4*>(p.pre + ((size_t)t * B + rowc) * N + 4 * u);
         const size_t mo = ((size_t)t * B + rowc) * H + u;
         const unsigned hm = p.hmask ? (unsigned)p.hmask[mo] : 1u, cm = p.cmask ? (unsigned)p.cmask[mo] : 1u;
-        PD_STAMP(0);
         gates_ctx(t);
         ps_gates_store<RT>(acc, red);
-        PD_STAMP(1);
         __syncthreads();
         float4 ga;
         if (cellthr) ps_cell(red, row, uu, bias4, pre4, c_state, h_state, (int)hm, (int)cm, p.hmask != nullptr, p.cell, ga);
@@ -823,7 +788,6 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 ps_st16_sc1(ps_rsrc(p.h + (size_t)(t + 1) * B * H, (unsigned)(B * H * 4)), (unsigned)((row * H + u) * 4), h4);
             }
         }
-        PD_STAMP(2);
         ps_bar_arrive(p.sync, ++epoch);
         constexpr int NMEM = PD_NCM * (LT < 2 ? LT : 2);      // memory rows per thread requested ahead; LT == 3: the third tile's rows are requested inside the context stage
         float4 wq4[16]; float4 mem4[NMEM];
@@ -887,7 +851,6 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         // re-read it until no sentinel is left (the payload is the flag: one store -> load hop instead of drain -> two-level arrive ->
         // poll -> fetch).  The barrier itself is then waited for after the attention step, where it has long completed.
         if (!p.poll_h && !ps_bar_wait(p.sync, epoch)) return;
-        PD_STAMP(3);
         bool early = false;          // h-part fragments of step t + 1 already requested (workgroup-uniform)
 
         // ================= phase 2: attention (sample role) =================
@@ -928,7 +891,6 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             if (LT > 1) __builtin_amdgcn_sched_barrier(0);      // keep the memory rows' registers behind the query weights' (no hoisting above the query)
             pd_prefetch_mem();
             __syncthreads();
-            PD_STAMP(4);
             // ---- location features (MFMA, exact split) + partial energies: wave w <-> positions [16 w, 16 w + 16)
 #pragma unroll
             for (int it = 0; it < LT; ++it) {
@@ -966,7 +928,6 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 }
                 if (LT > 1) __builtin_amdgcn_sched_barrier(0);      // one position tile at a time (register budget)
             }
-            PD_STAMP(5);
             // ---- the other three slices' partial energies (tagged granules: the data is the flag)
             for (int idx = tid; idx < 3 * LM; idx += PS_THREADS) {
                 const int o = idx / LM, l = idx - o * LM, j2 = o + (o >= sj ? 1 : 0);
@@ -987,7 +948,6 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             // of the next step's gates here - they travel while the softmax and the context run - and the barrier's wait is skipped.
             if (tid == 0) eflag[0] = (LT == 1 && p.early_h && t + 1 < p.t1 && (!p.poll_h || __hip_atomic_load(p.sync.cnt, PS_RLX, PS_AGENT) >= epoch * 8u)) ? 1u : 0u;
             __syncthreads();
-            PD_STAMP(6);
             early = LT == 1 && eflag[0] != 0u;
             if (LT == 1) { if (early) gates_h_prefetch(t + 1); }
             // ---- masked softmax over the positions, cumulative alignment.  EVERY wave computes it (the others would idle at the barrier
@@ -1018,7 +978,6 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 }
             }
             __syncthreads();
-            PD_STAMP(7);
             // ---- context columns of this slice
             {
                 const int c4 = tid % nc4, lg = tid / nc4;
@@ -1065,19 +1024,13 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 ps_publish4<PREC>(xregion((t + 1) & 1), sb, d0 + 4 * tid, nkb, tt);
             }
         }
-        PD_STAMP(8);
         if (p.poll_h && !early && !ps_bar_wait(p.sync, epoch)) return;       // the h barrier of this step (complete long ago; `early`: seen complete)
         ps_bar_arrive(p.sync, ++epoch);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (t + 1 < p.t1) gates_h(t + 1, early);      // h_{t+1} landed one barrier ago
         if (!ps_bar_wait(p.sync, epoch)) return;
-        PD_STAMP(9);
     }
-#ifdef PS_PROF
-    if (g_ps_prof_dev && blockIdx.x == 0) for (int i = tid; i < 300; i += PS_THREADS) g_ps_prof_dev[i] = stamps[i];
-#endif
-#undef PD_STAMP
 }
 
 }  // namespace
@@ -1187,7 +1140,6 @@ MTTS_API long mtts_decoder_persist_ws_bytes(int B, int L, int H, int Dm, int A) 
     return ps_ws_eg_off(H, Dm) + 64L * 4 * (PD_LMAX * PD_LT_MAX) * 8 + 1024;
 }
 
-unsigned long long* g_ps_prof = nullptr;      // timeline buffer of the micro-benchmark harness (NULL in the library)
 bool g_pdec_poll_off = false;                 // harness switch: barrier-only hand-off of h (bit-equality check of the two forms)
 bool g_pdec_early_off = false;                // harness switch: h-part fragments requested behind the context barrier's arrive only
 
@@ -1198,7 +1150,7 @@ PsInst pgen_instance(int B, int H, int precision) {
     const int RT = (B + 15) / 16;
     PsInst k{nullptr, 0, 0};
     if (precision == 0) {
-        k.threads = PS4_THREADS; k.lds = (size_t)RT * 8 * 256 * 4 + 64 + PS_PROF_WORDS * 4;
+        k.threads = PS4_THREADS; k.lds = (size_t)RT * 8 * 256 * 4 + 64;
         k.fn = RT == 1 ? (const void*)pgen7_kernel<1> : RT == 2 ? (const void*)pgen7_kernel<2> : RT == 3 ? (const void*)pgen7_kernel<3> : (const void*)pgen7_kernel<4>;
     } else {
         k.threads = PS_THREADS; k.lds = (size_t)(H / 32) * 1024 + 8 * 64 * 16 * 4;
@@ -1208,9 +1160,6 @@ PsInst pgen_instance(int B, int H, int precision) {
 }
 size_t pdec_lds(int H, int Dm, int precision, int LT) {
     size_t lds = (size_t)((Dm + H) / 32) * (precision ? 1024 : 2048) + 8 * 64 * 16 * 4 + (LT == 1 ? PD_LMAX * 32 * 4 : 0) + (PD_LMAX * LT + 64) * 4 + 2 * 3 * 64 * 16 + 64 * 4 + 16;
-#ifdef PS_PROF
-    lds += 300 * 8;
-#endif
     return lds;
 }
 typedef void (*PdecFn)(PsDec);
@@ -1252,7 +1201,6 @@ int pgen_launch(const DecoderArgs& a, int t0, int t1, hipStream_t s) {
     char* ws = (char*)a.persist_ws;
     p.sync.cnt = (unsigned*)ws; p.sync.err = ps_err_word(a);
     p.xp = (float*)(ws + ps_ws_gen_off());
-    p.prof = g_ps_prof;
     std::lock_guard<std::mutex> launch_lk(ps_dev().launch_mu);      // serialize -> launch -> record is one critical section
     MTTS_TRY(ps_serialize(s));
     MTTS_CHECK_HIP(hipMemsetAsync(ws, 0, PS_ERR_OFF, s));           // counters (the error word is sticky until the host reads it)
@@ -1320,9 +1268,6 @@ int pdec_launch(const DecoderArgs& a, int t0, int t1, hipStream_t s) {
     if (p.poll_h)       // h rows of the steps this launch produces: sentinel until their owner's store lands
         MTTS_CHECK_HIP(hipMemsetAsync(a.h_att + (size_t)(t0 + 1) * a.B * a.H, 0xff, (size_t)(t1 - t0) * a.B * a.H * sizeof(float), s));
     const size_t lds = pdec_lds(a.H, a.Dm, a.precision, LT);
-#ifdef PS_PROF
-    MTTS_CHECK_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_ps_prof_dev), &g_ps_prof, sizeof(g_ps_prof), 0, hipMemcpyHostToDevice, s));
-#endif
     const int RT = (a.B + 15) / 16;
     hipLaunchKernelGGL(pdec_fn(RT, a.precision, LT), dim3(PS_WGS), dim3(PS_THREADS), lds, s, p);
     MTTS_CHECK_LAUNCH("pdec_kernel");

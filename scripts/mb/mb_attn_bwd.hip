@@ -1,7 +1,7 @@
 // Stand-alone harness of the attention-step backward (csrc/attention_bwd.hip compiled into this translation unit): per-launch time over
 // back-to-back launches on random operands at the benchmark's shape, and (-DATB_PROF) the in-kernel stage timeline of workgroup 0.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -DATB_PROF -o mb_attn_bwd mb_attn_bwd.hip && ./mb_attn_bwd [B] [L] [Dm] [n_part]
-#include "../../multilingual_text_to_speech_amd/csrc/attention_bwd.hip"
+#include "gen/attention_bwd.hip"
 #include <cstdio>
 #include <cstdlib>
 #include <stdarg.h>

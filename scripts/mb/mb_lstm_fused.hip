@@ -4,9 +4,10 @@
 //   -DLF_NO_X     activation fragments not loaded (constant operand)      -DLF_NO_W     weight fragments not loaded
 //   -DLF_NO_MFMA  products skipped                                        -DLF_NO_EPI   no cell / query epilogue (accumulators stored raw)
 //   -DLF_NO_STAGE (F2) no staging of the next block (no wait for its loads, no split, no LDS stores)
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast [-DLF_...] -o mb_lstm_fused mb_lstm_fused.hip
+//   python scripts/mb/instrument.py apply   (csrc/lstm_step.hip + instrumentation/lstm_step.hip.patch -> gen/lstm_step.hip: the knock-outs live in the patch)
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast [-DLF_...] -I ../../multilingual_text_to_speech_amd/csrc -I ../../include -o mb_lstm_fused mb_lstm_fused.hip
 //   ./mb_lstm_fused [B] [Kctx] [prec: 0 fp32 MFMA, 1 bf16, 2 fp32 as pre-split bf16 planes] [nb_max: 0 = F2 for prec 1 / 2 (lone chain), 4 = F]
-#include "../../multilingual_text_to_speech_amd/csrc/lstm_step.hip"
+#include "gen/lstm_step.hip"
 #include <cstdio>
 #include <cstdlib>
 #include <stdarg.h>

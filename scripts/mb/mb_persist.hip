@@ -1,8 +1,9 @@
 // Stand-alone harness for the persistent recurrence kernels (csrc/persist.hip compiled into this translation unit):
 //   * correctness: a short decode against a host (double precision) LSTM on the same random weights;
 //   * timing: T steps, HIP-event time per step, and (PS_PROF builds) the in-kernel timeline of workgroup 0.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -DPS_PROF=1024 [-DMB_PGEN4] -o mb_persist mb_persist.hip && ./mb_persist [B] [T]
-#include "../../multilingual_text_to_speech_amd/csrc/persist.hip"
+//   python scripts/mb/instrument.py apply   (csrc/persist.hip + instrumentation/persist.hip.patch -> gen/persist.hip: the stage clocks live in the patch)
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -DPS_PROF=1024 [-DMB_PGEN4] -I ../../multilingual_text_to_speech_amd/csrc -I ../../include -o mb_persist mb_persist.hip && ./mb_persist [B] [T]
+#include "gen/persist.hip"
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>

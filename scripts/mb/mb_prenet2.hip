@@ -1,7 +1,7 @@
 // Stand-alone harness of prenet2_kernel (csrc/lstm_step.hip compiled into this translation unit): the two prenet layers of one
 // free-running frame, per-launch time over back-to-back launches and (-DPN_PROF) the stage timeline of workgroup (0, 0).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -DPN_PROF -o mb_prenet2 mb_prenet2.hip && ./mb_prenet2 [B] [M] [P]
-#include "../../multilingual_text_to_speech_amd/csrc/lstm_step.hip"
+#include "gen/lstm_step.hip"
 #include <cstdio>
 #include <cstdlib>
 #include <stdarg.h>

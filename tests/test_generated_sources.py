@@ -18,3 +18,39 @@ def test_committed_gemm_stream_is_what_the_generator_emits():
         for n in range(8):
             for stage in ('S1A', 'S1B', 'S2A', 'S2B'):
                 assert committed.count(f'PP_{stage}({o}, {n})') == 1
+
+
+def test_committed_presplit_gemm_streams_are_what_the_generator_emits():
+    """csrc/gemm_planes_body.inc / gemm_planes_body_bf16.inc (K step of gemm_planes_kernel, fp32 mode: 48 MFMAs of the six terms; bf16
+    mode: 24 MFMAs, three K blocks per record) equal scripts/gen_gemm_planes.py's output; every step stores and requests the six
+    quanta of both operands once, reads every fragment of both k-halves once and holds one block barrier."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for flag, name, n_mfma in ((None, 'gemm_planes_body.inc', 48), ('--bf16', 'gemm_planes_body_bf16.inc', 24)):
+        cmd = [sys.executable, os.path.join(root, 'scripts', 'gen_gemm_planes.py')] + ([flag] if flag else [])
+        out = subprocess.run(cmd, capture_output=True, text=True, check=True).stdout
+        committed = open(os.path.join(root, 'multilingual_text_to_speech_amd', 'csrc', name)).read()
+        assert out == committed, name
+        groups = [l for l in committed.splitlines() if l.startswith('PL_MFMA')]
+        assert len(groups) == n_mfma and all(l.count('PL_MFMA(') == 1 and l.endswith('PL_SB') for l in groups)
+        assert committed.count('PL_BARRIER') == 1
+        assert committed.count('PL_RDA(') == 12 and committed.count('PL_RDB(') == 12
+        for o in 'AB':
+            assert committed.count(f'PL_NEXT({o})') == 1
+            for j in range(6):
+                assert committed.count(f'PL_ST({o}, {j})') == 1 and committed.count(f'PL_LD({o}, {j})') == 1
+
+
+def test_product_kernel_sources_carry_no_harness_instrumentation():
+    """The stage clocks and stream knock-outs of the micro-benchmark harnesses live in scripts/mb/instrumentation/*.patch
+    (scripts/mb/instrument.py), not behind #ifdef in the product's kernel sources - and the patches still apply to them."""
+    import os, re, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, 'multilingual_text_to_speech_amd', 'csrc')
+    pat = re.compile(r'LF_NO_|PS_PROF|PN_PROF|ATB_PROF|_STAMP\(|KO_LD|KO_MFMA')
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith(('.hip', '.h', '.inc', '.cpp')):
+            hits = [l for l in open(os.path.join(csrc, f)).read().splitlines() if pat.search(l)]
+            assert not hits, (f, hits[:3])
+    r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'mb', 'instrument.py'), 'apply'], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
