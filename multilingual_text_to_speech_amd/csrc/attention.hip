@@ -13,6 +13,7 @@
 // depends on computed data) and only then starts the dependent phases.  A generic kernel without the
 // register-resident prefetch covers shapes outside the fast kernel's static bounds.
 #include "common.h"
+#include <stdlib.h>
 
 constexpr int ATT_THREADS = 512;
 constexpr int NC_MAX = 8;     // memory float4 per thread   (ceil(L/ng) <= NC_MAX)
@@ -579,7 +580,8 @@ static bool att_big_ok(int B, int L, int A, int Dm, int ksz, int kq, int nch) {
 
 // workgroups per sample for a decoder step (the caller sizes nothing by it: every chunk of a sample writes its own rows / columns)
 int attn_step_nch(int B, int L, int A, int Dm, int ksz, int kq) {
-    for (int nch = 1; nch <= 2; ++nch)
+    static const int nch0 = [] { const char* e = getenv("MTTS_ATTN_BIG_NCH"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > 2 ? 2 : v); }();      // A/B switch
+    for (int nch = nch0; nch <= 2; ++nch)
         if (att_big_ok(B, L, A, Dm, ksz, kq, nch)) return nch;          // large batch: one (two) 1024-thread workgroup(s) per sample
     int nch = (Dm + 511) / 512;
     if (nch < 4 && B * 4 <= 1024) nch = 4;                              // small batch: four workgroups per sample fill the chip

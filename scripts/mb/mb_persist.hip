@@ -2,7 +2,7 @@
 //   * correctness: a short decode against a host (double precision) LSTM on the same random weights;
 //   * timing: T steps, HIP-event time per step, and (PS_PROF builds) the in-kernel timeline of workgroup 0.
 //   python scripts/mb/instrument.py apply   (csrc/persist.hip + instrumentation/persist.hip.patch -> gen/persist.hip: the stage clocks live in the patch)
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -DPS_PROF=1024 [-DMB_PGEN4] -I ../../multilingual_text_to_speech_amd/csrc -I ../../include -o mb_persist mb_persist.hip && ./mb_persist [B] [T]
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -DPS_PROF=1024 -I ../../multilingual_text_to_speech_amd/csrc -I ../../include -o mb_persist mb_persist.hip && ./mb_persist [B] [T]
 #include "gen/persist.hip"
 #include <cmath>
 #include <cstdio>
@@ -11,28 +11,6 @@
 #include <stdarg.h>
 #include <vector>
 
-#ifdef MB_PGEN4
-#include "pgen4_variant.inc"
-// launch of the variant kernel with pgen_launch's argument marshalling (fp32, no zoneout)
-static int pgen4_launch(const DecoderArgs& a, int t0, int t1, hipStream_t s) {
-    PsGen p; memset(&p, 0, sizeof(p));
-    p.B = a.B; p.H = a.H; p.t0 = t0; p.t1 = t1;
-    p.w_packed = (const float*)a.gen_w2p; p.bias_u = a.gen_bias_u; p.pre = a.pre_gen;
-    p.h = a.h_gen; p.c = a.c_gen; p.gates = a.gates_gen;
-    if (a.training && a.gen_hmask && a.p_hidden > 0.f) { p.hmask = a.gen_hmask; p.cell.hscale = 1.f / (1.f - a.p_hidden); }
-    char* ws = (char*)a.persist_ws;
-    p.sync.cnt = (unsigned*)ws; p.sync.err = (unsigned*)(ws + PS_ERR_OFF);
-    p.xp = (float*)(ws + ps_ws_gen_off());
-    p.prof = g_ps_prof;
-    (void)hipMemsetAsync(ws, 0, PS_ERR_OFF, s);
-    const int RT = (a.B + 15) / 16;
-    const size_t lds4 = (size_t)RT * 8 * 256 * 4 + 64 + PS_PROF_WORDS * 4;
-#define PGEN4_GO(G) hipLaunchKernelGGL((pgen4_kernel<G>), dim3(PS_WGS), dim3(PS4_THREADS), lds4, s, p);
-    if (RT == 1) PGEN4_GO(1) else if (RT == 2) PGEN4_GO(2) else if (RT == 3) PGEN4_GO(3) else PGEN4_GO(4)
-#undef PGEN4_GO
-    return hipGetLastError() == hipSuccess ? 0 : 1;
-}
-#endif
 
 thread_local char g_mtts_err[512] = {0};
 int mtts_fail(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(g_mtts_err, sizeof(g_mtts_err), fmt, ap); va_end(ap); return 1; }
@@ -108,26 +86,6 @@ int main(int argc, char** argv) {
         printf("pgen B=%d: max |h, c - host double| over %d steps = %.3e  %s\n", B, Tc, worst, worst < 2e-5 ? "OK" : "MISMATCH");
     }
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-#ifdef MB_PGEN4
-    {   // the fp32-exchange form (pgen7, the product) must reproduce the bf16-plane form (pgen4_variant.inc) bit for bit
-        const int Tq = T < 60 ? T : 60;
-        std::vector<float> ref_h, ref_c, ref_g;
-        for (int pass = 0; pass < 2; ++pass) {
-            (void)hipMemset(a.h_gen, 0, (size_t)(T + 1) * B * H * 4); (void)hipMemset(a.c_gen, 0, (size_t)(T + 1) * B * H * 4); (void)hipMemset(a.gates_gen, 0, (size_t)T * B * 4 * H * 4);
-            if (pass == 0 ? pgen4_launch(a, 0, Tq, 0) : pgen_launch(a, 0, Tq, 0)) { printf("pgen launch failed: %s\n", g_mtts_err); return 1; }
-            (void)hipDeviceSynchronize();
-            std::vector<float> hh((size_t)(Tq + 1) * B * H), cc((size_t)(Tq + 1) * B * H), gg((size_t)Tq * B * 4 * H);
-            (void)hipMemcpy(hh.data(), a.h_gen, hh.size() * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(cc.data(), a.c_gen, cc.size() * 4, hipMemcpyDeviceToHost);
-            (void)hipMemcpy(gg.data(), a.gates_gen, gg.size() * 4, hipMemcpyDeviceToHost);
-            printf("pgen%d correctness run: status %d\n", pass ? 7 : 4, mtts_decoder_persist_status(a.persist_ws, 0));
-            if (pass == 0) { ref_h = hh; ref_c = cc; ref_g = gg; continue; }
-            size_t bad = 0;
-            for (size_t k = 0; k < hh.size(); ++k) bad += memcmp(&hh[k], &ref_h[k], 4) != 0 || memcmp(&cc[k], &ref_c[k], 4) != 0;
-            for (size_t k = 0; k < gg.size(); ++k) bad += memcmp(&gg[k], &ref_g[k], 4) != 0;
-            printf("  pgen7 vs pgen4 over %d steps (h, c, gates): %zu values differ  %s\n", Tq, bad, bad ? "MISMATCH" : "OK");
-        }
-    }
-#endif
     for (int rep = 0; rep < 3; ++rep) {
         (void)hipEventRecord(e0, 0);
         if (pgen_launch(a, 0, T, 0)) { printf("pgen_launch failed: %s\n", g_mtts_err); return 1; }
