@@ -128,8 +128,9 @@ typedef struct SkSeg {
     int K;
     int ldx;
     int ldw;
-    int xpack;             /* != 0: x is in the MFMA tile order written by the producer kernels (see mtts_pack_rows) */
-    int wpack;             /* != 0: w is in the MFMA tile order produced by mtts_pack_weight */
+    int xpack;             /* 1: x is in the MFMA tile order written by the producer kernels (see mtts_pack_rows); 2: bf16 pair tiles
+                              (SkinnyArgs.dg_pack_bf16 / mtts_pack_weight_bf16; plain products only, every operand of the launch, K % 32 == 0) */
+    int wpack;             /* 1: w is in the MFMA tile order produced by mtts_pack_weight; 2: bf16 pair tiles (mtts_pack_weight_bf16) */
 } SkSeg;
 
 typedef struct SkinnyArgs {
@@ -186,6 +187,8 @@ typedef struct SkinnyArgs {
     float* dh_carry_out;   /* [B,H] or NULL */
     float* h_pack_out;     /* lstm == 1: additional copy of h_out in MFMA tile order (K = H) or NULL */
     float* dg_pack_out;    /* lstm == 2: additional copy of the gate gradients in MFMA tile order (K = 4H) or NULL */
+    int dg_pack_bf16;      /* != 0: dg_pack_out receives bf16 pair tiles ([row tile][4H / 32][64 lanes][8 bf16], RNE) instead of fp32 tiles:
+                              the x operand of the bf16 path's per-step input-gradient products (round 5) */
 } SkinnyArgs;
 
 int mtts_skinny_gemm(const SkinnyArgs* args, void* stream);
@@ -196,6 +199,10 @@ int mtts_skinny_gemm(const SkinnyArgs* args, void* stream);
  * mtts_pack_rows: rows are batch rows (padded with zeros to a multiple of 16). */
 int mtts_pack_weight(const float* src, int ld, int N, int K, int lstm_H, float* dst, void* stream);
 int mtts_pack_rows(const float* src, int ld, int rows, int K, float* dst, void* stream);
+/* bf16 pair tiles of a weight matrix (rows = weight rows, K % 32 == 0): [tiles of 16 rows][K / 32][64 lanes][16 B]; lane 16q + i holds
+ * columns 32c + 4q .. + 3 and 32c + 16 + 4q .. + 3 of row 16 tile + i, RNE-rounded: the w operand (wpack == 2) of the per-step
+ * input-gradient products in bf16 mode - two v_mfma_f32_16x16x16_bf16 per tile.  dst: N16 * K * 2 bytes (N16 = rows rounded up to 16). */
+int mtts_pack_weight_bf16(const float* src, int ld, int N, int K, void* dst, void* stream);
 
 /* ---- recurrent LSTM step without operand re-reads: K-split gate GEMM + (partial sum, cell, query partials) --------------
  * Replaces torch.nn.LSTMCell + dropout / zoneout (modules/layers.py:18-47, call site modules/tacotron2.py:185) and the

@@ -227,8 +227,18 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
     MTTS_TRY(transpose2d(a.att_w_hh, g.att_w_rec_T + (long)Dm * 4 * H, 4 * H, H, s));
     MTTS_TRY(transpose2d(a.gen_w_hh, g.gen_w_hh_T, 4 * H, H, s));
     MTTS_TRY(transpose2d(a.w_query, g.w_query_T, A, H, s));
-    if (g.att_w_rec_Tp) MTTS_TRY(mtts_pack_weight(g.att_w_rec_T, 4 * H, Dm + H, 4 * H, 0, g.att_w_rec_Tp, s));
-    if (g.gen_w_hh_Tp) MTTS_TRY(mtts_pack_weight(g.gen_w_hh_T, 4 * H, H, 4 * H, 0, g.gen_w_hh_Tp, s));
+    // bf16 mode (round 5): the per-step input-gradient products dG W^T of both chains run on bf16 MFMA - transposed recurrent weights
+    // and the cell backward's packed copy of dG as RNE-rounded bf16 pair tiles (skinny_body.h, PK = 3): half the 42 MB of weights the
+    // three products re-stream per step, 1/4 of their MFMA issue; fp32 accumulation, the cell / attention backward stay fp32
+    const bool bfp = a.precision == 1 && g.dG_att_p && g.dG_gen_p && g.att_w_rec_Tp && g.gen_w_hh_Tp && (Dm & 15) == 0 && (H & 7) == 0;
+    const int pkv = bfp ? 2 : 1;
+    if (bfp) {
+        MTTS_TRY(mtts_pack_weight_bf16(g.att_w_rec_T, 4 * H, Dm + H, 4 * H, g.att_w_rec_Tp, s));
+        MTTS_TRY(mtts_pack_weight_bf16(g.gen_w_hh_T, 4 * H, H, 4 * H, g.gen_w_hh_Tp, s));
+    } else {
+        if (g.att_w_rec_Tp) MTTS_TRY(mtts_pack_weight(g.att_w_rec_T, 4 * H, Dm + H, 4 * H, 0, g.att_w_rec_Tp, s));
+        if (g.gen_w_hh_Tp) MTTS_TRY(mtts_pack_weight(g.gen_w_hh_T, 4 * H, H, 4 * H, 0, g.gen_w_hh_Tp, s));
+    }
     const long Bp4H = (long)((B + 15) & ~15) * 4 * H;
     const float* dout1 = g.dout + (long)B * Mo;      // slot 1 = step 0
     // ---- projection backward (batched): dHG = dout W_out[:, :H],  dctx_all[1:] = dout W_out[:, H:]
@@ -292,14 +302,15 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
             if (a.zone) { k.dh_b = g.dh_carry_gen + ((t + 1) & 1) * BH; k.dh_carry_out = g.dh_carry_gen + (t & 1) * BH; }
             k.dgates_out = g.dG_gen + t * B4H; k.ld_dgates = 4 * H;
             k.dg_pack_out = g.dG_gen_p ? g.dG_gen_p + t * Bp4H : nullptr;
+            k.dg_pack_bf16 = bfp ? 1 : 0;
             bwd_reg(a, k, a.gen_hmask, a.gen_cmask, t);
             MTTS_TRY(skinny_launch(k, sb));
             if (t > 0) {
                 SkinnyArgs q; memset(&q, 0, sizeof(q));
                 q.nseg = 1; q.B = B; q.N = H; q.ksplit = ksb;
                 q.seg[0] = SkSeg{g.dG_gen + t * B4H, g.gen_w_hh_T, 4 * H, 4 * H, 4 * H, 0, 0};
-                if (g.dG_gen_p) { q.seg[0].x = g.dG_gen_p + t * Bp4H; q.seg[0].xpack = 1; }
-                if (g.gen_w_hh_Tp) { q.seg[0].w = g.gen_w_hh_Tp; q.seg[0].wpack = 1; }
+                if (g.dG_gen_p) { q.seg[0].x = g.dG_gen_p + t * Bp4H; q.seg[0].xpack = pkv; }
+                if (g.gen_w_hh_Tp) { q.seg[0].w = g.gen_w_hh_Tp; q.seg[0].wpack = pkv; }
                 q.out = g.part_gen; q.ldo = H; q.out_ks = BH;
                 MTTS_TRY(skinny_launch(q, sb));
             }
@@ -333,8 +344,8 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
     const int cb_ctx = Dm >> 4;                                 // packed tiles of the ctx rows of [W_ih[:, P:] | W_hh]^T
     auto gemm_seg = [&](int t, bool h_part) {
         SkSeg sg = SkSeg{g.dG_att + t * B4H, g.att_w_rec_T + (h_part ? (long)Dm * 4 * H : 0), 4 * H, 4 * H, 4 * H, 0, 0};
-        if (g.dG_att_p) { sg.x = g.dG_att_p + t * Bp4H; sg.xpack = 1; }
-        if (g.att_w_rec_Tp && (Dm & 15) == 0) { sg.w = g.att_w_rec_Tp + (h_part ? (long)cb_ctx * (4 * H / 16) * 256 : 0); sg.wpack = 1; }
+        if (g.dG_att_p) { sg.x = g.dG_att_p + t * Bp4H; sg.xpack = pkv; }
+        if (g.att_w_rec_Tp && (Dm & 15) == 0) { sg.w = g.att_w_rec_Tp + (h_part ? (long)cb_ctx * (4 * H / (bfp ? 32 : 16)) * 256 : 0); sg.wpack = pkv; }
         return sg;
     };
     auto submit_A = [&](int c) -> int {
@@ -373,6 +384,7 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
                 if (a.zone) { k.dh_b = g.dh_carry_att + ((t + 1) & 1) * BH; k.dh_carry_out = g.dh_carry_att + (t & 1) * BH; }
                 k.dgates_out = g.dG_att + t * B4H; k.ld_dgates = 4 * H;
                 k.dg_pack_out = g.dG_att_p ? g.dG_att_p + t * Bp4H : nullptr;
+                k.dg_pack_bf16 = bfp ? 1 : 0;
                 bwd_reg(a, k, a.att_hmask, a.att_cmask, t);
                 MTTS_TRY(skinny_launch(k, s));
             }

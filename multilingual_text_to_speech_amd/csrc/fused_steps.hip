@@ -38,7 +38,8 @@ int attn_bwd_plus_skinny(const AttnBwdArgs& a, const SkinnyArgs& k, hipStream_t 
     const size_t lds_sk = sizeof(float) * NW * 64 * 17;
     if (lds_sk > lds) lds = lds_sk;
     const dim3 grid(n_attn + cbs * q.ksplit);
-    if (q.seg[0].xpack && q.seg[0].wpack) hipLaunchKernelGGL(attn_bwd_plus_skinny_kernel<1>, grid, dim3(NT), lds, s, a, q, n_attn, cbs);
+    if (q.seg[0].xpack == 2 && q.seg[0].wpack == 2) hipLaunchKernelGGL(attn_bwd_plus_skinny_kernel<3>, grid, dim3(NT), lds, s, a, q, n_attn, cbs);
+    else if (q.seg[0].xpack && q.seg[0].wpack) hipLaunchKernelGGL(attn_bwd_plus_skinny_kernel<1>, grid, dim3(NT), lds, s, a, q, n_attn, cbs);
     else if (!q.seg[0].xpack && !q.seg[0].wpack) hipLaunchKernelGGL(attn_bwd_plus_skinny_kernel<2>, grid, dim3(NT), lds, s, a, q, n_attn, cbs);
     else hipLaunchKernelGGL(attn_bwd_plus_skinny_kernel<0>, grid, dim3(NT), lds, s, a, q, n_attn, cbs);
     MTTS_CHECK_LAUNCH("attn_bwd_plus_skinny_kernel");

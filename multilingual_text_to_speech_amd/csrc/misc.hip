@@ -220,6 +220,40 @@ MTTS_API int mtts_pack_weight(const float* src, int ld, int N, int K, int lstm_H
     return 0;
 }
 
+// bf16 tile order of the per-step backward products in bf16 mode (skinny_body.h, PK = 3): [tiles][K/32][64 lanes][16 B]; lane 16q+i
+// holds, RNE-rounded, columns 32c + 4q .. + 3 (low 8 bytes: the operand of the first v_mfma_f32_16x16x16_bf16 of the pair) and
+// 32c + 16 + 4q .. + 3 (high 8 bytes: the second) of row 16 tile + i.
+__device__ __forceinline__ unsigned pw_bf16_rne(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__global__ void pack_weight_bf16_kernel(const float* __restrict__ src, uint4* __restrict__ dst, int ld, int N, int K, int ntile) {
+    const int nc = K >> 5;
+    const long total = (long)ntile * nc * 64;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        const long tc = i >> 6;
+        const int c = (int)(tc % nc), cb = (int)(tc / nc);
+        const int j = lane & 15, q = lane >> 4, row = cb * 16 + j;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (row < N) {
+            const float* sp = src + (long)row * ld + c * 32 + 4 * q;
+            v.x = pw_bf16_rne(sp[0]) | (pw_bf16_rne(sp[1]) << 16); v.y = pw_bf16_rne(sp[2]) | (pw_bf16_rne(sp[3]) << 16);
+            v.z = pw_bf16_rne(sp[16]) | (pw_bf16_rne(sp[17]) << 16); v.w = pw_bf16_rne(sp[18]) | (pw_bf16_rne(sp[19]) << 16);
+        }
+        dst[i] = v;
+    }
+}
+
+MTTS_API int mtts_pack_weight_bf16(const float* src, int ld, int N, int K, void* dst, void* stream) {
+    MTTS_REQUIRE((K & 31) == 0, "mtts_pack_weight_bf16: K = %d must be a multiple of 32", K);
+    const int ntile = cdiv(N, 16);
+    hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(nblocks((long)ntile * (K >> 5) * 64)), dim3(256), 0, (hipStream_t)stream, src,
+                       (uint4*)dst, ld, N, K, ntile);
+    MTTS_CHECK_LAUNCH("pack_weight_bf16");
+    return 0;
+}
+
 MTTS_API int mtts_pack_rows(const float* src, int ld, int rows, int K, float* dst, void* stream) {
     MTTS_REQUIRE((K & 15) == 0, "mtts_pack_rows: K = %d must be a multiple of 16", K);
     const int ntile = cdiv(rows, 16);

@@ -116,9 +116,16 @@ int skinny_launch(const SkinnyArgs& p, hipStream_t s) {
         all_p = all_p && p.seg[i].xpack && p.seg[i].wpack;
         none_p = none_p && !p.seg[i].xpack && !p.seg[i].wpack;
     }
-    const int pk = all_p ? 1 : none_p ? 2 : 0;
+    bool all_b = p.nseg > 0;      // every operand in bf16 pair tiles (xpack == wpack == 2): plain products of the bf16 path's backward
+    for (int i = 0; i < p.nseg; ++i) all_b = all_b && p.seg[i].xpack == 2 && p.seg[i].wpack == 2;
+    for (int i = 0; i < p.nseg; ++i)
+        MTTS_REQUIRE(all_b || (p.seg[i].xpack != 2 && p.seg[i].wpack != 2), "skinny: bf16 pair tiles (pack == 2) must be used by every operand of a launch");
+    MTTS_REQUIRE(!all_b || p.lstm == 0, "skinny: bf16 pair tiles are for plain products");
+    for (int i = 0; all_b && i < p.nseg; ++i) MTTS_REQUIRE((p.seg[i].K & 31) == 0, "skinny: bf16 pair tiles need K %% 32 == 0 (K=%d)", p.seg[i].K);
+    const int pk = all_b ? 3 : all_p ? 1 : none_p ? 2 : 0;
 #define SK_LAUNCH(KERNEL, MT_, GRID) do { \
-        if (pk == 1) hipLaunchKernelGGL((KERNEL<MT_, 1>), GRID, dim3(NT), 0, s, q); \
+        if (pk == 3) hipLaunchKernelGGL((KERNEL<MT_, 3>), GRID, dim3(NT), 0, s, q); \
+        else if (pk == 1) hipLaunchKernelGGL((KERNEL<MT_, 1>), GRID, dim3(NT), 0, s, q); \
         else if (pk == 2) hipLaunchKernelGGL((KERNEL<MT_, 2>), GRID, dim3(NT), 0, s, q); \
         else hipLaunchKernelGGL((KERNEL<MT_, 0>), GRID, dim3(NT), 0, s, q); } while (0)
     // LSTM cell backward (K <= the query width): the launch is all epilogue operands (16 loads per (row, unit)); one 16-row tile per

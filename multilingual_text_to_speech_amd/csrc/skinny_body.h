@@ -67,7 +67,7 @@ __device__ __forceinline__ void sk_load(const SegTab t, int c, const int (&rows)
     const int nc = in0 ? t.n0 : (in1 ? t.n1 : t.n2);
     const int cs = in0 ? cc : (in1 ? cc - t.n0 : cc - t.n0 - t.n1);      // chunk within its segment
     const float* zp = g_sk_zero + lane * 4;
-    if (PK == 1) {       // 1 KiB contiguous tiles, already in MFMA operand order
+    if (PK == 1 || PK == 3) {       // 1 KiB contiguous tiles, already in MFMA operand order (PK 3: bf16 pairs of 16-k chunks, see sk_mma)
         f.xp = true; f.wp = true;
         const float* wa = sw + (((long)t.cb * nc + cs) * 64 + lane) * 4;
         f.w = *reinterpret_cast<const float4*>(live ? wa : zp);
@@ -110,8 +110,27 @@ __device__ __forceinline__ float4 to_mfma_layout(const float4 v, int src_lane) {
     return make_float4(__shfl(v.x, src_lane, 64), __shfl(v.y, src_lane, 64), __shfl(v.z, src_lane, 64), __shfl(v.w, src_lane, 64));
 }
 
+// PK = 3 (bf16 mode of the per-step backward products, round 5): a tile is a PAIR of 16-k chunks, 4 bf16 each per lane (the fp32 tile's
+// lane <-> (row, k quad) map, so the producers change only their store): two v_mfma_f32_16x16x16_bf16 per tile instead of eight
+// v_mfma_f32_16x16x4_f32 at 1/16 of their rate, half the operand bytes.  Operands RNE-rounded by their producers
+// (mtts_pack_weight_bf16, the cell backward's dg_pack_out with dg_pack_bf16), fp32 accumulation.
+typedef __attribute__((ext_vector_type(4))) short sk_s16x4;
+__device__ __forceinline__ sk_s16x4 sk_bf16_half(float lo, float hi) {
+    const uint2 u = make_uint2(__float_as_uint(lo), __float_as_uint(hi));
+    sk_s16x4 r; __builtin_memcpy(&r, &u, 8);
+    return r;
+}
 template <int MT, int PK>
 __device__ __forceinline__ void sk_mma(const Frag<MT>& f, f32x4 (&acc)[MT], int src_lane) {
+    if (PK == 3) {
+        const sk_s16x4 w0 = sk_bf16_half(f.w.x, f.w.y), w1 = sk_bf16_half(f.w.z, f.w.w);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(sk_bf16_half(f.x[m].x, f.x[m].y), w0, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(sk_bf16_half(f.x[m].z, f.x[m].w), w1, acc[m], 0, 0, 0);
+        }
+        return;
+    }
     const float4 w4 = (PK == 1 || (PK == 0 && f.wp)) ? f.w : to_mfma_layout(f.w, src_lane);
     const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
@@ -253,7 +272,17 @@ __device__ __forceinline__ void bwd_cell(const SkinnyArgs& p, const float (&red)
     float* dg = p.dgates_out + (long)row * p.ld_dgates + u;
     const float dgv[4] = {dct * gg * ig * (1.f - ig), dct * cp * fg * (1.f - fg), dct * ig * (1.f - gg * gg), d_o * og * (1.f - og)};
     dg[0] = dgv[0]; dg[p.H] = dgv[1]; dg[2 * p.H] = dgv[2]; dg[3 * p.H] = dgv[3];
-    if (p.dg_pack_out) {
+    if (p.dg_pack_out && p.dg_pack_bf16) {      // bf16 pair tiles (PK = 3 consumers): [row tile][4H / 32][64 lanes][8 bf16], RNE
+        unsigned short* dp = reinterpret_cast<unsigned short*>(p.dg_pack_out);
+        const long tile = (long)(row >> 4) * (p.H >> 3);           // 4H / 32 chunk pairs per row tile
+        const int lane_e = (4 * (u & 12) + (row & 15)) * 8 + (u & 3);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int j = g * p.H + u;
+            const unsigned b = __float_as_uint(dgv[g]);
+            dp[(tile + (j >> 5)) * 512 + lane_e + ((j >> 4) & 1) * 4] = (unsigned short)((b + 0x7fffu + ((b >> 16) & 1u)) >> 16);
+        }
+    } else if (p.dg_pack_out) {
         const long tile = (long)(row >> 4) * (p.H >> 2);           // 4H / 16 chunks per row tile
         const int lane_s = (4 * (u & 12) + (row & 15)) * 4 + (u & 3);
 #pragma unroll
@@ -317,9 +346,10 @@ __device__ __forceinline__ void skinny_body(const SkinnyArgs& p, float (&red)[NW
     t.wp0 = p.seg[0].wpack; t.wp1 = p.seg[1].wpack; t.wp2 = p.seg[2].wpack;
     t.cb = cb; t.mt0 = row_tile * MT; t.mt_last = ((p.B + 15) >> 4) - 1;
     const int nseg = p.nseg;
-    t.n0 = (t.K0 + 15) >> 4;
-    t.n1 = nseg > 1 ? (t.K1 + 15) >> 4 : 0;
-    t.n2 = nseg > 2 ? (t.K2 + 15) >> 4 : 0;
+    constexpr int CSH = PK == 3 ? 5 : 4, CRND = PK == 3 ? 31 : 15;      // k per chunk: 16, or 32 for the bf16 pair tiles
+    t.n0 = (t.K0 + CRND) >> CSH;
+    t.n1 = nseg > 1 ? (t.K1 + CRND) >> CSH : 0;
+    t.n2 = nseg > 2 ? (t.K2 + CRND) >> CSH : 0;
     t.total = t.n0 + t.n1 + t.n2;
     const int total = t.total;
 

@@ -44,7 +44,8 @@ def _r(x, site):
 
 
 # Backward of the bf16-operand mode.  The product's BATCHED backward GEMMs round their operands as well (dY, and the W / X they multiply it
-# with); its per-step recurrence products (decoder LSTM input gradients, attention) stay fp32.  `BF16_BWD_SITES` lists the sites whose
+# with); since round 5 so do the per-step input-gradient products of the decoder LSTMs in the all-teacher-forced schedule (the tests
+# then list 'lstm' in BF16_BWD_SITES); the attention backward and the general schedule's per-step products stay fp32.  `BF16_BWD_SITES` lists the sites whose
 # input AND weight gradient come from rounded operands; for the sites in `BF16_BWD_WGRAD_ONLY` (the decoder LSTMs: weight gradients are
 # batched GEMMs, input gradients per-step fp32 products) only the weight gradient does.  Empty (default): plain autograd through the
 # forward rounding (straight-through).  Test infrastructure only, like everything in this file.

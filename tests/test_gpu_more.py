@@ -210,9 +210,13 @@ def run_train_step_case(preset, B, L, T, over, check_grads=True, ragged=None, te
             om[k] = mult(v, hp.dropout).permute(0, 2, 1)
     torch.set_flush_denormal(True)               # CPU speed only: identical output (SURVEY 8c recipe 5)
     O.BF16_SITES = BF16_ORACLE_SITES if bf16 else frozenset()      # bf16 path: the oracle rounds the same contraction operands
-    if bf16 and check_grads:      # ... and its backward rounds what the product's batched backward GEMMs round (see oracle._RoundedLinear)
-        O.BF16_BWD_SITES = BF16_ORACLE_SITES - {'lstm', 'loc'}
-        O.BF16_BWD_WGRAD_ONLY = frozenset({'lstm'})
+    if bf16 and check_grads:      # ... and its backward rounds what the product's backward rounds (see oracle._RoundedLinear): the batched
+        # GEMMs and - since round 5 - the per-step input-gradient products dG W^T of both decoder LSTMs (bf16 pair tiles, skinny_body.h
+        # PK = 3: dG and the transposed recurrent weights RNE-rounded, fp32 accumulation).  A mixed-teacher-forcing step keeps fp32
+        # per-step products (general schedule): there only the weight gradients of the LSTMs round.
+        fast = all(teacher)
+        O.BF16_BWD_SITES = BF16_ORACLE_SITES - ({'loc'} if fast else {'lstm', 'loc'})
+        O.BF16_BWD_WGRAD_ONLY = frozenset() if fast else frozenset({'lstm'})
     spread64 = None
     try:
         with torch.set_grad_enabled(check_grads):
