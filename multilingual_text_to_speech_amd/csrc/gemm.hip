@@ -956,6 +956,14 @@ MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
             while (S > 1 && (size_t)S * p.batch * p.zt * p.M * p.N * sizeof(float) > region_bytes) --S;
             if (S < 1) S = 1;
         }
+        // bf16 GEMMs on the pre-split core: a K step is 96 wide and four times faster, so the split's partial slabs and its reduction
+        // launch (20 us for a 4096 x 1568 weight gradient) cost more than the second half-round of workgroups they fill
+        static const int planes_split = [] { const char* e = getenv("MTTS_PLANES_SPLITK"); return e ? atoi(e) : 0; }();
+        static const int nosplit_tiles = [] { const char* e = getenv("MTTS_PLANES_NOSPLIT_TILES"); return e ? atoi(e) : 128; }();
+        // fp32 GEMMs (one pipelined workgroup per CU): a split only pays when the tiles do not fill the chip once (experiment switch)
+        static const int pipe_nosplit_tiles = [] { const char* e = getenv("MTTS_PIPE_NOSPLIT_TILES"); return e ? atoi(e) : 0; }();
+        if (S > 1 && pipe_nosplit_tiles > 0 && p.precision != 1 && tiles >= pipe_nosplit_tiles) S = 1;
+        if (S > 1 && !planes_split && p.precision == 1 && tiles >= nosplit_tiles && planes_wanted(p, true)) S = 1;
     }
     dim3 grid(ntx * nty, S, p.batch * p.zt);
     // side-stream launches (nosplit) ask for > half of the CU's LDS so that only ONE GEMM workgroup sits on a CU and the
