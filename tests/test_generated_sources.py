@@ -54,3 +54,34 @@ def test_product_kernel_sources_carry_no_harness_instrumentation():
             assert not hits, (f, hits[:3])
     r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'mb', 'instrument.py'), 'apply'], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_gemm_tile_order_is_a_bijection_for_every_grid():
+    """gemm_tile_block (csrc/gemm.hip): linear tile index -> (tile row, tile column) in column strips of four tiles.  The device function
+    is restated here line by line; for every grid shape up to 40 x 40 each tile must be produced exactly once, and 32 consecutive
+    indices of a full strip must cover 8 x 4 tiles (what an XCD's workgroups share in L2)."""
+    import os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, 'multilingual_text_to_speech_amd', 'csrc', 'gemm.hip')).read()
+    body = src[src.index('void gemm_tile_block('):]
+    body = body[:body.index('\n}\n')]
+    # the restatement below mirrors these statements; if the device code changes, change both
+    for stmt in ('constexpr int W = 4;', 'const int nfull = ntx / W, per_strip = W * nty;', 'int strip = id / per_strip, rem = id - strip * per_strip, w = W;',
+                 'if (strip >= nfull) { strip = nfull; rem = id - nfull * per_strip; w = ntx - W * nfull; }', 'tile_m = rem / w;',
+                 'tile_n = strip * W + (rem - tile_m * w);'):
+        assert stmt in body, stmt
+
+    def tile(id_, ntx, nty, W=4):
+        nfull, per_strip = ntx // W, W * nty
+        strip, rem, w = id_ // per_strip, id_ % per_strip, W
+        if strip >= nfull:
+            strip, rem, w = nfull, id_ - nfull * per_strip, ntx - W * nfull
+        tm = rem // w
+        return tm, strip * W + (rem - tm * w)
+
+    for ntx in range(1, 41):
+        for nty in range(1, 41):
+            seen = {tile(i, ntx, nty) for i in range(ntx * nty)}
+            assert len(seen) == ntx * nty and all(0 <= m < nty and 0 <= n < ntx for m, n in seen), (ntx, nty)
+    block = {tile(i, 32, 300) for i in range(64, 96)}
+    assert len({m for m, _ in block}) == 8 and len({n for _, n in block}) == 4
