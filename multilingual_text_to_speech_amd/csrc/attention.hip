@@ -580,8 +580,8 @@ static bool att_big_ok(int B, int L, int A, int Dm, int ksz, int kq, int nch) {
 
 // workgroups per sample for a decoder step (the caller sizes nothing by it: every chunk of a sample writes its own rows / columns)
 int attn_step_nch(int B, int L, int A, int Dm, int ksz, int kq) {
-    static const int nch0 = [] { const char* e = getenv("MTTS_ATTN_BIG_NCH"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > 2 ? 2 : v); }();      // A/B switch
-    for (int nch = nch0; nch <= 2; ++nch)
+    // (two workgroups per sample where one fits were measured at batch 240: 86.5 -> 93.9 us per step fp32, 55.7 -> 66.0 bf16 - profiles/r05_attn_big_nch.txt)
+    for (int nch = 1; nch <= 2; ++nch)
         if (att_big_ok(B, L, A, Dm, ksz, kq, nch)) return nch;          // large batch: one (two) 1024-thread workgroup(s) per sample
     int nch = (Dm + 511) / 512;
     if (nch < 4 && B * 4 <= 1024) nch = 4;                              // small batch: four workgroups per sample fill the chip

@@ -960,9 +960,8 @@ MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
         // launch (20 us for a 4096 x 1568 weight gradient) cost more than the second half-round of workgroups they fill
         static const int planes_split = [] { const char* e = getenv("MTTS_PLANES_SPLITK"); return e ? atoi(e) : 0; }();
         static const int nosplit_tiles = [] { const char* e = getenv("MTTS_PLANES_NOSPLIT_TILES"); return e ? atoi(e) : 128; }();
-        // fp32 GEMMs (one pipelined workgroup per CU): a split only pays when the tiles do not fill the chip once (experiment switch)
-        static const int pipe_nosplit_tiles = [] { const char* e = getenv("MTTS_PIPE_NOSPLIT_TILES"); return e ? atoi(e) : 0; }();
-        if (S > 1 && pipe_nosplit_tiles > 0 && p.precision != 1 && tiles >= pipe_nosplit_tiles) S = 1;
+        // (the same rule for the fp32 cores was measured and not kept: 4096 x 1024 x 3072 0.166 -> 0.138 ms per call, but 4096 x 1536 x 38400
+        //  2.73 -> 3.04 and no change of the train step: profiles/r05_gemm_core.txt)
         if (S > 1 && !planes_split && p.precision == 1 && tiles >= nosplit_tiles && planes_wanted(p, true)) S = 1;
     }
     dim3 grid(ntx * nty, S, p.batch * p.zt);
