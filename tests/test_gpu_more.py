@@ -825,3 +825,35 @@ def test_fused_adam_two_groups_mixed_steps_match_torch():
     for a, b in zip(p1, p2):
         assert float(o1.state[a]['step']) == float(o2.state[b]['step'])
         assert (o1.state[a]['exp_avg_sq'] - o2.state[b]['exp_avg_sq']).abs().max().item() <= 1e-7
+
+
+def test_fused_adam_skips_a_non_finite_step_and_reports_it():
+    """Guarded optimizer step (csrc/loss_optim.hip, AdamArgs.guard): a non-finite gradient norm leaves weights and moments untouched on
+    the device; FusedAdam.poll_skipped() surfaces it one poll later without stalling the stream (round 5) - the reference's
+    clip_grad_norm_ + Adam (train.py:84-85) would have written NaNs into every weight."""
+    import warnings
+    from multilingual_text_to_speech_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    w = [torch.nn.Parameter(torch.randn(300, 17, device='cuda')), torch.nn.Parameter(torch.randn(1000, device='cuda'))]
+    opt = FusedAdam(w, lr=1e-2)
+    for p in w:
+        p.grad = torch.randn_like(p)
+    opt.step(max_norm=0.25)
+    assert opt.poll_skipped() == 0
+    before = [p.detach().clone() for p in w]
+    w[1].grad[123] = float('inf')
+    opt.step(max_norm=0.25)
+    torch.cuda.synchronize()
+    for p, b in zip(w, before):
+        assert torch.equal(p.detach(), b)                     # the update was skipped on the device
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter('always')
+        opt.poll_skipped()                                     # enqueues the copy of [norm, coefficient] of the skipped step
+        torch.cuda.synchronize()
+        n = opt.poll_skipped()                                 # accounts for it
+    assert n == 1 and any('skipped' in str(c.message) for c in caught)
+    for p in w:
+        p.grad = torch.randn_like(p)
+    opt.step(max_norm=0.25)
+    torch.cuda.synchronize()
+    assert not torch.equal(w[0].detach(), before[0])          # a finite step updates again
