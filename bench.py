@@ -325,7 +325,7 @@ def traffic_probe(args):
     presets.apply(args.preset, speaker_number=91)
     torch.manual_seed(0)
     model = Tacotron().to(device).train()
-    B, L = args.batch, L_CHARS
+    B, L = args.batch, args.chars
     lib = _C.lib()
     with torch.no_grad():
         batches = {T: synthetic_batch(hp, B, L, T, device) for T in TRAFFIC_T}
@@ -344,7 +344,7 @@ def traffic_probe(args):
         torch.cuda.synchronize()
 
 
-def measure_traffic(preset, B, dtype='f32', timeout=240):
+def measure_traffic(preset, B, dtype='f32', timeout=240, chars=L_CHARS):
     """HBM bytes per forward decoder step from two rocprofv3 PMC passes over a child process (FETCH_SIZE, WRITE_SIZE; both
     in KB; gfx950: FETCH_SIZE counts 64 B per 128-B request of wide coalesced reads -> x2, MI355X_MICROARCH.md HBM section).
     Per step = (bytes of the long decode - bytes of the short one) / (difference of frame counts)."""
@@ -360,7 +360,7 @@ def measure_traffic(preset, B, dtype='f32', timeout=240):
         d = tempfile.mkdtemp(prefix='mtts_pmc_', dir='/tmp')
         try:
             cmd = ['rocprofv3', '--kernel-trace', '--pmc', counter, '-d', d, '-o', 'p', '--output-format', 'csv', '--',
-                   sys.executable, os.path.abspath(__file__), '--traffic-probe', '--preset', preset, '--batch', str(B), '--dtype', dtype]
+                   sys.executable, os.path.abspath(__file__), '--traffic-probe', '--preset', preset, '--batch', str(B), '--dtype', dtype, '--chars', str(chars)]
             r = subprocess.run(cmd, cwd='/tmp', env={**os.environ, 'TMPDIR': '/tmp'}, capture_output=True, text=True, timeout=timeout)
             files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
             if r.returncode != 0 or not files:
@@ -566,6 +566,7 @@ def main():
     ap.add_argument('--no-secondary', action='store_true', help='skip the batch-240 step roofline, the inference object and the PMC traffic passes')
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--traffic-probe', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--chars', type=int, default=L_CHARS, help=argparse.SUPPRESS)          # traffic probe only: encoder length
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline()), flush=True)
@@ -724,6 +725,9 @@ def main():
             try:
                 line['roofline_L200'] = long_input_roofline(device)
                 torch.cuda.empty_cache()
+                traffic, why = measure_traffic(PRESET, PER_GPU_BATCH, 'f32', timeout=180, chars=200)      # (full-length rows: the probe does not vary the lengths)
+                line['roofline_L200']['traffic'] = traffic['bytes_per_step'] if traffic else None
+                line['roofline_L200']['traffic_detail'] = traffic if traffic else {'error': why}
             except Exception as exc:
                 line['roofline_L200'] = {'error': repr(exc)[:200]}
             _C.set_precision('bf16' if args.dtype == 'bf16' else 'fp32')
