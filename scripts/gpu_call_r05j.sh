@@ -1,3 +1,4 @@
+# NOTE: the A/B switch MTTS_ATTN_BIG_NCH measured by the second half of this call was removed from the product afterwards (result: profiles/r05_attn_big_nch.txt)
 # round 5, call J: A/Bs - long inputs old vs new schedule (forward + train step), large-batch attention with two workgroups per sample
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; O=gpurun_out/r05j; mkdir -p $O
 {

@@ -1,3 +1,4 @@
+# NOTE: the A/B switch MTTS_PIPE_NOSPLIT_TILES measured by this call was removed from the product afterwards (result: profiles/r05_gemm_core.txt)
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; O=gpurun_out/r05p; mkdir -p $O
 {
 for t in 0 256 160; do
