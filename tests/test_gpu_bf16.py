@@ -117,3 +117,11 @@ def test_bf16_gradients_match_the_oracle_with_bf16_rounded_operands(preset, B, L
     # generated encoder: the per-tensor bound is an order looser (1.5e-1, 14 batch-normed generated blocks); the fp64 run of the
     # same-rounding oracle shows that spread between two CORRECT evaluations and bounds the product by it (run_train_step_case)
     run_train_step_case(preset, B, L, T, {}, bf16=True, fp64_spread=preset == 'generated_switching')
+
+
+def test_bf16_gradients_on_a_long_input_match_the_oracle_with_bf16_rounded_operands():
+    """200 characters in bf16 mode: the two-position-tile bf16 instance of the persistent attention decoder, the attention backward with
+    one workgroup per 32 positions and the bf16 pair tiles of the per-step products together, every gradient against the same-rounding
+    oracle (seed 11: see tests/test_gpu_persist.py on the encoder's ReLU discontinuity at long inputs)."""
+    from tests.test_gpu_more import run_train_step_case
+    run_train_step_case('shared_training', 16, 200, 8, {}, bf16=True, seed=11)
