@@ -213,7 +213,7 @@ def secondary_step_roofline(preset, B, L, T, device, dtype='f32'):
     return out
 
 
-def long_input_roofline(device, preset=PRESET, B=PER_GPU_BATCH, L=200, T=300, train_steps=3):
+def long_input_roofline(device, preset=PRESET, B=PER_GPU_BATCH, L=200, T=300, train_steps=3, warm_steps=2):
     """`roofline_L200` (round 5): the headline preset on inputs the length real CSS10 batches have - 200 characters at most, ragged
     lengths U[100, 200] sorted like the collate function sorts them (the reference's validation set has min 25 / median 124
     / max 304 characters, so a batch of 60 almost always exceeds the 128 positions the round-3/4 persistent decoder was limited to).
@@ -243,7 +243,8 @@ def long_input_roofline(device, preset=PRESET, B=PER_GPU_BATCH, L=200, T=300, tr
     # the whole train step on this batch (what a real CSS10 batch costs against the L = 120 headline)
     crit = TacotronLoss(hp.guided_attention_steps, hp.guided_attention_toleration, hp.guided_attention_gain)
     opt = FusedAdam(model.parameters(), lr=hp.learning_rate, weight_decay=hp.weight_decay)
-    train_step(model, crit, opt, None, batch, hp)
+    for _ in range(warm_steps):
+        train_step(model, crit, opt, None, batch, hp)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(train_steps):
         train_step(model, crit, opt, None, batch, hp)

@@ -5,5 +5,5 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import bench
 
-out = bench.long_input_roofline(torch.device('cuda', 0), T=int(sys.argv[1]) if len(sys.argv) > 1 else 300)
+out = bench.long_input_roofline(torch.device('cuda', 0), T=int(sys.argv[1]) if len(sys.argv) > 1 else 300, train_steps=5, warm_steps=3)
 print(json.dumps({k: out[k] for k in ('us_per_step', 'frac', 'train_ms_per_step', 'train_frames_per_s', 'mean_valid_length')}))
