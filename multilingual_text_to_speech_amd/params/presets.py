@@ -84,10 +84,12 @@ PRESETS = {
 
 
 def apply(name, reset=True, **extra):
-    """Load preset `name` into the global Params (optionally after restoring defaults)."""
+    """Load preset `name` into the global Params (optionally after restoring defaults); `None` / "defaults" = the class defaults
+    (the reference's LJ Speech configuration, which has no json)."""
     if reset:
         reset_defaults()
-    Params.load_state_dict(PRESETS[name])
+    if name not in (None, "defaults"):
+        Params.load_state_dict(PRESETS[name])
     if Params.multi_language and not Params.language_number:
         Params.language_number = len(Params.languages)       # reference train.py:240
     Params.load_state_dict(extra)

@@ -11,6 +11,9 @@ GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
 
 def golden_names(kind=None):
     names = sorted(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(GOLDEN, '*.pt')))
+    if kind == 'trajectory':          # several consecutive optimizer steps of the reference's training loop (oracle/make_golden.py)
+        return [n for n in names if '3step' in n]
+    names = [n for n in names if '3step' not in n]
     if kind == 'train':
         return [n for n in names if not n.endswith('_infer')]
     if kind == 'infer':
@@ -32,9 +35,9 @@ def cfg_of(fx):
     return cfg
 
 
-def oracle_replay(fx, with_grads=False):
-    cfg = cfg_of(fx)
-    sd = {k: v.clone() for k, v in fx['state_dict'].items()}
+def oracle_replay(fx, with_grads=False, state_dict=None, cfg=None):
+    cfg = cfg_of(fx) if cfg is None else cfg
+    sd = {k: v.clone() for k, v in (fx['state_dict'] if state_dict is None else state_dict).items()}
     if with_grads:
         for k, v in sd.items():
             if v.is_floating_point() and not k.endswith(('running_mean', 'running_var')):
@@ -48,6 +51,15 @@ def oracle_replay(fx, with_grads=False):
         loss.backward()
         grads = {k: v.grad for k, v in sd.items() if v.requires_grad and v.grad is not None}
     return out, loss, parts, grads
+
+
+def assert_after_step_close(got, want, what, lr=1e-3, max_mult=0.1):
+    """Parameters after an Adam step.  An element whose gradient is of the size of Adam's eps (1e-8) moves by anything in [-lr, lr]
+    depending on the last bits of that gradient (update = lr g / (|g| + eps) on the first step), so elementwise 1e-5 is not a
+    property of a correct implementation; per tensor: relative L2 <= 1e-4 and no element further off than a tenth of one update."""
+    d = (got.detach().double().cpu() - want.double())
+    rel = d.norm().item() / max(want.double().norm().item(), 1e-12)
+    assert rel <= 1e-4 and d.abs().max().item() <= max_mult * lr, f'{what}: relative L2 {rel:.2e}, max |delta| {d.abs().max().item():.2e}'
 
 
 # ------------------------------------------------------------------------------------------------

@@ -57,6 +57,22 @@ def test_benchmark_encoder_length_train_step_gradients_match_oracle(preset, B):
     run_train_step_case(preset, B, 120, 6, {})
 
 
+@pytest.mark.parametrize('preset,B,L,T,over', [
+    (None, 8, 30, 20, {}),                         # `Params` defaults = the reference's LJ Speech model: simple encoder 512, Dm = 512
+    ('singles/de', 6, 30, 20, {}),                 # params/singles/*.json: encoder 256, Dm = 256 (the narrowest memory pdec_kernel lays out)
+    ('separate_training', 20, 24, 12, {}),         # ConvolutionalEncoder with 10 language groups (stored grouped weights), Dm = 288
+    ('shared_switching', 10, 30, 20, {}),          # simple encoder 256 + language 4 + speaker 32: Dm = 292 (not a multiple of 32:
+                                                   # per-step launch schedule) with the adversarial classifier at weight 0.5
+    ('separate_switching', 10, 24, 12, {}),        # ConvolutionalEncoder, 5 groups, speaker embedding, no classifier
+    (None, 64, 20, 49, {})])                       # defaults at the benchmark's batch: four row tiles through the Dm = 512 layout
+def test_real_width_train_step_of_the_remaining_presets(preset, B, L, T, over):
+    """Every reference configuration that no other GPU test runs at its real widths (reference params/params.py:69-119 defaults,
+    params/singles/de.json, params/separate_training.json, params/shared_switching.json, params/separate_switching.json): forward,
+    loss and EVERY parameter gradient against the oracle.  The persistent decoder kernel's LDS layout depends on the memory width
+    (csrc/persist.hip), the encoder kernels on the group count."""
+    run_train_step_case(preset, B, L, T, over)
+
+
 def test_batch_above_64_train_step_gradients_match_oracle():
     """Batch 80 (five 16-row tiles, 16 per language group): above the 64-row limit of the round-3 persistent kernels - the forward
     schedule of large batches and the backward's multi-tile paths, every gradient against the oracle."""

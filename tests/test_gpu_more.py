@@ -154,6 +154,46 @@ BF16_GRAD_TOL = 3e-2
 BF16_ORACLE_SITES = frozenset({'conv', 'bilstm_in', 'lstm', 'memory', 'loc', 'prenet', 'proj', 'linear'})
 
 
+def make_draws(hp, B, L, T, g, teacher):
+    """Every dropout / zoneout draw of one train-mode step as the product's injected uint8 keep flags (`inj`, channel-last) and as
+    the oracle's multipliers (`om`, reference layout), from generator `g`."""
+    keep = lambda *shape, p: (torch.rand(*shape, generator=g) >= p).to(torch.uint8)
+    H, P = hp.decoder_dimension, hp.prenet_dimension
+    inj = {'teacher': teacher, 'dec.att_lstm': keep(T, B, H, p=hp.dropout_hidden), 'dec.gen_lstm': keep(T, B, H, p=hp.dropout_hidden)}
+    zone = hp.decoder_regularization == 'zoneout'
+    if zone:
+        for cell in ('att_lstm', 'gen_lstm'):
+            inj[f'dec.{cell}.h'] = keep(T, B, H, p=hp.zoneout_hidden)
+            inj[f'dec.{cell}.c'] = keep(T, B, H, p=hp.zoneout_cell)
+    inj.update({f'dec.prenet.{i}': keep(T, B, P, p=hp.dropout) for i in range(2)})
+    grouped = hp.encoder_type in ('generated', 'convolutional')       # reference modules/tacotron2.py:299-303: block dropout 0.05
+    G = (hp.language_number if hp.multi_language else 1) if grouped else 1
+    if grouped:
+        from multilingual_text_to_speech_amd.modules.encoder import _LAYERS
+        for i, (k, d, hw) in enumerate(_LAYERS):
+            inj[f'enc.{i}'] = keep(B // G, L, G * hp.encoder_dimension * (2 if hw else 1), p=0.05)
+    else:
+        inj.update({f'enc.{i}': keep(B, L, hp.encoder_dimension, p=hp.dropout) for i in range(hp.encoder_blocks)})
+    nb = hp.postnet_blocks
+    inj.update({f'post.{i}': keep(B, T, hp.postnet_dimension if i < nb - 1 else hp.num_mels, p=hp.dropout) for i in range(nb)})
+
+    mult = lambda m, p: m.float() / (1 - p)
+    om = {'att_lstm': mult(inj['dec.att_lstm'], hp.dropout_hidden), 'gen_lstm': mult(inj['dec.gen_lstm'], hp.dropout_hidden)}
+    if zone:
+        for cell in ('att_lstm', 'gen_lstm'):
+            om[f'{cell}.h'] = mult(inj[f'dec.{cell}.h'], hp.zoneout_hidden)
+            om[f'{cell}.c'] = mult(inj[f'dec.{cell}.c'], hp.zoneout_cell)
+    for i in range(2):
+        om[f'prenet.{i}'] = torch.cat((mult(inj[f'dec.prenet.{i}'], hp.dropout).transpose(0, 1), torch.ones(B, 1, P)), 1)
+        om[f'prenet_step.{i}'] = mult(inj[f'dec.prenet.{i}'], hp.dropout)          # free-running steps draw per step ([T,B,P])
+    for k, v in inj.items():
+        if k.startswith('enc.'):
+            om[k] = mult(v, 0.05 if grouped else hp.dropout).permute(0, 2, 1)
+        if k.startswith('post.'):
+            om[k] = mult(v, hp.dropout).permute(0, 2, 1)
+    return inj, om
+
+
 def run_train_step_case(preset, B, L, T, over, check_grads=True, ragged=None, teacher=None, bf16=False, seed=9, fp64_spread=False):
     """One train-mode step of the product on the GPU against the CPU oracle with identical dropout draws: outputs, loss and
     (check_grads) the gradient of every parameter.  Shared by the chunk-boundary tests in test_gpu_chunks.py."""
@@ -168,46 +208,15 @@ def run_train_step_case(preset, B, L, T, over, check_grads=True, ragged=None, te
     for b in range(B):
         stop_t[b, max(int(tgl[b]) - hp.stop_frames, 0):] = 1.0
     g = torch.Generator().manual_seed(21)
-    keep = lambda *shape, p: (torch.rand(*shape, generator=g) >= p).to(torch.uint8)
-    H, P = hp.decoder_dimension, hp.prenet_dimension
     teacher = [True] * T if teacher is None else [bool(x) for x in teacher]
-    inj = {'teacher': teacher, 'dec.att_lstm': keep(T, B, H, p=hp.dropout_hidden), 'dec.gen_lstm': keep(T, B, H, p=hp.dropout_hidden)}
+    inj, om = make_draws(hp, B, L, T, g, teacher)
     zone = hp.decoder_regularization == 'zoneout'
-    if zone:
-        for cell in ('att_lstm', 'gen_lstm'):
-            inj[f'dec.{cell}.h'] = keep(T, B, H, p=hp.zoneout_hidden)
-            inj[f'dec.{cell}.c'] = keep(T, B, H, p=hp.zoneout_cell)
-    inj.update({f'dec.prenet.{i}': keep(T, B, P, p=hp.dropout) for i in range(2)})
-    G = hp.language_number if hp.encoder_type == 'generated' else 1
-    if hp.encoder_type == 'generated':
-        from multilingual_text_to_speech_amd.modules.encoder import _LAYERS
-        for i, (k, d, hw) in enumerate(_LAYERS):
-            inj[f'enc.{i}'] = keep(B // G, L, G * hp.encoder_dimension * (2 if hw else 1), p=0.05)
-    else:
-        inj.update({f'enc.{i}': keep(B, L, hp.encoder_dimension, p=hp.dropout) for i in range(hp.encoder_blocks)})
-    nb = hp.postnet_blocks
-    inj.update({f'post.{i}': keep(B, T, hp.postnet_dimension if i < nb - 1 else hp.num_mels, p=hp.dropout) for i in range(nb)})
-
     # ---- oracle (CPU autograd)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     for k, v in sd.items():
         if v.is_floating_point() and not k.endswith(('running_mean', 'running_var')):
             v.requires_grad_(True)
     cfg = O.cfg_from_params(hp)
-    mult = lambda m, p: m.float() / (1 - p)
-    om = {'att_lstm': mult(inj['dec.att_lstm'], hp.dropout_hidden), 'gen_lstm': mult(inj['dec.gen_lstm'], hp.dropout_hidden)}
-    if zone:
-        for cell in ('att_lstm', 'gen_lstm'):
-            om[f'{cell}.h'] = mult(inj[f'dec.{cell}.h'], hp.zoneout_hidden)
-            om[f'{cell}.c'] = mult(inj[f'dec.{cell}.c'], hp.zoneout_cell)
-    for i in range(2):
-        om[f'prenet.{i}'] = torch.cat((mult(inj[f'dec.prenet.{i}'], hp.dropout).transpose(0, 1), torch.ones(B, 1, P)), 1)
-        om[f'prenet_step.{i}'] = mult(inj[f'dec.prenet.{i}'], hp.dropout)          # free-running steps draw per step ([T,B,P])
-    for k, v in inj.items():
-        if k.startswith('enc.'):
-            om[k] = mult(v, 0.05 if hp.encoder_type == 'generated' else hp.dropout).permute(0, 2, 1)
-        if k.startswith('post.'):
-            om[k] = mult(v, hp.dropout).permute(0, 2, 1)
     torch.set_flush_denormal(True)               # CPU speed only: identical output (SURVEY 8c recipe 5)
     O.BF16_SITES = BF16_ORACLE_SITES if bf16 else frozenset()      # bf16 path: the oracle rounds the same contraction operands
     if bf16 and check_grads:      # ... and its backward rounds what the product's backward rounds (see oracle._RoundedLinear): the batched
@@ -299,12 +308,21 @@ def run_train_step_case(preset, B, L, T, over, check_grads=True, ragged=None, te
                         round(1.0 - (torch.dot(g64, r64) / (g64.norm() * r64.norm()).clamp_min(1e-30)).item(), 7))
         top = sorted(worst.items(), key=lambda kv: -kv[1])[:6]
         print('bf16 gradients vs bf16-operand oracle, worst relative L2 (norm ratio, 1 - cosine):', [(k, round(v, 5), shape[k]) for k, v in top])
-        # generated encoder: the gradients of the parameter GENERATORS (tens of values that steer whole convolution kernels through
-        # 14 batch-normed layers) see the forward's 5e-3 encoder difference amplified: observed up to 6.6e-2 (norm ratio 1.03,
-        # 1 - cosine 1.8e-3) on a bottleneck bias at B = 40 - bounded at 1.5e-1, still an order below a wrong kernel's O(1)
-        gtol, ntol, ctol = (1.5e-1, 8e-2, 1e-2) if hp.encoder_type == 'generated' else (BF16_GRAD_TOL, 2e-2, 5e-4)
-        bad = {k: (v, shape[k]) for k, v in worst.items() if v > gtol or abs(shape[k][0] - 1.0) > ntol or shape[k][1] > ctol}
-        assert not bad, f'{preset} B={B} T={T} bf16 gradients: {bad}'
+        # generated encoder: the gradients of the parameter GENERATORS (tens of values that steer whole convolution kernels through 14
+        # batch-normed layers) move by percents between two CORRECT evaluations of this function (the same-rounding oracle carried in
+        # fp32 and in fp64: `spread64`).  No flat constant (round 5 used 1.5e-1, which cannot see a 10 % error in a generator gradient):
+        # per tensor, the product may be as far from the fp32 oracle as max(BF16_GRAD_TOL, 3x spread) + spread, spread = the distance
+        # between the two oracles on that tensor (product -> fp64 oracle <= max(BF16_GRAD_TOL, 3x spread), fp64 -> fp32 oracle = spread); the norm ratio is held to
+        # the same number and 1 - cosine to its square.
+        if hp.encoder_type == 'generated':
+            assert spread64 is not None, 'generated-encoder bf16 gradient cases need fp64_spread=True (the bound is per tensor)'
+        gtol = {k: max(BF16_GRAD_TOL, 3.0 * spread64[k]) + spread64[k] if spread64 is not None else BF16_GRAD_TOL for k in worst}
+        bad = {k: (v, shape[k], gtol[k]) for k, v in worst.items()
+               if v > gtol[k] or abs(shape[k][0] - 1.0) > max(2e-2, gtol[k]) or shape[k][1] > max(5e-4, gtol[k] ** 2)}
+        assert not bad, f'{preset} B={B} T={T} bf16 gradients (relative L2, (norm ratio, 1 - cosine), bound): {bad}'
+        if spread64 is not None:
+            loose = {k: round(t, 4) for k, t in gtol.items() if t > BF16_GRAD_TOL}
+            print(f'{len(loose)} of {len(gtol)} tensors carry a bound above {BF16_GRAD_TOL} (from the fp32 / fp64 oracles\' own distance):', loose)
         if spread64 is not None:
             # DEMONSTRATION that the loose bound above is the model's, not the kernels': the fp32 oracle and the fp64 oracle (same
             # rounding sites, both correct) are as far from each other as the product is from either.  Per tensor the product's
