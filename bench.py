@@ -18,6 +18,7 @@ Extra objects on the line (N = 1):
                  `kernels` keeps the per-launch figures of the dominant kernel as a sub-field, sampled inside the timed train steps:
                  `persistent_attention_decoder` (pdec_kernel: ONE launch = all 600 steps of attention LSTM + attention, reported
                  per step) or, when the per-step launch schedule runs (batch > 64), `attention_lstm_step`.
+  train_b40_bf16 - the whole train step of ONE RANK of BASELINE configs[3] (generated_switching, batch 40, classifier on), bf16 and fp32
   roofline_b240 / roofline_b240_bf16 / roofline_b40_bf16 - the same quantity for params/generated_switching at batch 240 (the valid
                  batch next to the north star's 256) in fp32 and bf16, and at batch 40 (one rank's shard of configs[3]) in bf16.
   inference    - BASELINE configs[4]: batched synthesis, 128 utterances x 201 tokens -> 600 frames, with its own step roofline.
@@ -210,6 +211,58 @@ def secondary_step_roofline(preset, B, L, T, device, dtype='f32'):
     finally:
         _C.set_precision('bf16' if before else 'fp32')
     del model
+    return out
+
+
+def secondary_train_step(preset, B, L, T, device, dtype='bf16', train_steps=3, warm_steps=2):
+    """`train_b40_bf16` (round 6): the PER-RANK work of BASELINE configs[3] on one GPU - params/generated_switching (5 language groups,
+    91 speakers, adversarial speaker classifier on), per-rank batch 40 (global 320 over 8 GPUs), 120 characters -> T frames, full train
+    step (forward + TacotronLoss incl. the classifier's cross entropy + backward + fused clip / Adam) in `dtype` arithmetic, and the
+    same step in fp32 on the same box for the ratio.  No all-reduce: one rank (the 8-GPU run is the driver's)."""
+    from multilingual_text_to_speech_amd import _C
+    from multilingual_text_to_speech_amd.params import presets, Params as hp
+    from multilingual_text_to_speech_amd.modules.tacotron2 import Tacotron, TacotronLoss
+    from multilingual_text_to_speech_amd.optim import FusedAdam
+    presets.apply(preset, speaker_number=91)
+    before = _C.get_precision()
+    out = {'workload': f'params/{preset} train step (classifier {"on" if hp.reversal_classifier else "off"}), per-rank batch {B}, L={L} -> T={T}, '
+                       'one rank of BASELINE configs[3]', 'frames_per_step': B * T}
+    try:
+        for dt_ in ('f32', dtype):
+            _C.set_precision(dt_)
+            torch.manual_seed(0)
+            model = Tacotron().to(device).train()
+            batch = synthetic_batch(hp, B, L, T, device)
+            crit = TacotronLoss(hp.guided_attention_steps, hp.guided_attention_toleration, hp.guided_attention_gain)
+            opt = FusedAdam(model.parameters(), lr=hp.learning_rate, weight_decay=hp.weight_decay)
+
+            def one():
+                opt.zero_grad(set_to_none=True)
+                post, pre, stop, align, spk, enc = model(batch['text'], batch['text_length'], batch['target'], batch['target_length'],
+                                                         batch['speakers'], batch['languages'], 1.0)
+                loss, _ = crit(batch['text_length'].to(device), batch['target_length'].to(device), pre, batch['target'], post, batch['target'],
+                               stop, batch['stop'], align, batch['speakers'], spk, enc, None)
+                loss.backward()
+                opt.step(max_norm=hp.gradient_clipping)
+                crit.update_states()
+                return loss
+            for _ in range(warm_steps):
+                one()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(train_steps):
+                loss = one()
+            torch.cuda.synchronize()
+            ms = 1e3 * (time.perf_counter() - t0) / train_steps
+            out[f'{dt_}_ms_per_step'] = round(ms, 2)
+            out[f'{dt_}_frames_per_s'] = round(B * T / (ms * 1e-3), 1)
+            out[f'{dt_}_loss'] = float(loss.item())
+            del model, opt, crit, batch
+            torch.cuda.empty_cache()
+        out['ratio'] = round(out[f'{dtype}_ms_per_step'] / out['f32_ms_per_step'], 3)
+        out['ms_per_step'] = out[f'{dtype}_ms_per_step']
+        out['dtype'] = dtype
+    finally:
+        _C.set_precision('bf16' if before else 'fp32')
     return out
 
 
@@ -722,6 +775,11 @@ def main():
                     line[key]['traffic_detail'] = traffic if traffic else {'error': why}
                 except Exception as exc:
                     line.setdefault(key, {})['error'] = repr(exc)[:200]
+            try:      # the per-rank train step of the 8-GPU configuration (configs[3]), bf16 and fp32 on this box
+                line['train_b40_bf16'] = secondary_train_step('generated_switching', 40, L_CHARS, T_FRAMES, device, 'bf16')
+                torch.cuda.empty_cache()
+            except Exception as exc:
+                line['train_b40_bf16'] = {'error': repr(exc)[:200]}
             _C.set_precision('fp32')
             try:
                 line['roofline_L200'] = long_input_roofline(device)

@@ -75,12 +75,20 @@ int mtts_gemm_ex(const GemmArgs* args, void* stream);
  * mtts_decoder_fwd/bwd and mtts_bilstm_fwd/bwd.  The per-step kernels take theirs from DecoderArgs.precision. */
 int mtts_set_precision(int precision);
 int mtts_get_precision(void);
-/* Scratch arena for split-K partial tiles, provided by the caller (the library never allocates); NULL disables split-K.
+/* Scratch arena for split-K partial tiles, provided by the caller; NULL disables split-K.  (The library allocates device memory in ONE
+ * place only: the pack buffer of the pre-split GEMM core, bf16 mode - see mtts_set_planes_workspace below.)
  * mtts_set_workspace binds the arena to the CURRENT device (default for all of its streams); mtts_set_stream_workspace
  * gives one caller stream its own arena, which is what makes concurrent callers on different streams of one device
  * independent: helper streams, ordering events and scratch are all looked up by (device, caller stream). */
 int mtts_set_workspace(void* ptr, size_t bytes);
 int mtts_set_stream_workspace(void* stream, void* ptr, size_t bytes);
+/* Pack buffer of the pre-split GEMM core (bf16 mode's large plain GEMMs; csrc/gemm_planes.h): per (device, stream).  By default the
+ * library hipMallocs it on first use and grows it in 64 MB granules (hundreds of MB per stream at 38400 x 4096 operands, invisible to
+ * the caller's allocator).  mtts_set_planes_workspace hands the stream a CALLER-OWNED arena instead (never resized: a GEMM whose pack
+ * does not fit runs on the core that needs no pack pass); ptr = NULL returns the stream to the library-owned buffer.  mtts_planes_trim
+ * frees every library-owned pack buffer of the current device (synchronises their streams) and returns the bytes released. */
+int mtts_set_planes_workspace(void* stream, void* ptr, size_t bytes);
+size_t mtts_planes_trim(void);
 int mtts_gemm(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
               int transA, int transB, float alpha, float beta, const float* bias, int act, void* stream);
 
@@ -717,6 +725,9 @@ int mtts_prof_begin(int max_samples, int stride);
 /* Launches the no-op `mtts_marker_kernel` on `stream`: region boundaries for rocprofv3 traces / PMC passes (bench.py). */
 int mtts_prof_marker(int tag, void* stream);
 int mtts_prof_end(float* total_ms, int* count);
+/* Test hook: launches `workgroups` x 64 threads that each hold `lds_bytes` of LDS and sleep for `ms` milliseconds on `stream` - a
+ * foreign resident kernel beside which the persistent decoder kernels must start late instead of timing out (tests/test_gpu_persist.py). */
+int mtts_debug_occupy(int workgroups, int lds_bytes, float ms, void* stream);
 /* summed duration (ms) of the EMPTY event brackets recorded in front of every sample: the cost of an event pair with nothing
  * between, subtracted by bench.py from the kernel brackets */
 float mtts_prof_empty_ms(void);

@@ -148,29 +148,74 @@ float* workspace_for(hipStream_t s, size_t* bytes) {
     return nullptr;
 }
 
-// Pack buffer of the pre-split GEMM core (gemm_planes.h) for launches on `s`: grow-only, one per (device, stream) - helper streams get
-// their own, their GEMMs run beside the caller's.  Owned by the library (hipMalloc): its size follows the largest operand pair seen.
+// Pack buffer of the pre-split GEMM core (gemm_planes.h) for launches on `s`: one per (device, stream) - helper streams get their own,
+// their GEMMs run beside the caller's.  Either provided by the caller (mtts_set_planes_workspace: never resized, a request that does
+// not fit returns nullptr and the GEMM takes the core that needs no pack pass) or owned by the library (hipMalloc, grow-only, 64 MB
+// granules, released by mtts_planes_trim).  g_mu is NOT held across the stream synchronisation / hipFree / hipMalloc of a growth.
 namespace {
-struct PlanesBuf { int device; hipStream_t stream; char* ptr; size_t bytes; };
+struct PlanesBuf { int device; hipStream_t stream; char* ptr; size_t bytes; bool owned; };
 std::vector<PlanesBuf> g_planes;
+PlanesBuf* planes_entry_locked(int dev, hipStream_t s) {
+    for (PlanesBuf& b : g_planes) if (b.device == dev && b.stream == s) return &b;
+    g_planes.push_back(PlanesBuf{dev, s, nullptr, 0, true});
+    return &g_planes.back();
+}
 }
 char* planes_buffer(hipStream_t s, size_t bytes) {
-    std::lock_guard<std::mutex> lk(g_mu);
     const int dev = current_device();
-    PlanesBuf* e = nullptr;
-    for (PlanesBuf& b : g_planes) if (b.device == dev && b.stream == s) { e = &b; break; }
-    if (!e) { g_planes.push_back(PlanesBuf{dev, s, nullptr, 0}); e = &g_planes.back(); }
-    if (e->bytes >= bytes) return e->ptr;
-    if (e->ptr) {                                    // kernels of earlier launches may still read the old buffer
-        if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        (void)hipFree(e->ptr);
-        e->ptr = nullptr; e->bytes = 0;
+    char* old = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        PlanesBuf* e = planes_entry_locked(dev, s);
+        if (e->bytes >= bytes) return e->ptr;
+        if (!e->owned) return nullptr;               // the caller's arena is too small for this operand pair: no pack pass
+        old = e->ptr; e->ptr = nullptr; e->bytes = 0;
+    }
+    if (old) {                                       // kernels of earlier launches on `s` may still read the old buffer
+        if (hipStreamSynchronize(s) != hipSuccess) (void)hipGetLastError();
+        (void)hipFree(old);
     }
     const size_t want = ((bytes + bytes / 4) + ((size_t)64 << 20) - 1) & ~(((size_t)64 << 20) - 1);
     void* q = nullptr;
     if (hipMalloc(&q, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    std::lock_guard<std::mutex> lk(g_mu);
+    PlanesBuf* e = planes_entry_locked(dev, s);
+    if (e->ptr || !e->owned) { (void)hipFree(q); return e->bytes >= bytes ? e->ptr : nullptr; }      // set meanwhile by another thread
     e->ptr = (char*)q; e->bytes = want;
     return e->ptr;
+}
+
+// Caller-provided pack arena for GEMMs launched on `stream` (nullptr / 0 hands the stream back to the library-owned buffer).
+MTTS_API int mtts_set_planes_workspace(void* stream, void* ptr, size_t bytes) {
+    char* old = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        PlanesBuf* e = planes_entry_locked(current_device(), (hipStream_t)stream);
+        if (e->owned) old = e->ptr;
+        e->ptr = (char*)ptr; e->bytes = ptr ? bytes : 0; e->owned = ptr == nullptr;
+    }
+    if (old) {
+        if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) (void)hipGetLastError();
+        (void)hipFree(old);
+    }
+    return 0;
+}
+
+// Release every library-owned pack buffer of the current device (their streams are synchronised first).  Returns the bytes freed.
+MTTS_API size_t mtts_planes_trim(void) {
+    std::vector<PlanesBuf> take;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        const int dev = current_device();
+        for (PlanesBuf& b : g_planes)
+            if (b.device == dev && b.owned && b.ptr) { take.push_back(b); b.ptr = nullptr; b.bytes = 0; }
+    }
+    size_t freed = 0;
+    for (const PlanesBuf& b : take) {
+        if (hipStreamSynchronize(b.stream) != hipSuccess) (void)hipGetLastError();      // a destroyed stream reports an error: nothing can be in flight on it
+        if (hipFree(b.ptr) == hipSuccess) freed += b.bytes; else (void)hipGetLastError();
+    }
+    return freed;
 }
 
 MTTS_API int mtts_set_workspace(void* ptr, size_t bytes) {

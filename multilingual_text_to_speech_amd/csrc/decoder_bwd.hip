@@ -230,7 +230,7 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
     // bf16 mode (round 5): the per-step input-gradient products dG W^T of both chains run on bf16 MFMA - transposed recurrent weights
     // and the cell backward's packed copy of dG as RNE-rounded bf16 pair tiles (skinny_body.h, PK = 3): half the 42 MB of weights the
     // three products re-stream per step, 1/4 of their MFMA issue; fp32 accumulation, the cell / attention backward stay fp32
-    const bool bfp = a.precision == 1 && g.dG_att_p && g.dG_gen_p && g.att_w_rec_Tp && g.gen_w_hh_Tp && (Dm & 15) == 0 && (H & 7) == 0;
+    const bool bfp = a.precision == 1 && g.dG_att_p && g.dG_gen_p && g.att_w_rec_Tp && g.gen_w_hh_Tp && (Dm & 15) == 0 && (H & 15) == 0;      // H % 16: the cell backward's pair-tile store derives lane and element from u alone (skinny_body.h bwd_cell)
     const int pkv = bfp ? 2 : 1;
     if (bfp) {
         MTTS_TRY(mtts_pack_weight_bf16(g.att_w_rec_T, 4 * H, Dm + H, 4 * H, g.att_w_rec_Tp, s));

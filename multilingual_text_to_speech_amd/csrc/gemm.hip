@@ -943,6 +943,15 @@ MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
     int S = 1;
     size_t g_ws_bytes = 0;
     float* g_ws_host = workspace_for((hipStream_t)stream, &g_ws_bytes);
+    // will the pre-split core really run?  (not during stream capture: its pack buffer may have to grow, which synchronises) - known
+    // BEFORE the split-K factor is chosen, so that a launch that falls back to the split core keeps its split-K
+    static const bool exact_f32 = [] { const char* e = getenv("MTTS_GEMM_EXACT_F32"); return e && e[0] == '1'; }();
+    bool planes_can = !exact_f32 && planes_wanted(p, p.precision == 1);
+    if (planes_can) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+        planes_can = cap == hipStreamCaptureStatusNone;
+    }
     const int region = p.nosplit < 0 || p.nosplit > 2 ? 0 : p.nosplit;
     const size_t region_bytes = (g_ws_bytes / 3) & ~(size_t)255;
     {
@@ -962,12 +971,11 @@ MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
         static const int nosplit_tiles = [] { const char* e = getenv("MTTS_PLANES_NOSPLIT_TILES"); return e ? atoi(e) : 128; }();
         // (the same rule for the fp32 cores was measured and not kept: 4096 x 1024 x 3072 0.166 -> 0.138 ms per call, but 4096 x 1536 x 38400
         //  2.73 -> 3.04 and no change of the train step: profiles/r05_gemm_core.txt)
-        if (S > 1 && !planes_split && p.precision == 1 && tiles >= nosplit_tiles && planes_wanted(p, true)) S = 1;
+        if (S > 1 && !planes_split && p.precision == 1 && tiles >= nosplit_tiles && planes_can) S = 1;
     }
     dim3 grid(ntx * nty, S, p.batch * p.zt);
     // side-stream launches (nosplit) ask for > half of the CU's LDS so that only ONE GEMM workgroup sits on a CU and the
     // latency-critical step kernels of the main stream always find room next to it
-    static const bool exact_f32 = [] { const char* e = getenv("MTTS_GEMM_EXACT_F32"); return e && e[0] == '1'; }();
     const size_t lds_base = exact_f32 ? 4 * LDS_A * sizeof(float) : (size_t)SP_LDS_B;
     // Helper-stream launches (side / weight-gradient stream) ask for 96 KiB of LDS: ONE GEMM workgroup per CU.  Every step
     // kernel of the decoder chains is built to fit beside it (<= 128 VGPRs, <= 64 KiB LDS: lstm_gates_kernel<., 4>,
@@ -1010,13 +1018,9 @@ MTTS_API int mtts_gemm_ex(const GemmArgs* args, void* stream) {
     }
     // big plain GEMMs: operands split / rounded ONCE by a pack pass, K loop without vector arithmetic (gemm_planes.h)
     bool planes = false;
-    if (!exact_f32 && planes_wanted(p, p.precision == 1)) {
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
-        if (cap == hipStreamCaptureStatusNone) {
-            if (p.precision == 1) MTTS_TRY(planes_gemm<true>(p, grid, ws, s, &planes));
-            else MTTS_TRY(planes_gemm<false>(p, grid, ws, s, &planes));
-        }
+    if (planes_can) {
+        if (p.precision == 1) MTTS_TRY(planes_gemm<true>(p, grid, ws, s, &planes));
+        else MTTS_TRY(planes_gemm<false>(p, grid, ws, s, &planes));
     }
     if (planes) {
     } else if (pipe >= 0) {

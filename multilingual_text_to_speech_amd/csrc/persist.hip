@@ -46,6 +46,12 @@ constexpr int PS_THREADS = 512;
 constexpr int PS_WGS = 256;                 // one workgroup per CU; 4 LSTM units (16 gate columns) each: H = 1024
 constexpr int PS_ERR_OFF = 8192, PS_XP_OFF = 16384;     // workspace: [counters: 4 groups x (1 + 8) x 128 B][error word][exchange ...]
 constexpr unsigned PS_SPIN_MAX = 1u << 22;  // ~0.5 s of polling before a barrier gives up (error word, no hang)
+// The FIRST hand-off of a launch waits for something else: for every workgroup to become RESIDENT.  When a foreign kernel (another
+// stream's long-running kernel, RCCL's resident channels, another process) holds the LDS / registers of some CUs, the missing
+// workgroups start when it leaves - seconds, not microseconds - and nothing is wrong.  Round 6: the start-up hand-offs (grid barrier
+// epoch 1, pgen7's publish 1) get ~30 s of patience; every later hand-off is between resident workgroups and keeps the 0.5 s bound.
+constexpr unsigned PS_SPIN_START = 1u << 28;
+__device__ __forceinline__ unsigned ps_spin_limit(unsigned epoch) { return epoch <= 1u ? PS_SPIN_START : PS_SPIN_MAX; }
 #define PS_RLX __ATOMIC_RELAXED
 #define PS_AGENT __HIP_MEMORY_SCOPE_AGENT
 
@@ -147,11 +153,11 @@ __device__ __forceinline__ void ps_bar_arrive(const PsSync& s, unsigned epoch) {
 // wait half (thread 0 polls the top counter)
 __device__ __forceinline__ bool ps_bar_wait(const PsSync& s, unsigned epoch) {
     if (threadIdx.x == 0) {
-        const unsigned target = epoch * 8u;
+        const unsigned target = epoch * 8u, limit = ps_spin_limit(epoch);
         unsigned spins = 0;
         while (__hip_atomic_load(s.cnt, PS_RLX, PS_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 1023u) == 0 && (spins > PS_SPIN_MAX || __hip_atomic_load(s.err, PS_RLX, PS_AGENT) != 0)) {
+            if ((++spins & 1023u) == 0 && (spins > limit || __hip_atomic_load(s.err, PS_RLX, PS_AGENT) != 0)) {
                 __hip_atomic_store(s.err, 2u, PS_RLX, PS_AGENT);
                 break;
             }
@@ -168,11 +174,11 @@ __device__ __forceinline__ bool ps_barrier(const PsSync& s, unsigned epoch) {
         const unsigned nwg = gridDim.x, ng = 8, g = blockIdx.x % ng, gsz = nwg / ng;
         const unsigned prev = __hip_atomic_fetch_add(s.cnt + 32 * (1 + g), 1u, PS_RLX, PS_AGENT);
         if (prev + 1 == epoch * gsz) __hip_atomic_fetch_add(s.cnt, 1u, PS_RLX, PS_AGENT);
-        const unsigned target = epoch * ng;
+        const unsigned target = epoch * ng, limit = ps_spin_limit(epoch);
         unsigned spins = 0;
         while (__hip_atomic_load(s.cnt, PS_RLX, PS_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 1023u) == 0 && (spins > PS_SPIN_MAX || __hip_atomic_load(s.err, PS_RLX, PS_AGENT) != 0)) {
+            if ((++spins & 1023u) == 0 && (spins > limit || __hip_atomic_load(s.err, PS_RLX, PS_AGENT) != 0)) {
                 __hip_atomic_store(s.err, 2u, PS_RLX, PS_AGENT);
                 break;
             }
@@ -492,9 +498,10 @@ __global__ __launch_bounds__(PS4_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
         };
         auto land = [&](unsigned pub) -> bool {      // wait until publish `pub` of this group has arrived everywhere, then tell the multipliers
             unsigned spins = 0;
+            const unsigned limit = ps_spin_limit(pub);
             while (__hip_atomic_load(top, PS_RLX, PS_AGENT) < pub * 8u) {
                 __builtin_amdgcn_s_sleep(1);
-                if ((++spins & 1023u) == 0 && (spins > PS_SPIN_MAX || __hip_atomic_load(bar.err, PS_RLX, PS_AGENT) != 0)) {
+                if ((++spins & 1023u) == 0 && (spins > limit || __hip_atomic_load(bar.err, PS_RLX, PS_AGENT) != 0)) {
                     if (lane == 0) { __hip_atomic_store(bar.err, 2u, PS_RLX, PS_AGENT); *lerr = 1; }
                     return false;
                 }
@@ -573,9 +580,10 @@ __global__ __launch_bounds__(PS4_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
     }
     auto wait_seen = [&](int g, unsigned pub) -> bool {
         unsigned spins = 0;
+        const unsigned limit = pub <= 1u ? 0xfffffff0u : (PS_SPIN_MAX << 2);      // publish 1: the service wave's own (patient) wait decides
         while (seen[g] < pub) {
             __builtin_amdgcn_s_sleep(1);
-            if (*lerr != 0 || ++spins > (PS_SPIN_MAX << 2)) { *lerr = 1; return false; }
+            if (*lerr != 0 || ++spins > limit) { *lerr = 1; return false; }
         }
         return true;
     };
@@ -802,7 +810,8 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             if (LT > 1) {
                 // one descriptor over the sample's [L][A] slice, ONE per-lane offset, the position tile in the scalar offset, (row, channel
                 // tile) as immediates: 8 LT requests without 8 LT loop-invariant 64-bit addresses held in registers across the step loop.
-                // Positions >= L are beyond num_records and read as zero without touching memory (their energies are never used).
+                // The position tile sits in the PER-LANE offset (round 6): the hardware's range check covers the vector offset, so positions
+                // >= L read as zero without touching memory whatever a target does with the scalar offset (their energies are never used).
                 const __amdgpu_buffer_rsrc_t mt_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Mt + (size_t)sbc * L * A), 0, L * A * 4, 0x00020000);
                 const unsigned mt_v = (unsigned)(((4 * (lane >> 4)) * A + 32 * sj + (lane & 15)) * 4);
 #pragma unroll
@@ -812,7 +821,7 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
                         for (int ct = 0; ct < 2; ++ct)
-                            mtr[it][ct][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(mt_r, mt_v + (unsigned)((r * A + 16 * ct) * 4), mt_s, 0));
+                            mtr[it][ct][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(mt_r, mt_v + mt_s + (unsigned)((r * A + 16 * ct) * 4), 0, 0));
                 }
             }
         }
@@ -827,12 +836,12 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                     const int l = min(lg + i * ng, L - 1);
                     mem4[i] = *reinterpret_cast<const float4*>(mem + (size_t)l * Dm);
                 }
-            } else {      // descriptor over the sample's [L][Dm] rows: one per-lane offset, the row group in the scalar offset; rows >= L read as zero
+            } else {      // descriptor over the sample's [L][Dm] rows; the row group is part of the per-lane offset, which the hardware range-checks: rows >= L read as zero
                 const __amdgpu_buffer_rsrc_t mem_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.memory + (size_t)sbc * L * Dm), 0, L * Dm * 4, 0x00020000);
                 const unsigned mem_v = (unsigned)((lg * Dm + d0 + 4 * c4) * 4), mem_step = (unsigned)(ng * Dm * 4);
 #pragma unroll
                 for (int i = 0; i < NMEM; ++i) {
-                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(mem_r, mem_v, (unsigned)i * mem_step, 0);
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(mem_r, mem_v + (unsigned)i * mem_step, 0, 0);
                     mem4[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
                 }
             }
@@ -995,7 +1004,7 @@ __global__ __launch_bounds__(PS_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                     float4 m3[PD_NCM];
 #pragma unroll
                     for (int i = 0; i < PD_NCM; ++i) {
-                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(mem_r, mem_v, (unsigned)(NMEM + i) * mem_step, 0);
+                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(mem_r, mem_v + (unsigned)(NMEM + i) * mem_step, 0, 0);
                         m3[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
                     }
 #pragma unroll

@@ -74,3 +74,23 @@ MTTS_API int mtts_prof_marker(int tag, void* stream) {
     MTTS_CHECK_LAUNCH("mtts_marker_kernel");
     return 0;
 }
+
+// Test hook (tests/test_gpu_persist.py): a FOREIGN resident kernel - `workgroups` workgroups of 64 threads that each hold `lds_bytes`
+// of LDS and sleep for `ms` milliseconds (constant 100 MHz wall clock).  With more than ~4 KB free LDS short of a persistent decoder
+// workgroup's request it keeps those CUs closed to the persistent kernels for as long as it runs, the way a long kernel of another
+// stream (or RCCL's resident channels) does.
+__global__ void mtts_occupy_kernel(long long ticks, int* sink) {
+    extern __shared__ char occ_lds[];
+    occ_lds[threadIdx.x] = (char)threadIdx.x;
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(100);
+    if (sink && threadIdx.x == 0) *sink = occ_lds[1];
+}
+
+MTTS_API int mtts_debug_occupy(int workgroups, int lds_bytes, float ms, void* stream) {
+    MTTS_REQUIRE(workgroups > 0 && lds_bytes >= 64 && lds_bytes <= 160 * 1024 && ms >= 0.f && ms <= 10000.f, "mtts_debug_occupy: bad arguments");
+    MTTS_CHECK_HIP(hipFuncSetAttribute((const void*)mtts_occupy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipLaunchKernelGGL(mtts_occupy_kernel, dim3(workgroups), dim3(64), (size_t)lds_bytes, (hipStream_t)stream, (long long)(ms * 1e5f), (int*)nullptr);
+    MTTS_CHECK_LAUNCH("mtts_occupy_kernel");
+    return 0;
+}

@@ -103,6 +103,7 @@ int skinny_launch(const SkinnyArgs& p, hipStream_t s) {
                      "skinny: segment %d pointers must be 16-byte aligned", i);
     }
     MTTS_REQUIRE(p.n_part <= MAX_PART, "skinny: at most %d partial slabs", MAX_PART);
+    MTTS_REQUIRE(!(p.lstm == 2 && p.dg_pack_out) || (p.H & 15) == 0, "skinny: the cell backward's packed copy of dG needs H %% 16 == 0 (H=%d)", p.H);
     const int ks = p.ksplit < 1 ? 1 : p.ksplit;
     SkinnyArgs q = p; q.ksplit = ks;
     if (p.nseg == 0) { q.seg[0] = SkSeg{p.gates, p.gates, 0, 0, 0, 0, 0}; q.nseg = 1; }   // pure pointwise: empty K range

@@ -146,6 +146,20 @@ def broadcast_parameters(module, src=0):
         dist.broadcast(t.data, src)
 
 
+def agree_on_guard(flag):
+    """Data-parallel ranks must take the SAME decision about an optimizer step.  The gradient norm is identical everywhere after the
+    all-reduce (a non-finite value on one rank is non-finite on all), but the device error words (`kernels._err_flag`: a persistent
+    decoder kernel whose grid barrier gave up, an embedding id outside its table) are per GPU: a rank that skips its guarded Adam
+    step (mtts.h AdamArgs.guard) while the others update leaves the replicas different for the rest of the run.  One MAX
+    all-reduce over the words, in place, makes every rank see the worst word of any rank: all of them skip the step, and all of
+    them raise at their next error poll.  A COLLECTIVE (call it once per optimizer step on every rank); no-op outside data parallel.
+    Reference semantics it protects: train.py:84-85, 173-179 (one model, one optimizer step per global batch)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return flag
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    return flag
+
+
 def global_mean_scale(n_local, device):
     """Factor that turns a rank's LOCAL mean over `n_local` items into its share of the GLOBAL mean after the gradient all-reduce
     (which averages over ranks): mean_global = (1 / world) * sum_r [ local_mean_r * n_local_r * world / n_global ].

@@ -52,6 +52,31 @@ class Postnet(Module):
         return x + residual
 
 
+_WARNED_SHAPES = set()
+
+
+def _warn_if_not_persistent(decoder_dim, attention_dim, memory_dim, kernel_size):
+    """The persistent (weights-stationary) decoder kernels are laid out for the widths every reference configuration uses: decoder 1024,
+    attention 128, memory width a multiple of 32 up to 768, odd location kernel up to 31 taps (csrc/persist.hip: pdec_supported /
+    pgen_supported).  Any other model still runs - on the per-step launch schedule, at roughly 2.5x the decoder time - and used to do so
+    silently; say it once per shape."""
+    why = []
+    if decoder_dim != 1024:
+        why.append(f'decoder_dimension {decoder_dim} != 1024')
+    if attention_dim != 128:
+        why.append(f'attention_dimension {attention_dim} != 128')
+    if memory_dim % 32 != 0 or memory_dim > 768:
+        why.append(f'memory width {memory_dim} (encoder + speaker + language embedding) is not a multiple of 32 up to 768')
+    if kernel_size % 2 == 0 or kernel_size > 31:
+        why.append(f'attention_kernel_size {kernel_size} is even or above 31')
+    key = (decoder_dim, attention_dim, memory_dim, kernel_size)
+    if why and key not in _WARNED_SHAPES:
+        _WARNED_SHAPES.add(key)
+        import warnings
+        warnings.warn('multilingual_text_to_speech_amd: the persistent decoder kernels do not take this model (' + '; '.join(why) +
+                      '): the teacher-forced decoder will run on the per-step launch schedule (about 2.5x its time at batch 64)')
+
+
 class Decoder(Module):
     """Attention + 2 LSTM cells + frame/stop projections; reference modules/tacotron2.py:79-219."""
 
@@ -70,6 +95,7 @@ class Decoder(Module):
             if hp.multi_speaker and hp.speaker_embedding_dimension > 0 else None
         self._language_embedding = self._get_embedding(hp.language_embedding_dimension, len(hp.languages)) \
             if hp.multi_language and hp.language_embedding_dimension > 0 else None
+        _warn_if_not_persistent(decoder_dim, hp.attention_dimension, context_dim, hp.attention_kernel_size)
 
     @staticmethod
     def _get_embedding(embedding_dimension, size=None):

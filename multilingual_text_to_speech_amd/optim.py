@@ -98,30 +98,45 @@ class FusedAdam(torch.optim.Adam):
         self._tables = {}
         self.skipped_steps = 0
         self._skip_poll = None
+        self._steps_issued = 0
 
-    def poll_skipped(self):
-        """Non-blocking: enqueue a copy of [grad_norm, clip_coefficient] of the step just issued into pinned memory and account for
-        what the PREVIOUS poll fetched (one step late, like kernels.poll_device_errors).  Returns the number of skipped steps so far."""
-        norm = self._tables.get('norm')
-        if norm is None:
-            return self.skipped_steps
-        st = self._skip_poll
-        if st is None:
-            st = self._skip_poll = dict(host=torch.zeros(2, dtype=torch.float32).pin_memory(), event=None)
-        if st['event'] is not None:
-            if not st['event'].query():
-                return self.skipped_steps
-            st['event'] = None
+    def _account_landed(self):
+        """Count the copies that have landed, oldest first."""
+        ring = self._skip_poll
+        while ring and ring['slots'] and ring['slots'][0]['event'].query():
+            st = ring['slots'].pop(0)
             if float(st['host'][1]) < 0:
                 self.skipped_steps += 1
                 if self.skipped_steps == 1 or self.skipped_steps % 100 == 0:
                     import warnings
                     warnings.warn(f'FusedAdam: {self.skipped_steps} optimizer step(s) skipped on the device (gradient norm '
                                   f'{float(st["host"][0])} not finite, or a device error word was set); weights unchanged')
-        with torch.cuda.device(norm.device):
-            st['host'].copy_(norm, non_blocking=True)
-            st['event'] = torch.cuda.Event()
-            st['event'].record()
+            ring['free'].append(st)
+        return self.skipped_steps
+
+    def poll_skipped(self, wait=False):
+        """Non-blocking: enqueue a copy of [grad_norm, clip_coefficient] of the step just issued into a pinned slot of a small ring and
+        account for every earlier copy that has landed.  One slot per step in flight: the host may run several steps ahead of the GPU,
+        and `norm[1]` of EVERY step is fetched before the next step overwrites it on the device (the copy is stream-ordered between
+        the two).  A second call without a new step only accounts.  Returns the number of skipped steps seen so far - it trails the
+        device by the steps still in flight; `wait=True` blocks until the step just issued has been accounted for."""
+        norm = self._tables.get('norm')
+        if norm is None:
+            return self.skipped_steps
+        if self._skip_poll is None:
+            self._skip_poll = dict(slots=[], free=[], polled=0)
+        ring = self._skip_poll
+        self._account_landed()
+        if ring['polled'] != self._steps_issued:
+            ring['polled'] = self._steps_issued
+            st = ring['free'].pop() if ring['free'] else dict(host=torch.zeros(2, dtype=torch.float32).pin_memory(), event=torch.cuda.Event())
+            with torch.cuda.device(norm.device):
+                st['host'].copy_(norm, non_blocking=True)
+                st['event'].record()
+            ring['slots'].append(st)
+        if wait and ring['slots']:
+            ring['slots'][-1]['event'].synchronize()
+            self._account_landed()
         return self.skipped_steps
 
     def load_state_dict(self, state_dict):
@@ -199,11 +214,13 @@ class FusedAdam(torch.optim.Adam):
             work += [(gi, k, step, ps) for k, (step, ps) in enumerate(sorted(by_step.items()))]
         if not everything:
             return None
+        self._steps_issued += 1
         dev = everything[0].device
         # device-side guard: the update is skipped when this GPU's persistent-kernel error word is set or the gradient norm is not
         # finite (mtts.h AdamArgs.guard) - no host synchronisation; kernels.poll_device_errors raises one step later
         from .kernels import _err_flag
-        self._guard = _err_flag(dev)
+        from .dist import agree_on_guard
+        self._guard = agree_on_guard(_err_flag(dev))        # data parallel: every rank skips when any rank has to (one tiny MAX all-reduce)
         norm = self._tables.get('norm')
         if norm is None or norm.device != dev:
             norm = self._tables['norm'] = torch.zeros(2, dtype=torch.float32, device=dev)

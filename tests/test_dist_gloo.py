@@ -182,3 +182,37 @@ def test_local_mean_is_rescaled_to_the_global_mean(tmp_path):
         got = torch.load(f'{tmp_path}/s{r}.pt')
         assert abs(float(got['share']) - [0.5, 1.5][r]) < 1e-6
         assert abs(float(got['mean_of_ranks']) - float(everything.mean())) < 1e-4
+
+
+def _worker_guard(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from multilingual_text_to_speech_amd import dist as D
+    D.init(backend='gloo')
+    seen = []
+    for step, bad_rank in enumerate((None, 1, None, 0)):
+        flag = torch.zeros(2, dtype=torch.int32)            # [invalid input, persistent kernel error] of this rank's GPU
+        if bad_rank == rank:
+            flag[1] = 2
+        seen.append(D.agree_on_guard(flag).tolist())
+    torch.save(seen, f'{out}/guard{rank}.pt')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_guard_words_are_an_all_rank_decision(tmp_path):
+    """The guarded optimizer step (mtts.h AdamArgs.guard) skips on the device when this GPU's error word is set.  Under data
+    parallelism the word is MAX-all-reduced first (dist.agree_on_guard, called by FusedAdam.step): when ONE rank's persistent decoder
+    gave up, EVERY rank sees the word, skips the step and raises at its next poll - replicas never diverge (reference semantics:
+    one model, one optimizer step per global batch, train.py:84-85,173-179)."""
+    port = _free_port()
+    mp.spawn(_worker_guard, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    s0, s1 = torch.load(tmp_path / 'guard0.pt'), torch.load(tmp_path / 'guard1.pt')
+    assert s0 == s1 == [[0, 0], [0, 2], [0, 0], [0, 2]]
+
+
+def test_agree_on_guard_is_a_no_op_outside_data_parallel():
+    from multilingual_text_to_speech_amd import dist as D
+    flag = torch.tensor([0, 2], dtype=torch.int32)
+    assert D.agree_on_guard(flag) is flag and flag.tolist() == [0, 2]

@@ -66,11 +66,14 @@ def test_benchmark_encoder_length_train_step_gradients_match_oracle(preset, B):
     ('separate_switching', 10, 24, 12, {}),        # ConvolutionalEncoder, 5 groups, speaker embedding, no classifier
     (None, 64, 20, 49, {})])                       # defaults at the benchmark's batch: four row tiles through the Dm = 512 layout
 def test_real_width_train_step_of_the_remaining_presets(preset, B, L, T, over):
-    """Every reference configuration that no other GPU test runs at its real widths (reference params/params.py:69-119 defaults,
+    """(Input seed 10 for the two defaults cases: on seed 9 a ReLU unit of the first / third encoder block sits within rounding of zero and
+    the fp32 and fp64 CPU oracles THEMSELVES disagree by 1.2-1.4 % on that block's batch-norm / convolution gradients and on the embedding
+    - scripts/dbg_seed_sweep.py, profiles/r06_defaults_seed_sweep.txt; seeds 10-13 agree on every gradient.)
+    Every reference configuration that no other GPU test runs at its real widths (reference params/params.py:69-119 defaults,
     params/singles/de.json, params/separate_training.json, params/shared_switching.json, params/separate_switching.json): forward,
     loss and EVERY parameter gradient against the oracle.  The persistent decoder kernel's LDS layout depends on the memory width
     (csrc/persist.hip), the encoder kernels on the group count."""
-    run_train_step_case(preset, B, L, T, over)
+    run_train_step_case(preset, B, L, T, over, seed=10 if preset is None else 9)
 
 
 def test_batch_above_64_train_step_gradients_match_oracle():

@@ -175,3 +175,46 @@ def test_two_persistent_decodes_in_flight_from_two_streams():
     for i in range(2):
         for o in outs[i]:
             assert torch.equal(o, base)
+
+
+def test_persistent_decode_beside_a_foreign_resident_kernel_starts_late_instead_of_timing_out():
+    """A long kernel of ANOTHER stream holds the LDS of 16 CUs for 2 s (mtts_debug_occupy: 16 workgroups x 100 KB) - what RCCL's resident
+    channels or a neighbour's kernel do to a rank.  The persistent decoder kernels need all 256 workgroups resident (one per CU, 156 KB of
+    LDS each): 16 of them cannot start before the occupant leaves.  Round 5's kernels gave up after 0.5 s at their first grid barrier
+    (device error word 2, MttsError); the start-up hand-off now waits for residency (csrc/persist.hip: PS_SPIN_START), every later
+    hand-off keeps the 0.5 s bound.  Asserts: the decode completes, bit-equal to the undisturbed one, no error word, and it really
+    waited for the occupant."""
+    import ctypes
+    import time
+    from multilingual_text_to_speech_amd import _C, kernels
+    from multilingual_text_to_speech_amd.masks import provider
+    from multilingual_text_to_speech_amd.params import presets, Params as hp
+    from multilingual_text_to_speech_amd.modules.tacotron2 import Tacotron
+    from tests.test_gpu_more import _random_batch
+    presets.apply('shared_training')
+    torch.manual_seed(0)
+    model = Tacotron().cuda().eval()
+    B, L, T = 24, 40, 60
+    text, tl, target, tgl, spk, lang = _random_batch(hp, B, L, T)
+    args = (text.cuda(), tl, target.cuda(), tgl, None, lang.cuda(), 1.0)
+    g = torch.Generator().manual_seed(3)
+    draws = {f'dec.prenet.{i}': (torch.rand(T, B, hp.prenet_dimension, generator=g) >= hp.dropout).to(torch.uint8).cuda() for i in range(2)}
+    provider.injected = {**draws, 'teacher': [True] * T}
+    try:
+        with torch.no_grad():
+            base = model(*args)[0].clone()
+        torch.cuda.synchronize()
+        kernels.check_device_errors()
+        side = torch.cuda.Stream()
+        t0 = time.perf_counter()
+        _C.check(_C.lib().mtts_debug_occupy(16, 100 * 1024, ctypes.c_float(2000.0), ctypes.c_void_p(side.cuda_stream)), 'mtts_debug_occupy')
+        with torch.no_grad():
+            out = model(*args)[0].clone()
+        torch.cuda.current_stream().synchronize()
+        waited = time.perf_counter() - t0
+        side.synchronize()
+    finally:
+        provider.injected = None
+    kernels.check_device_errors()                     # raises MttsError if a persistent kernel's barrier gave up
+    assert torch.equal(out, base)
+    assert waited >= 1.0, f'the decode finished in {waited:.2f} s: the occupant did not hold the CUs (test set-up)'

@@ -110,3 +110,22 @@ def test_fused_adam_loads_the_reference_two_group_state_dict():
     for p in shared + other + enc:
         assert torch.equal(mine.state[p]['exp_avg'], ref.state[p]['exp_avg'])
         assert float(mine.state[p]['step']) == float(ref.state[p]['step'])      # (torch steps a twice-listed tensor twice)
+
+
+def test_models_outside_the_persistent_kernels_geometry_say_so_once():
+    """decoder_dimension 1024 / attention_dimension 128 / memory width % 32 are what the persistent decoder kernels are laid out for
+    (csrc/persist.hip); other models run the per-step schedule at ~2.5x the decoder time - with ONE warning per shape, not silently."""
+    import warnings
+    from multilingual_text_to_speech_amd.modules import tacotron2
+    from multilingual_text_to_speech_amd.params import presets
+    tacotron2._WARNED_SHAPES.clear()
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter('always')
+        presets.apply('shared_training')
+        tacotron2.Tacotron()
+        assert not [c for c in caught if 'persistent decoder kernels' in str(c.message)]
+        presets.apply('shared_switching', speaker_number=7)           # memory width 256 + 4 + 32 = 292
+        tacotron2.Tacotron()
+        tacotron2.Tacotron()
+        msgs = [str(c.message) for c in caught if 'persistent decoder kernels' in str(c.message)]
+    assert len(msgs) == 1 and '292' in msgs[0]
