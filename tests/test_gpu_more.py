@@ -586,11 +586,13 @@ def _ddp_guard_worker(rank, world, port, out):
     res = {}
     w[0].grad = grads[0]
     opt.step(max_norm=0.25)
+    opt.poll_skipped()
     res['after0'] = w[0].detach().cpu().clone()
     if rank == 1:
         _err_flag('cuda')[1] = 2                # this rank's persistent decoder "gave up"
     w[0].grad = grads[1]
     opt.step(max_norm=0.25)
+    opt.poll_skipped()
     torch.cuda.synchronize()
     res['after1'] = w[0].detach().cpu().clone()
     res['flag'] = _err_flag('cuda').tolist()
