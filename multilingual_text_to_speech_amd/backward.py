@@ -44,16 +44,13 @@ def decoder_bwd(ctx, dspec, dstop, dalign):
         return t
 
     import os
-    # K-splits of the per-step input-gradient products dG W_hh^T (both chains).  33..64 rows with packed operands run the column-PAIR
-    # body (csrc/skinny_body.h: two 16-column blocks per workgroup): twice the splits keep the launch at 256 workgroups
-    pair = 32 < B <= 64 and H % 32 == 0 and Dm % 32 == 0 and st.h_att_p is not None and os.environ.get('MTTS_SKINNY_PAIR', '1') != '0'
-    ksb = int(os.environ.get('MTTS_KSB', cfg.get('ksb', 8 if pair else 4)))                 # tuning knobs (scripts/sweep_bwd.sh)
+    ksb = int(os.environ.get('MTTS_KSB', cfg.get('ksb', 4)))                 # tuning knobs (scripts/sweep_bwd.sh)
     # workgroups per sample of the attention-step backward: 4 fill the chip at batch 64; inputs above 128 characters get one per 32
     # positions so that they stay on the MFMA kernel (attn_bwd_fast_ok: <= 32 own rows per workgroup) instead of the generic one,
     # whose LDS request also ends at L ~ 310
     nch = int(os.environ.get('MTTS_NCH_BWD', cfg.get('nch_bwd', max(4, (L + 31) // 32))))
     # K-split of the ctx-column input gradient: as many slabs as keep the launch within ONE wave of workgroups (256 CUs)
-    ksc = int(os.environ.get('MTTS_KSC', cfg.get('ksb_ctx', max(1, min(8, 256 // ((Dm + 31) // 32 if pair else (Dm + 15) // 16))))))
+    ksc = int(os.environ.get('MTTS_KSC', cfg.get('ksb_ctx', max(1, min(8, 256 // ((Dm + 15) // 16))))))
     g.ksb, g.nch, g.ksb_ctx = ksb, nch, ksc
     # every workspace size comes from the library (mtts_decoder_grad_buffer_elems)
     lib().mtts_decoder_grad_buffer_elems.restype = ctypes.c_long

@@ -94,7 +94,6 @@ struct GridRC {
 int gemm_plain(const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, bool tA,
                bool tB, float alpha, float beta, const float* bias, int act, hipStream_t s);
 int skinny_launch(const SkinnyArgs& p, hipStream_t s);
-bool skinny_pair_enabled();      // column-pair body for the packed per-step products (skinny.hip; MTTS_SKINNY_PAIR=0: off)
 int attn_step_launch(const AttnStepArgs& p, hipStream_t s);
 int attn_step_nch(int B, int L, int A, int Dm, int ksz, int kq);
 int attn_pl_init(const float* Mt, const float* bias, float* PL, long total, int A, hipStream_t s);

@@ -10,8 +10,7 @@
 
 // launch bound 4 waves/SIMD (<= 128 VGPRs): an attention workgroup and a GEMM workgroup must fit on one CU together.
 // PK: operands of the product in MFMA tile order (skinny_body's packed-only instantiation); the product is a plain one (PLAIN).
-// PAIR: the product part runs the column-pair body (two 16-column blocks per workgroup, sk_cbs = N / 32; skinny_body.h).
-template <int PK, int PAIR = 0>
+template <int PK>
 __global__ __launch_bounds__(NT, 4) void attn_bwd_plus_skinny_kernel(AttnBwdArgs a, SkinnyArgs k, int n_attn, int sk_cbs) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int id = blockIdx.x;
@@ -20,8 +19,7 @@ __global__ __launch_bounds__(NT, 4) void attn_bwd_plus_skinny_kernel(AttnBwdArgs
     } else {
         const int j = id - n_attn;
         float (&red)[NW][64][17] = *reinterpret_cast<float (*)[NW][64][17]>(sm);
-        if (PAIR) skinny_pair_body<PK == 3 ? 3 : 1>(k, red, j % sk_cbs, j / sk_cbs);
-        else skinny_body<4, 2, PK, 1>(k, red, j % sk_cbs, 0, j / sk_cbs);
+        skinny_body<4, 2, PK, 1>(k, red, j % sk_cbs, 0, j / sk_cbs);
     }
 }
 
@@ -39,14 +37,6 @@ int attn_bwd_plus_skinny(const AttnBwdArgs& a, const SkinnyArgs& k, hipStream_t 
     size_t lds = attn_bwd_fast_lds(a);
     const size_t lds_sk = sizeof(float) * NW * 64 * 17;
     if (lds_sk > lds) lds = lds_sk;
-    if (skinny_pair_enabled() && skinny_pair_ok(q)) {
-        const int cbp = q.N / 32;
-        const dim3 gridp(n_attn + cbp * q.ksplit);
-        if (q.seg[0].xpack == 2) hipLaunchKernelGGL((attn_bwd_plus_skinny_kernel<3, 1>), gridp, dim3(NT), lds, s, a, q, n_attn, cbp);
-        else hipLaunchKernelGGL((attn_bwd_plus_skinny_kernel<1, 1>), gridp, dim3(NT), lds, s, a, q, n_attn, cbp);
-        MTTS_CHECK_LAUNCH("attn_bwd_plus_skinny_kernel");
-        return 0;
-    }
     const dim3 grid(n_attn + cbs * q.ksplit);
     if (q.seg[0].xpack == 2 && q.seg[0].wpack == 2) hipLaunchKernelGGL(attn_bwd_plus_skinny_kernel<3>, grid, dim3(NT), lds, s, a, q, n_attn, cbs);
     else if (q.seg[0].xpack && q.seg[0].wpack) hipLaunchKernelGGL(attn_bwd_plus_skinny_kernel<1>, grid, dim3(NT), lds, s, a, q, n_attn, cbs);

@@ -18,19 +18,6 @@ __global__ __launch_bounds__(NT, 4) void skinny_kernel_lo(SkinnyArgs p) {
     skinny_body<MT, 2, PK>(p, red, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
-// Column-pair variant (skinny_body.h: skinny_pair_body): the plain per-step products of the decoder backward with packed operands,
-// 33..64 rows; grid (N / 32, 1, ksplit).  MTTS_SKINNY_PAIR=0 keeps the 16-column body (A/B).
-template <int PK>
-__global__ __launch_bounds__(NT, 4) void skinny_pair_kernel(SkinnyArgs p) {
-    __shared__ float red[NW][64][17];
-    skinny_pair_body<PK>(p, red, blockIdx.x, blockIdx.z);
-}
-
-bool skinny_pair_enabled() {
-    static const bool on = [] { const char* e = getenv("MTTS_SKINNY_PAIR"); return !(e && e[0] == '0'); }();
-    return on;
-}
-
 // ---------------------------------------------------------------------------------------------------------------------------
 // One-round-trip kernel for plain products with few output columns in the free-running loop (frame / stop projection: 6 column
 // tiles, K = H + Dm; reference modules/tacotron2.py:191-193): workgroup = 16 output columns x 16 rows over the whole K, the 16-wide
@@ -165,13 +152,6 @@ int skinny_launch(const SkinnyArgs& p, hipStream_t s) {
         if (lean && ktot <= 16 * NW * PJ_NF) hipLaunchKernelGGL(skinny_proj_kernel, dim3(cbs, cdiv(p.B, 16), 1), dim3(NT), 0, s, q);
         else hipLaunchKernelGGL(skinny_kernel_wide<1>, dim3(cbs, cdiv(p.B, 16), 1), dim3(NT), 0, s, q);
         MTTS_CHECK_LAUNCH("skinny_proj_kernel");
-        return 0;
-    }
-    if (skinny_pair_enabled() && skinny_pair_ok(q)) {
-        const dim3 grid(q.N / 32, 1, ks);
-        if (pk == 3) hipLaunchKernelGGL(skinny_pair_kernel<3>, grid, dim3(NT), 0, s, q);
-        else hipLaunchKernelGGL(skinny_pair_kernel<1>, grid, dim3(NT), 0, s, q);
-        MTTS_CHECK_LAUNCH("skinny_pair_kernel");
         return 0;
     }
     if (p.B <= 16) SK_LAUNCH(skinny_kernel, 1, dim3(cbs, cdiv(p.B, 16), ks));

@@ -419,107 +419,3 @@ __device__ __forceinline__ void skinny_body(const SkinnyArgs& p, float (&red)[NW
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// Column-PAIR body (round 6) for the plain per-step products of the decoder backward, dG W^T with both operands in MFMA tile order
-// (PK 1: fp32 tiles, 3: bf16 pair tiles), 33..64 rows: one workgroup owns TWO 16-column blocks.  The 16-column body moves, per 16-k
-// chunk and wave, four activation fragments for one weight fragment - 80 % of its bytes and load instructions are the SAME dG rows
-// that every column tile of the launch fetches again; these launches are bound by exactly that (bytes and load instructions,
-// profiles/r05_bwd_plane_tiles_ab.txt).  With two column blocks per workgroup a wave issues 6 loads per 2 x 4 MFMA groups instead of
-// 5 per 4, and the launch keeps its workgroup count by splitting K twice as often (8 partial slabs instead of 4: the consumers -
-// cell backward, attention backward - take up to 8).  Same arithmetic per output element; the K-split boundaries (and with them the
-// summation order) differ from the 16-column form.  The two blocks share one LDS reduction buffer, used twice.
-// ---------------------------------------------------------------------------------------------------------------------------
-template <int PK>
-__device__ __forceinline__ void skinny_pair_body(const SkinnyArgs& p, float (&red)[NW][64][17], const int cbp, const int ks) {
-    static_assert(PK == 1 || PK == 3, "skinny_pair_body: packed operands only");
-    constexpr int MT = 4;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 15, lq = lane >> 4;
-    constexpr int CSH = PK == 3 ? 5 : 4;
-    const int nc = (p.seg[0].K + (1 << CSH) - 1) >> CSH;                   // chunks along K
-    const int mt_last = ((p.B + 15) >> 4) - 1;
-    const float* sx = p.seg[0].x;
-    const float* sw = p.seg[0].w;
-    const float* zp = g_sk_zero + lane * 4;
-    // per-lane element offsets of the fragments of chunk 0 (chunk c adds c * 256 floats)
-    const long wo0 = ((long)(2 * cbp) * nc * 64 + lane) * 4, wo1 = wo0 + (long)nc * 256;
-    long xo[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) xo[m] = ((long)min(m, mt_last) * nc * 64 + lane) * 4;
-    struct F2 { float4 w[2]; float4 x[MT]; };
-    auto load = [&](int c, F2& f) {
-        const bool live = c < nc;                      // wave-uniform; the ADDRESS is selected (see g_sk_zero)
-        const long co = (long)(live ? c : 0) * 256;
-        f.w[0] = *reinterpret_cast<const float4*>(live ? sw + wo0 + co : zp);
-        f.w[1] = *reinterpret_cast<const float4*>(live ? sw + wo1 + co : zp);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) f.x[m] = *reinterpret_cast<const float4*>(live ? sx + xo[m] + co : zp);
-    };
-    f32x4 acc[2][MT];
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[g][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    auto mma = [&](const F2& f) {
-        if (PK == 3) {
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const sk_s16x4 w0 = sk_bf16_half(f.w[g].x, f.w[g].y), w1 = sk_bf16_half(f.w[g].z, f.w[g].w);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    acc[g][m] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(sk_bf16_half(f.x[m].x, f.x[m].y), w0, acc[g][m], 0, 0, 0);
-                    acc[g][m] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(sk_bf16_half(f.x[m].z, f.x[m].w), w1, acc[g][m], 0, 0, 0);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const float xv[4] = {f.x[m].x, f.x[m].y, f.x[m].z, f.x[m].w};
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    const float wv[4] = {f.w[g].x, f.w[g].y, f.w[g].z, f.w[g].w};
-#pragma unroll
-                    for (int s2 = 0; s2 < 4; ++s2) acc[g][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[s2], wv[s2], acc[g][m], 0, 0, 0);
-                }
-            }
-        }
-    };
-    const int step = NW * p.ksplit;
-    int c = ks * NW + wave;
-    {
-        F2 f0, f1;
-        load(c, f0);
-        load(c + step, f1);
-        for (; c < nc; c += 2 * step) {
-            mma(f0);
-            load(c + 2 * step, f0);
-            mma(f1);
-            load(c + 3 * step, f1);
-        }
-    }
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        if (g) __syncthreads();                        // the sums of block 0 have been read
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[wave][m * 16 + lq * 4 + r][li] = acc[g][m][r];
-        __syncthreads();
-        for (int e = tid; e < MT * 16 * 16; e += NT) {
-            const int rr = e >> 4, cc = e & 15;
-            const int col = (2 * cbp + g) * 16 + cc;
-            if (rr >= p.B || col >= p.N) continue;
-            const float v = red_sum<MT>(red, rr, cc);
-            p.out[(p.ksplit > 1 ? (long)ks * p.out_ks : 0) + (long)rr * p.ldo + col] = v;
-        }
-    }
-}
-
-// shapes the column-pair body takes (the launchers ask before choosing a grid)
-static inline bool skinny_pair_ok(const SkinnyArgs& p) {
-    return p.lstm == 0 && p.nseg == 1 && p.B > 32 && p.B <= 64 && (p.N & 31) == 0 && !p.bias && !p.act && !p.mask && p.ksplit >= 1 &&
-           ((p.seg[0].xpack == 1 && p.seg[0].wpack == 1 && (p.seg[0].K & 15) == 0) || (p.seg[0].xpack == 2 && p.seg[0].wpack == 2 && (p.seg[0].K & 31) == 0));
-}
-

@@ -6,5 +6,5 @@ for i in $(seq $n); do for cfg in "$@"; do
   ( if [ "$cfg" != "-" ]; then export $cfg; fi
     timeout 200 python bench.py --steps $steps --warmup 5 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print('%-44s' % '$cfg', 'ms/step', d['ms_per_step'], 'decoder fwd us/step', d['roofline']['us_per_step'])" )
+d=json.loads(sys.stdin.read()); print('%-44s' % '$cfg', 'ms/step', d['ms_per_step'], 'decoder fwd us/step', d['roofline']['us_per_step'], 'decoder bwd ms', d.get('roofline_bwd', {}).get('ms_per_backward'))" )
 done; done

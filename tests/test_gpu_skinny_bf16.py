@@ -81,37 +81,3 @@ def test_cell_backward_bf16_copy_of_the_gate_gradients(B):
     q.out, q.ldo = ptr(out), 4 * H
     check(lib().mtts_skinny_gemm(ctypes.byref(q), stream_ptr()), 'skinny')
     assert torch.equal(out, bufs['dgates_out'].to(torch.bfloat16).float())
-
-
-@pytest.mark.parametrize('B,N,K,ks', [(64, 1024, 4096, 8), (40, 544, 4096, 8), (33, 288 - 32, 4096, 3), (64, 64, 512, 1), (48, 1024, 1024, 2)])
-@pytest.mark.parametrize('bf16', [False, True])
-def test_column_pair_product_kernel(B, N, K, ks, bf16, monkeypatch):
-    """Round 6: the plain per-step products with packed operands and 33..64 rows run two 16-column blocks per workgroup
-    (csrc/skinny_body.h skinny_pair_body; fp32 tiles and bf16 pair tiles): against the fp64 product of the operands (fp32: exact
-    fp32 MFMA products, fp32 accumulation; bf16: RNE-rounded operands), with K splits that do not divide the chunk count, a ragged
-    last row tile and a single split."""
-    from multilingual_text_to_speech_amd import _C
-    from multilingual_text_to_speech_amd._C import check, lib, ptr, stream_ptr
-    g = torch.Generator(device='cuda').manual_seed(B + N + ks)
-    X = torch.randn(B, K, device='cuda', generator=g) * torch.exp2(torch.randint(-4, 4, (B, K), device='cuda', generator=g).float())
-    W = torch.randn(N, K, device='cuda', generator=g) * 0.1
-    if bf16:
-        xp, wp = _pack_bf16(X, B, K), _pack_bf16(W, N, K)
-    else:
-        xp = torch.zeros(((B + 15) & ~15) * K, device='cuda')
-        wp = torch.zeros(((N + 15) & ~15) * K, device='cuda')
-        check(lib().mtts_pack_rows(ptr(X), K, B, K, ptr(xp), stream_ptr()), 'pack_rows')
-        check(lib().mtts_pack_weight(ptr(W), K, N, K, 0, ptr(wp), stream_ptr()), 'pack_weight')
-    a = _C.SkinnyArgs()
-    a.nseg, a.B, a.N, a.ksplit = 1, B, N, ks
-    pk = 2 if bf16 else 1
-    a.seg[0].x, a.seg[0].w, a.seg[0].K, a.seg[0].ldx, a.seg[0].ldw, a.seg[0].xpack, a.seg[0].wpack = ptr(xp), ptr(wp), K, K, K, pk, pk
-    out = torch.full((ks, B, N), float('nan'), device='cuda')                # every slab element must be written
-    a.out, a.ldo, a.out_ks = ptr(out), N, (B * N if ks > 1 else 0)
-    check(lib().mtts_skinny_gemm(ctypes.byref(a), stream_ptr()), 'skinny')
-    got = out.double().sum(0)
-    Xr, Wr = (X.to(torch.bfloat16).double(), W.to(torch.bfloat16).double()) if bf16 else (X.double(), W.double())
-    ref = Xr @ Wr.t()
-    scale = Xr.abs() @ Wr.abs().t()
-    err = ((got - ref).abs() / scale).max().item()
-    assert err <= 2e-6, f'{err:.3e}'
