@@ -551,6 +551,9 @@ typedef struct DecoderGradArgs {
     float* dU;             /* [A,ksz] */
     float* dpren;          /* [n_prenet][T,B,P] gradient scratch for the prenet layers */
     float* colsum_ws;      /* mtts_colsum_workspace_floats(max C) floats */
+    float* part_ring;      /* persistent backward (round 6, csrc/pbwd.hip): [part_ring_slots][ksb_ctx*B*Dm + ksb*B*H] partial slabs indexed by
+                              the step (slot t % part_ring_slots), or NULL: the per-step launch schedule runs */
+    int part_ring_slots;   /* >= mtts_decoder_bwd_ring_slots() */
     /* outputs */
     float* dmemory;        /* [B,L,Dm] */
     float* d_prenet_w[4];
@@ -574,6 +577,8 @@ typedef struct DecoderGradArgs {
 } DecoderGradArgs;
 
 int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* grad, void* stream);
+/* slots DecoderGradArgs.part_ring needs for the persistent backward at the current chunk length (chunk + 2) */
+int mtts_decoder_bwd_ring_slots(void);
 
 /* Backward of mtts_bilstm_fwd. */
 typedef struct BiLstmGradArgs {
@@ -738,7 +743,8 @@ float mtts_prof_empty_ms(void);
 long mtts_gemm_planes_count(void);
 
 const char* mtts_last_error(void);
-/* ABI version.  101 (round 5) is NOT layout-compatible with 100: AdamArgs gained `guard`, LstmPackArgs lost `plain_rows`, AttnBwdArgs
+/* ABI version.  102 (round 6): DecoderGradArgs gained part_ring / part_ring_slots; new exports mtts_decoder_bwd_ring_slots,
+ * mtts_set_planes_workspace, mtts_planes_trim, mtts_debug_occupy.  101 (round 5) is NOT layout-compatible with 100: AdamArgs gained `guard`, LstmPackArgs lost `plain_rows`, AttnBwdArgs
  * lost `hsum_out` / `hsum_cols`, DecoderGradArgs lost three fields, the mtts_ksplit_* exports are gone, LstmStepArgs.precision takes 2
  * (pre-split planes), DecoderArgs gained the long-input fields of the persistent decoder.  Bindings that do not generate their structs
  * from this header must check mtts_version() and mtts_sizeof_struct(). */

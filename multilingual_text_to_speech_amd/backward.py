@@ -98,6 +98,11 @@ def decoder_bwd(ctx, dspec, dstop, dalign):
     buf('dq_all', Z('dq_all'))
     buf('part_gen', Z('part_gen'))
     buf('part_att', Z('part_att'))
+    if st.fast and 32 < B <= 64 and st.h_att_p is not None and H % 16 == 0 and os.environ.get('MTTS_PBWD', '0') == '1':
+        # persistent backward of chain A (csrc/pbwd.hip; opt-in, measured slower than the per-step launches: profiles/r06_pbwd_ab.txt):
+        # partial slabs in a ring indexed by the step; the library falls back to the per-step launches for shapes it does not take
+        g.part_ring_slots = int(lib().mtts_decoder_bwd_ring_slots())
+        buf('part_ring', E('part_ring'))
     for name in ('dc_att', 'dc_gen', 'dh_carry_att', 'dh_carry_gen', 'dMt', 'dU_slab', 'dv_slab', 'dbias_slab'):
         buf(name, Z(name))
     buf('dU', E('dU'))

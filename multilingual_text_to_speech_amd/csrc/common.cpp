@@ -14,7 +14,7 @@ int mtts_fail(const char* fmt, ...) {
 }
 
 MTTS_API const char* mtts_last_error(void) { return g_mtts_err; }
-MTTS_API int mtts_version(void) { return 101; }      // 101: struct layouts changed since 100 (see mtts.h)
+MTTS_API int mtts_version(void) { return 102; }      // 102: DecoderGradArgs.part_ring (see mtts.h)
 
 // Bitmask of compile-time switches that make a build produce WRONG results by design (timing experiments).  The product sources have
 // none (round 4 removed the last two); the entry stays so that bindings keep refusing a library that reports anything but 0

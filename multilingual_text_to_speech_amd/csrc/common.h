@@ -155,5 +155,11 @@ bool pgen_supported(const DecoderArgs& a);
 int pgen_launch(const DecoderArgs& a, int t0, int t1, hipStream_t s);
 bool pdec_supported(const DecoderArgs& a);
 int pdec_launch(const DecoderArgs& a, int t0, int t1, hipStream_t s);
+bool ps_ready_ext(const void* fn, int threads, size_t lds);
+int ps_run_launch(const DecoderArgs& a, hipStream_t s, void (*go)(void* ctx, unsigned* cnt, unsigned* err, hipStream_t s), void* ctx);
+// persistent decoder backward: chain A (attention + attention LSTM) of a chunk in one launch (pbwd.hip)
+struct PbwdChunk { int a0, a1; };      // chain A steps [a0, a1)
+bool pbwd_supported(const DecoderArgs& a, const DecoderGradArgs& g);
+int pbwd_launch(const DecoderArgs& a, const DecoderGradArgs& g, const PbwdChunk& c, hipStream_t s);
 int prenet2_launch(const float* x, int ldx, int Kin, const float* w1, const float* b1, const float* w2, const float* b2, const uint8_t* m1,
                    const uint8_t* m2, float scale, float* y1, float* y2, int B, int P, hipStream_t s);

@@ -348,10 +348,14 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
         if (g.att_w_rec_Tp && (Dm & 15) == 0) { sg.w = g.att_w_rec_Tp + (h_part ? (long)cb_ctx * (4 * H / (bfp ? 32 : 16)) * 256 : 0); sg.wpack = pkv; }
         return sg;
     };
+    const bool persistent_a = pbwd_supported(a, g);
     auto submit_A = [&](int c) -> int {
         const int c0 = c * CH, c1 = std::min(T, c0 + CH);
         MTTS_CHECK_HIP(hipStreamWaitEvent(s, chunk_ev[c], 0));
         tmark(s, "A start", c);
+        if (persistent_a) {      // round 6 (csrc/pbwd.hip): the chunk's steps of chain A in ONE resident launch
+            MTTS_TRY(pbwd_launch(a, g, PbwdChunk{c0, c1}, s));
+        } else
         for (int t = c1 - 1; t >= c0; --t) {
             {
                 AttnBwdArgs q; memset(&q, 0, sizeof(q));

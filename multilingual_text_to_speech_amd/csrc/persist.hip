@@ -36,6 +36,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
+#include "persist_sync.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -45,16 +46,6 @@ namespace {
 constexpr int PS_THREADS = 512;
 constexpr int PS_WGS = 256;                 // one workgroup per CU; 4 LSTM units (16 gate columns) each: H = 1024
 constexpr int PS_ERR_OFF = 8192, PS_XP_OFF = 16384;     // workspace: [counters: 4 groups x (1 + 8) x 128 B][error word][exchange ...]
-constexpr unsigned PS_SPIN_MAX = 1u << 22;  // ~0.5 s of polling before a barrier gives up (error word, no hang)
-// The FIRST hand-off of a launch waits for something else: for every workgroup to become RESIDENT.  When a foreign kernel (another
-// stream's long-running kernel, RCCL's resident channels, another process) holds the LDS / registers of some CUs, the missing
-// workgroups start when it leaves - seconds, not microseconds - and nothing is wrong.  Round 6: the start-up hand-offs (grid barrier
-// epoch 1, pgen7's publish 1) get ~30 s of patience; every later hand-off is between resident workgroups and keeps the 0.5 s bound.
-constexpr unsigned PS_SPIN_START = 1u << 28;
-__device__ __forceinline__ unsigned ps_spin_limit(unsigned epoch) { return epoch <= 1u ? PS_SPIN_START : PS_SPIN_MAX; }
-#define PS_RLX __ATOMIC_RELAXED
-#define PS_AGENT __HIP_MEMORY_SCOPE_AGENT
-
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t ps_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x27000);
 }
@@ -129,63 +120,6 @@ __device__ __forceinline__ void ps_publish4(__amdgpu_buffer_rsrc_t r, int row, i
     } else {
         ps_st16_sc1(r, ps_xp_off(row, k, nkb), v);
     }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// Grid barrier: two levels (8 groups by blockIdx % 8, observed = XCD; correctness does not depend on it), monotonic counters
-// zeroed by the host before the launch, relaxed agent-scope atomics, sc1 payload drained by every wave before the arrive.
-// Returns false when the spin bound was hit or another workgroup reported an error (every workgroup then leaves the kernel).
-// ---------------------------------------------------------------------------------------------------------------------------
-struct PsSync { unsigned* cnt; unsigned* err; };      // cnt[0] global, cnt[32 * (1 + g)] group g; err: device error word (0 = ok)
-
-
-// arrive half: every wave drains its write-through stores, one lane bumps the counters (call BEFORE issuing loads that need not be
-// complete at the barrier: the drain waits for everything this wave has in flight)
-__device__ __forceinline__ void ps_bar_arrive(const PsSync& s, unsigned epoch) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned nwg = gridDim.x, ng = 8, g = blockIdx.x % ng, gsz = nwg / ng;
-        const unsigned prev = __hip_atomic_fetch_add(s.cnt + 32 * (1 + g), 1u, PS_RLX, PS_AGENT);
-        if (prev + 1 == epoch * gsz) __hip_atomic_fetch_add(s.cnt, 1u, PS_RLX, PS_AGENT);
-    }
-}
-// wait half (thread 0 polls the top counter)
-__device__ __forceinline__ bool ps_bar_wait(const PsSync& s, unsigned epoch) {
-    if (threadIdx.x == 0) {
-        const unsigned target = epoch * 8u, limit = ps_spin_limit(epoch);
-        unsigned spins = 0;
-        while (__hip_atomic_load(s.cnt, PS_RLX, PS_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 1023u) == 0 && (spins > limit || __hip_atomic_load(s.err, PS_RLX, PS_AGENT) != 0)) {
-                __hip_atomic_store(s.err, 2u, PS_RLX, PS_AGENT);
-                break;
-            }
-        }
-    }
-    __syncthreads();
-    return __hip_atomic_load(s.err, PS_RLX, PS_AGENT) == 0;
-}
-
-__device__ __forceinline__ bool ps_barrier(const PsSync& s, unsigned epoch) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned nwg = gridDim.x, ng = 8, g = blockIdx.x % ng, gsz = nwg / ng;
-        const unsigned prev = __hip_atomic_fetch_add(s.cnt + 32 * (1 + g), 1u, PS_RLX, PS_AGENT);
-        if (prev + 1 == epoch * gsz) __hip_atomic_fetch_add(s.cnt, 1u, PS_RLX, PS_AGENT);
-        const unsigned target = epoch * ng, limit = ps_spin_limit(epoch);
-        unsigned spins = 0;
-        while (__hip_atomic_load(s.cnt, PS_RLX, PS_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 1023u) == 0 && (spins > limit || __hip_atomic_load(s.err, PS_RLX, PS_AGENT) != 0)) {
-                __hip_atomic_store(s.err, 2u, PS_RLX, PS_AGENT);
-                break;
-            }
-        }
-    }
-    __syncthreads();
-    return __hip_atomic_load(s.err, PS_RLX, PS_AGENT) == 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -1299,3 +1233,19 @@ MTTS_API int mtts_decoder_persist_status(const void* persist_ws, void* stream) {
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
     return (int)v;
 }
+
+// ---- host helpers shared with the persistent decoder BACKWARD (pbwd.hip) -----------------------------------------------------------
+bool ps_ready_ext(const void* fn, int threads, size_t lds) { return ps_kernel_ready(fn, threads, lds); }
+// One persistent launch on `s` with the forward's workspace (a.persist_ws: counters zeroed here, error word = the decode's): ordered
+// behind the device's previous persistent launch when that went to another stream; `go` issues the kernel.
+int ps_run_launch(const DecoderArgs& a, hipStream_t s, void (*go)(void* ctx, unsigned* cnt, unsigned* err, hipStream_t s), void* ctx) {
+    char* ws = (char*)a.persist_ws;
+    unsigned* err = ps_err_word(a);
+    std::lock_guard<std::mutex> launch_lk(ps_dev().launch_mu);
+    MTTS_TRY(ps_serialize(s));
+    MTTS_CHECK_HIP(hipMemsetAsync(ws, 0, PS_ERR_OFF, s));
+    go(ctx, (unsigned*)ws, err, s);
+    MTTS_CHECK_LAUNCH("persistent launch");
+    return ps_launched(s);
+}
+

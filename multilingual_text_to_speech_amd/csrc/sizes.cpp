@@ -58,6 +58,7 @@ MTTS_API long mtts_decoder_grad_buffer_elems(const DecoderArgs* fwd, const Decod
         {"dc_att", 2 * B * H}, {"dc_gen", 2 * B * H}, {"dh_carry_att", 2 * B * H}, {"dh_carry_gen", 2 * B * H},
         {"dMt", B * L * A}, {"dU_slab", B * nch * A * a.ksz}, {"dv_slab", B * nch * A}, {"dbias_slab", B * nch * A}, {"dU", A * (long)a.ksz},
         {"dpren", n * T * B * P}, {"colsum_ws", mtts_colsum_workspace_floats((int)cmax)}, {"dmemory", B * L * Dm},
+        {"part_ring", (long)g.part_ring_slots * (ksc * B * Dm + ksb * B * H)},
     };
     for (const Row& r : rows)
         if (strcmp(r.name, field) == 0) return r.n;

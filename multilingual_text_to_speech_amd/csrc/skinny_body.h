@@ -246,7 +246,13 @@ __device__ __forceinline__ void fwd_cell(const SkinnyArgs& p, const float (&red)
     if (p.y_out) p.y_out[(long)row * p.ldy + u] = carried ? 0.f : ho;
 }
 
-template <int MT>
+// write-through (sc1) store of one float: data that ANOTHER workgroup of the same launch reads (persistent backward, pbwd.hip)
+__device__ __forceinline__ void sk_store(float* p, float v, bool sc1) {
+    if (sc1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+template <int MT, int SC1 = 0>
 __device__ __forceinline__ void bwd_cell(const SkinnyArgs& p, const float (&red)[NW][MT * 16][17], int rr, int cc, int row,
                                          int u, const BwdPre& f) {
     if (!f.valid) return;
@@ -287,7 +293,7 @@ __device__ __forceinline__ void bwd_cell(const SkinnyArgs& p, const float (&red)
         const int lane_s = (4 * (u & 12) + (row & 15)) * 4 + (u & 3);
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-            p.dg_pack_out[(tile + ((g * p.H + u) >> 4)) * 256 + lane_s] = dgv[g];
+            sk_store(p.dg_pack_out + (tile + ((g * p.H + u) >> 4)) * 256 + lane_s, dgv[g], SC1 != 0);
     }
     p.dc_out[hi] = dct * fg + dc_carry;
     if (p.dh_carry_out) p.dh_carry_out[hi] = dh_carry;
@@ -295,7 +301,9 @@ __device__ __forceinline__ void bwd_cell(const SkinnyArgs& p, const float (&red)
 
 // Body of the skinny kernel for workgroup (column block cb, row tile, K split ks); `red` is the workgroup's LDS reduction buffer.
 // PLAIN = 1: the plain-product epilogue only (p.lstm == 0 is the caller's promise): the fused attention-backward launch
-template <int MT, int DEPTH = 4, int PK = 0, int PLAIN = 0>
+// SC1 = 1: the outputs another workgroup of the SAME launch consumes (raw / K-split partial sums, the cell backward's packed copy of dG)
+// are stored write-through (persistent backward, pbwd.hip); 0: plain stores (a kernel boundary publishes them).
+template <int MT, int DEPTH = 4, int PK = 0, int PLAIN = 0, int SC1 = 0>
 __device__ __forceinline__ void skinny_body(const SkinnyArgs& p, float (&red)[NW][MT * 16][17], const int cb, const int row_tile,
                                             const int ks) {
     const int tid = threadIdx.x;
@@ -393,7 +401,7 @@ __device__ __forceinline__ void skinny_body(const SkinnyArgs& p, float (&red)[NW
             const int row = row0 + rr, col = cb * 16 + cc;
             if (row >= p.B || col >= p.N) continue;
             float v = red_sum<MT>(red, rr, cc);
-            if (p.ksplit > 1) { p.out[(long)ks * p.out_ks + (long)row * p.ldo + col] = v; continue; }
+            if (p.ksplit > 1) { sk_store(p.out + (long)ks * p.out_ks + (long)row * p.ldo + col, v, SC1 != 0); continue; }
             if (p.bias) v += p.bias[col];
             v = apply_act(p.act, v);
             if (p.mask) v = p.mask[(long)row * p.ldmask + col] ? v * p.mask_scale : 0.f;
@@ -404,12 +412,12 @@ __device__ __forceinline__ void skinny_body(const SkinnyArgs& p, float (&red)[NW
     if (p.lstm == 2) {
         {
             const int rr = tid >> 4, cc = tid & 15;
-            bwd_cell<MT>(p, red, rr, cc, row0 + rr, cb * 16 + cc, bp0);
+            bwd_cell<MT, SC1>(p, red, rr, cc, row0 + rr, cb * 16 + cc, bp0);
         }
         if (MT * 256 > NT) {
             const int e = tid + NT;
             const int rr = e >> 4, cc = e & 15;
-            bwd_cell<MT>(p, red, rr, cc, row0 + rr, cb * 16 + cc, bp1);
+            bwd_cell<MT, SC1>(p, red, rr, cc, row0 + rr, cb * 16 + cc, bp1);
         }
         return;
     }

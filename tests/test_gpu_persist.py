@@ -218,3 +218,52 @@ def test_persistent_decode_beside_a_foreign_resident_kernel_starts_late_instead_
     kernels.check_device_errors()                     # raises MttsError if a persistent kernel's barrier gave up
     assert torch.equal(out, base)
     assert waited >= 1.0, f'the decode finished in {waited:.2f} s: the occupant did not hold the CUs (test set-up)'
+
+
+_BWD_CHILD = r'''
+import sys, torch
+sys.path.insert(0, %(root)r)
+import bench
+from multilingual_text_to_speech_amd.params import presets, Params as hp
+from multilingual_text_to_speech_amd.modules.tacotron2 import Tacotron, TacotronLoss
+preset, B, L, T = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+presets.apply(preset, speaker_number=91)
+torch.manual_seed(11)
+dev = torch.device('cuda:0')
+model = Tacotron().to(dev).train()
+batch = bench.synthetic_batch(hp, B, L, T, dev, seed=5)
+crit = TacotronLoss(hp.guided_attention_steps, hp.guided_attention_toleration, hp.guided_attention_gain)
+torch.manual_seed(12)                                   # dropout draws
+post, pre, stop, align, spk, enc = model(batch['text'], batch['text_length'], batch['target'], batch['target_length'],
+                                         batch['speakers'], batch['languages'], 1.0)
+loss, _ = crit(batch['text_length'].to(dev), batch['target_length'].to(dev), pre, batch['target'], post, batch['target'], stop, batch['stop'],
+               align, batch['speakers'], spk, enc, None)
+loss.backward()
+torch.cuda.synchronize()
+from multilingual_text_to_speech_amd import kernels
+kernels.check_device_errors()
+torch.save({k: p.grad.cpu() for k, p in model.named_parameters() if p.grad is not None}, sys.argv[1])
+'''
+
+
+@pytest.mark.parametrize('preset,B,L,T', [('shared_training', 64, 40, 100), ('generated_switching', 40, 30, 61), ('shared_training', 33, 120, 50)])
+def test_persistent_backward_equals_the_per_step_launches(tmp_path, preset, B, L, T):
+    """Round 6 (csrc/pbwd.hip, opt-in MTTS_PBWD=1): chain A of the decoder backward (attention / attention LSTM) as ONE resident launch
+    per chunk against the per-step launch schedule on the same model, batch and dropout draws.  The stages run the per-step kernels' bodies with the same K
+    splits, so every gradient agrees to accumulation-order noise of the L2 atomics (dq, dcum) - 1e-4 of the tensor's largest element (observed: 1.5e-5 on the attention bias at 120 positions, 0 elsewhere);
+    three chunks with a ragged last one, 64 / 40 / 33 rows (four, three and a ragged third row tile)."""
+    def run(name, env_add):
+        path = str(tmp_path / f'{name}.pt')
+        r = subprocess.run([sys.executable, '-c', _BWD_CHILD % {'root': ROOT}, path, preset, str(B), str(L), str(T)], env=dict(os.environ, **env_add),
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        return torch.load(path)
+    pers, steps = run('pbwd', {'MTTS_PBWD': '1'}), run('steps', {'MTTS_PBWD': '0'})
+    assert set(pers) == set(steps)
+    bad = []
+    for k, v in pers.items():
+        assert torch.isfinite(v).all(), k
+        d = (v.double() - steps[k].double()).abs().max().item()
+        if d > 1e-4 * steps[k].abs().max().item() + 1e-12:
+            bad.append(f'{k}: {d:.3e} of {steps[k].abs().max().item():.3e}')
+    assert not bad, bad[:12]
