@@ -39,7 +39,6 @@ struct PbwdArgs {
     int ring_slots, T, a0, a1, ksb, ksc, n_attn, nch, zone, mask_a;
     float *dc_att, *dhc_att;
     PsSync sync;
-    long long* clk;                                 // harness (MTTS_PBWD_CLOCK=1): stage stamps of workgroup 0, [iteration][8]
 };
 
 __device__ __forceinline__ float* ring_at(const PbwdArgs& P, int t) { return P.ring + (long)(t % P.ring_slots) * P.slot; }
@@ -61,16 +60,12 @@ __global__ __launch_bounds__(NT, 4) void pbwd_kernel(PbwdArgs P_unused) {
     const int id = blockIdx.x;
     unsigned epoch = 0;
     int n_it;
-    long long* clk = nullptr;
     {
         const PbwdArgs& P = pb_args();
         if (!ps_barrier(P.sync, ++epoch)) return;                  // start-up: every workgroup resident
         n_it = P.a1 - P.a0;
-        clk = (id == 0) ? P.clk : nullptr;
     }
-#define PB_STAMP(n) do { if (clk && threadIdx.x == 0) clk[i * 8 + (n)] = wall_clock64(); } while (0)
     for (int i = 0; i < n_it; ++i) {
-        PB_STAMP(0);
         // ---------------- stage 1: attention backward of step tA
         {
             const PbwdArgs& P = pb_args();
@@ -84,12 +79,10 @@ __global__ __launch_bounds__(NT, 4) void pbwd_kernel(PbwdArgs P_unused) {
                 attn_bwd_body(q, sm, id / P.nch, id % P.nch);
             }
         }
-        PB_STAMP(1);
         {
             const PbwdArgs& P = pb_args();
             if (!ps_barrier(P.sync, ++epoch)) return;
         }
-        PB_STAMP(2);
         // ---------------- stage 2: dq W_q + attention-LSTM cell backward of step tA -> dG_att(tA)
         {
             const PbwdArgs& P = pb_args();
@@ -107,12 +100,10 @@ __global__ __launch_bounds__(NT, 4) void pbwd_kernel(PbwdArgs P_unused) {
             if (P.mask_a & 2) k.cmask += tA * P.BH;
             if (id < cbs_h * rt_cells) skinny_body<1, 1, 2, 0, 1>(k, red1, id % cbs_h, id / cbs_h, 0);
         }
-        PB_STAMP(3);
         {
             const PbwdArgs& P = pb_args();
             if (!ps_barrier(P.sync, ++epoch)) return;
         }
-        PB_STAMP(4);
         // ---------------- stage 3: ctx-columns of dG_att(tA) (what the next attention backward waits for) ...
         {
             const PbwdArgs& P = pb_args();
@@ -125,7 +116,6 @@ __global__ __launch_bounds__(NT, 4) void pbwd_kernel(PbwdArgs P_unused) {
                 if (id < cbs_c * P.ksc) skinny_body<4, 2, 1, 1, 1>(k, red4, id % cbs_c, 0, id / cbs_c);
             }
         }
-        PB_STAMP(5);
         {
             const PbwdArgs& P = pb_args();
             ps_bar_arrive(P.sync, ++epoch);
@@ -143,14 +133,11 @@ __global__ __launch_bounds__(NT, 4) void pbwd_kernel(PbwdArgs P_unused) {
                 if (id < cbs_h * P.ksb) skinny_body<4, 2, 1, 1, 1>(k, red4, id % cbs_h, 0, id / cbs_h);
             }
         }
-        PB_STAMP(6);
         {
             const PbwdArgs& P = pb_args();
             if (!ps_bar_wait(P.sync, epoch)) return;
         }
-        PB_STAMP(7);
     }
-#undef PB_STAMP
 }
 
 size_t pbwd_lds(const AttnBwdArgs& q) {
@@ -244,26 +231,8 @@ int pbwd_launch(const DecoderArgs& a, const DecoderGradArgs& g, const PbwdChunk&
     };
     cell(P.cell_a, a.gates_att, a.c_att, g.dG_att, g.dG_att_p, g.dHA, a.att_hmask, a.att_cmask, P.mask_a);
     P.cell_a.seg[0] = SkSeg{g.dq_all, g.w_query_T, A, A, A, 0, 0};
-    static const bool clock_on = [] { const char* e = getenv("MTTS_PBWD_CLOCK"); return e && e[0] == '1'; }();
-    static long long* clk_dev = nullptr;
-    static int clk_launches = 0;
-    if (clock_on && !clk_dev) { (void)hipMalloc((void**)&clk_dev, 4096 * 8 * sizeof(long long)); }
-    const bool clk_this = clock_on && clk_dev && c.a1 - c.a0 >= 8 && ++clk_launches == 6;      // one full launch in the middle of a backward
-    if (clk_this) { (void)hipMemsetAsync(clk_dev, 0, 4096 * 8 * sizeof(long long), s); P.clk = clk_dev; }
     Go go{&P, pbwd_lds(P.attn)};
     MTTS_TRY(ps_run_launch(a, s, pbwd_go, &go));
-    if (clk_this) {
-        (void)hipStreamSynchronize(s);
-        const int n = c.a1 - c.a0;
-        std::vector<long long> h((size_t)n * 8);
-        (void)hipMemcpy(h.data(), clk_dev, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
-        const char* names[7] = {"attention", "barrier 1", "cell", "barrier 2", "ctx-columns", "h-columns", "barrier 3 wait"};
-        double sum[7] = {0}; int cnt = 0;
-        for (int i = 2; i < n - 1; ++i, ++cnt) for (int k = 0; k < 7; ++k) sum[k] += (double)(h[(size_t)i * 8 + k + 1] - h[(size_t)i * 8 + k]);
-        double tot = 0;
-        for (int k = 0; k < 7; ++k) { fprintf(stderr, "[mtts pbwd clock] %-12s %6.2f us\n", names[k], sum[k] / cnt * 0.01); tot += sum[k] / cnt * 0.01; }
-        fprintf(stderr, "[mtts pbwd clock] step         %6.2f us (workgroup 0, %d iterations)\n", tot, cnt);
-    }
     return 0;
 }
 

@@ -1,6 +1,7 @@
 """Timing instrumentation of the micro-benchmark harnesses lives HERE, not in the product sources.
 
-The stage clocks (PS_PROF / PN_PROF / ATB_PROF: shader-clock stamps between the stages of a kernel) and the stream knock-outs (LF_NO_X /
+The stage clocks (PS_PROF / PN_PROF / ATB_PROF / PB_PROF: clock stamps between the stages of a kernel; PB_PROF = the persistent decoder
+backward of round 6: build the library with MTTS_EXTRA_FLAGS=-DPB_PROF from the instrumented copy and run with MTTS_PBWD=1 MTTS_PBWD_CLOCK=1) and the stream knock-outs (LF_NO_X /
 _W / _MFMA / _EPI / _STAGE: what a fused LSTM step costs without one of its streams) used to sit behind #ifdef in csrc/persist.hip,
 csrc/lstm_step.hip and csrc/attention_bwd_body.h.  They are now patches under scripts/mb/instrumentation/:
 
@@ -13,11 +14,11 @@ import os, re, subprocess, sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, '..', '..', 'multilingual_text_to_speech_amd', 'csrc')
-FILES = ['persist.hip', 'lstm_step.hip', 'attention_bwd_body.h']
+FILES = ['persist.hip', 'lstm_step.hip', 'attention_bwd_body.h', 'pbwd.hip']
 COPIES = ['attention_bwd.hip']      # sources that only INCLUDE an instrumented file: copied next to it so that the include resolves to the copy
-SYMS = ('LF_NO_X', 'LF_NO_W', 'LF_NO_MFMA', 'LF_NO_EPI', 'LF_NO_STAGE', 'PS_PROF', 'PN_PROF', 'ATB_PROF')
-STAMP = re.compile(r'^\s*(PD_STAMP|PN_STAMP|ATB_STAMP|PS_STAMP)\(.*\);\s*(//.*)?$')
-STAMP_DEF = re.compile(r'^\s*#\s*(define|undef)\s+(PD_STAMP|PN_STAMP|ATB_STAMP|PS_STAMP)\b')
+SYMS = ('LF_NO_X', 'LF_NO_W', 'LF_NO_MFMA', 'LF_NO_EPI', 'LF_NO_STAGE', 'PS_PROF', 'PN_PROF', 'ATB_PROF', 'PB_PROF')
+STAMP = re.compile(r'^\s*(PD_STAMP|PN_STAMP|ATB_STAMP|PS_STAMP|PB_STAMP)\(.*\);\s*(//.*)?$')
+STAMP_DEF = re.compile(r'^\s*#\s*(define|undef)\s+(PD_STAMP|PN_STAMP|ATB_STAMP|PS_STAMP|PB_STAMP)\b')
 
 
 def strip_text(text):

@@ -65,6 +65,8 @@ def test_buffer_size_queries_cover_every_caller_allocated_buffer(library):
     assert q('prenet_act') == 600 * 64 * 256 and q('prenet_wp0') == 256 * 80 and q('prenet_mask') == 600 * 64 * 256
     g = _C.DecoderGradArgs()
     g.ksb, g.ksb_ctx, g.nch = 4, 7, 4
+    g.part_ring_slots = library.mtts_decoder_bwd_ring_slots()
+    assert g.part_ring_slots >= 50
     qg = lambda f: library.mtts_decoder_grad_buffer_elems(ctypes.byref(a), ctypes.byref(g), f.encode())
     assert qg('part_att') == 7 * 64 * 544 + 4 * 64 * 1024 and qg('dU_slab') == 64 * 4 * 128 * 31 and qg('dpren') == 2 * 600 * 64 * 256
     for name, ctype in _C.DecoderGradArgs._fields_:
