@@ -665,6 +665,10 @@ def main():
 
     for _ in range(args.warmup):
         train_step(model, crit, opt, buckets, batch, hp)
+    # steady state reached: one full pass of Python's garbage collector now, survivors frozen - otherwise the collector's first
+    # generation-2 pass (85 ms of host time, the GPU idle meanwhile) lands ~10 steps into the run, i.e. inside the timed steps
+    from multilingual_text_to_speech_amd.utils import settle_host_heap
+    settle_host_heap()
     lib = _C.lib()
     n_samples = 16
     _C.check(lib.mtts_prof_begin(n_samples * args.steps, max(1, T // n_samples)), 'prof_begin')

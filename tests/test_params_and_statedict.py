@@ -129,3 +129,22 @@ def test_models_outside_the_persistent_kernels_geometry_say_so_once():
         tacotron2.Tacotron()
         msgs = [str(c.message) for c in caught if 'persistent decoder kernels' in str(c.message)]
     assert len(msgs) == 1 and '292' in msgs[0]
+
+
+def test_settle_host_heap_freezes_the_long_lived_objects(monkeypatch):
+    """utils.settle_host_heap: one full collection, survivors into the collector's permanent generation (the first generation-2 pass of
+    a training run otherwise costs one whole train step of GPU idle time: profiles/r06_host_gc_outlier.txt); MTTS_HOST_GC_FREEZE=0 = off;
+    bench.py calls it between the warm-up and the timed steps, train.py two steps into a run / an epoch."""
+    import gc
+    from multilingual_text_to_speech_amd.utils import settle_host_heap
+    gc.unfreeze()
+    monkeypatch.setenv('MTTS_HOST_GC_FREEZE', '0')
+    assert settle_host_heap() == 0 and gc.get_freeze_count() == 0
+    monkeypatch.setenv('MTTS_HOST_GC_FREEZE', '1')
+    n = settle_host_heap()
+    assert n > 1000 and gc.get_freeze_count() == n and gc.isenabled()
+    gc.unfreeze()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, 'bench.py')).read()
+    assert src.index('settle_host_heap()') < src.index('t0 = time.perf_counter()\n    sync_each')        # before the timed region
+    assert 'settle_host_heap()' in open(os.path.join(root, 'train.py')).read()

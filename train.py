@@ -20,6 +20,7 @@ os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')      # kernel arguments in d
 import torch
 
 from bench import synthetic_batch, train_step
+from multilingual_text_to_speech_amd.utils import settle_host_heap
 
 
 def cos_decay(global_step, decay_steps):
@@ -119,6 +120,8 @@ def main():
         batch = batches[step % len(batches)] if batches else synthetic_batch(hp, per, args.chars, args.frames, device, seed=step * world + rank)
         t0 = time.time()
         loss = train_step(model, crit, opt, buckets, batch, hp, teacher_forcing_ratio(hp, step))
+        if step == 1:
+            settle_host_heap()           # steady state: the garbage collector's first full pass happens here, not 85 ms into some later step
         torch.cuda.synchronize()
         check_device_errors(device)
         if rank == 0:
@@ -255,6 +258,8 @@ def train_on_dataset(args, hp, datasets, model, opt, crit, buckets, rank, world,
             loss = train_step(model, crit, opt, buckets, batch, hp, teacher_forcing_ratio(hp, global_step))
             frames += int(batch['target_length'].sum())
             done += 1
+            if done == 2:
+                settle_host_heap()       # once per epoch, two steps in (the evaluation / checkpoint of the previous epoch left new long-lived objects)
         torch.cuda.synchronize()
         check_device_errors(device)
         if hp.learning_rate_decay_start - hp.learning_rate_decay_each < epoch * len(train_data):
