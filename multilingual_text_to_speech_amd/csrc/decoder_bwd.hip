@@ -255,7 +255,13 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
         MTTS_CHECK_HIP(hipEventRecord(ev, s));
         MTTS_CHECK_HIP(hipStreamWaitEvent(sb, ev, 0));
     }
-    const int nchunks = (T + CH - 1) / CH;
+    // Chunk bounds (ascending; chunk c = steps [bounds[c], bounds[c + 1]), processed from the last one down): uniform chunks of CH steps, the
+    // ragged one at the end of the decode.  (Round 6 measured a ramp - 8, 16, 32 steps first so that chain A starts after 8 steps of chain B
+    // instead of 48, a 16-step chunk last so that fewer weight-gradient GEMMs trail chain A: no difference, profiles/r06_chunk_ramp_ab.txt.)
+    std::vector<int> bounds;
+    for (int t = 0; t < T; t += CH) bounds.push_back(t);
+    bounds.push_back(T);
+    const int nchunks = (int)bounds.size() - 1;
     std::vector<hipEvent_t> chunk_ev(nchunks);
     // ---- weight gradients ride a third, least-priority stream: every chunk's dG^T x product is queued as soon as its chain
     //      has produced the chunk's dG, and accumulates (beta = 1) into the gradient; one workgroup per CU (nosplit) so that
@@ -291,7 +297,7 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
     tmark(s, "start", -1);
     const float* pren = a.prenet_act[a.n_prenet - 1];
     auto submit_B = [&](int c) -> int {
-        const int c0 = c * CH, c1 = std::min(T, c0 + CH), n = c1 - c0;
+        const int c0 = bounds[c], c1 = bounds[c + 1], n = c1 - c0;
         for (int t = c1 - 1; t >= c0; --t) {
             SkinnyArgs k; memset(&k, 0, sizeof(k));
             k.B = B; k.H = H; k.lstm = 2; k.nseg = 0; k.ksplit = 1;
@@ -350,7 +356,7 @@ MTTS_API int mtts_decoder_bwd(const DecoderArgs* fwd, const DecoderGradArgs* gra
     };
     const bool persistent_a = pbwd_supported(a, g);
     auto submit_A = [&](int c) -> int {
-        const int c0 = c * CH, c1 = std::min(T, c0 + CH);
+        const int c0 = bounds[c], c1 = bounds[c + 1];
         MTTS_CHECK_HIP(hipStreamWaitEvent(s, chunk_ev[c], 0));
         tmark(s, "A start", c);
         if (persistent_a) {      // round 6 (csrc/pbwd.hip): the chunk's steps of chain A in ONE resident launch
