@@ -71,7 +71,8 @@ def train_step(model, crit, opt, buckets, batch, hp, teacher_forcing=1.0):
     post, pre, stop, align, spk, enc = model(batch['text'], batch['text_length'], batch['target'], batch['target_length'],
                                              batch['speakers'], batch['languages'], teacher_forcing)
     dev = post.device
-    loss, _ = crit(batch['text_length'].to(dev), batch['target_length'].to(dev), pre, batch['target'], post, batch['target'],
+    # the sequence lengths stay host tensors: the loss moves them to the device without synchronising the stream (kernels.to_device_async)
+    loss, _ = crit(batch['text_length'], batch['target_length'], pre, batch['target'], post, batch['target'],
                    stop, batch['stop'], align, batch['speakers'], spk, enc, None)
     loss.backward()
     if buckets is not None:

@@ -8,6 +8,7 @@ import os
 import torch
 
 from . import _C
+from . import kernels as K
 from ._C import check, lib, ptr, require_gpu, stream_ptr
 
 
@@ -203,7 +204,7 @@ class DecoderFn(torch.autograd.Function):
         # frame fed at step t: zero frame at t=0, target[t-1] afterwards (tacotron2.py:129-131), time-major
         frames_in = torch.zeros(T, B, M, dtype=torch.float32, device=dev)
         frames_in[1:] = target[:, :T - 1].transpose(0, 1)
-        lengths32 = lengths.to(device=dev, dtype=torch.int32).contiguous()
+        lengths32 = K.to_device_async(lengths, dev, torch.int32).contiguous()
         run_decoder(st, w, memory, lengths32, frames_in, teacher, masks, cfg, 0, T)
         ctx.st, ctx.w, ctx.masks, ctx.cfg, ctx.teacher, ctx.n_prenet = st, w, masks, cfg, teacher, n_prenet
         ctx.memory, ctx.lengths32, ctx.frames_in = memory, lengths32, frames_in
@@ -270,7 +271,7 @@ class GraphedDecode:
     def load(self, memory, lengths, w, masks):
         """Copy this call's inputs into the persistent buffers (on the session stream)."""
         self.memory.copy_(memory)
-        self.lengths32.copy_(lengths.to(device=self.memory.device, dtype=torch.int32))
+        self.lengths32.copy_(K.to_device_async(lengths, self.memory.device, torch.int32))
         self.w_out.copy_(w['w_out']); self.b_out.copy_(w['b_out'])
         for k, buf in self.masks.items():
             m = masks.get(k)
@@ -356,7 +357,7 @@ def _decode_free_loop(memory, lengths, w, cfg, masks, max_frames, stop_frames, c
             masks = mask_fn(cap)
         st = DecoderState(B, L, cap, (M, P, H, A, Dm, ksz, C), dev, len(w['prenet_w']), save_gates=False, fast=False,
                           kq=cfg.get('kq', 8), precision=cfg.get('precision', _C.get_precision()))
-    lengths32 = lengths.to(device=dev, dtype=torch.int32).contiguous()
+    lengths32 = K.to_device_async(lengths, dev, torch.int32).contiguous()
     # The stop rule runs ON THE DEVICE (mtts_stop_rule_update: per-sample armed / done counters in a device int array); after
     # each chunk ONE int - how many utterances are still running - travels to the host through a copy stream, while the device
     # already runs the NEXT chunk (speculatively).

@@ -172,7 +172,9 @@ def global_mean_scale(n_local, device):
         return torch.ones(1, dtype=torch.float32, device=device)
     world = dist.get_world_size()
     if torch.is_tensor(n_local):
-        local = n_local.detach().to(device=device, dtype=torch.float32).reshape(1)
+        from .kernels import to_device_async          # no stream synchronisation for a host-side count
+        local = to_device_async(n_local.detach(), device, torch.float32).reshape(1) if torch.device(device).type == 'cuda' else \
+            n_local.detach().to(device=device, dtype=torch.float32).reshape(1)
     else:
         local = torch.tensor([float(n_local)], dtype=torch.float32, device=device)
     total = local.clone()

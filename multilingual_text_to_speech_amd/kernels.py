@@ -4,6 +4,7 @@ Every compute step goes through libmtts_hip.so; torch is used for device memory,
 autograd bookkeeping only.  Activations are channel-last ([N, L, C]).
 """
 import ctypes
+import os
 
 import torch
 
@@ -114,6 +115,57 @@ def linear(x, weight, bias=None, act='identity', mask=None, mask_scale=1.0):
 # ------------------------------------------------------------------------------------------------
 
 _ERR_FLAGS = {}
+
+
+class _PinnedRing:
+    """Small host -> device copies WITHOUT a stream synchronisation.  `cpu_tensor.to(device)` of pageable memory is hipMemcpyAsync +
+    hipStreamSynchronize: the host waits until everything queued on the stream has finished - a train step did that nine times (sequence
+    lengths in the encoder, the decoder, the output mask and the loss; the optimizer's pointer table), each one ending the host's run-ahead
+    and leaving the GPU idle until the next launch arrives (scripts/dbg_sync_points.py).  Here the values go through a ring of pinned
+    staging buffers: a CPU copy into the slot, an asynchronous copy to the device, an event that guards the slot's reuse."""
+    SLOTS, BYTES = 32, 1 << 16
+
+    def __init__(self):
+        self.slots, self.next = [], 0
+
+    def copy(self, src, device, dtype=None):
+        dtype = dtype or src.dtype
+        src = src.detach().to(dtype=dtype).contiguous().reshape(-1)
+        nbytes = src.numel() * src.element_size()
+        if nbytes > self.BYTES or nbytes == 0:
+            return src.to(device)
+        if len(self.slots) < self.SLOTS:
+            self.slots.append(dict(buf=torch.empty(self.BYTES, dtype=torch.uint8).pin_memory(), event=None))
+            slot = self.slots[-1]
+        else:
+            slot = self.slots[self.next]
+            self.next = (self.next + 1) % self.SLOTS
+            if slot['event'] is not None:
+                slot['event'].synchronize()              # the copy out of this slot was queued 32 copies ago: long done
+        view = slot['buf'][:nbytes].view(dtype)
+        view.copy_(src)
+        out = torch.empty(src.numel(), dtype=dtype, device=device)
+        with torch.cuda.device(device):
+            out.copy_(view, non_blocking=True)
+            if slot['event'] is None:
+                slot['event'] = torch.cuda.Event()
+            slot['event'].record()
+        return out
+
+
+_H2D = _PinnedRing()
+_H2D_BLOCKING = os.environ.get('MTTS_H2D_BLOCKING', '0') == '1'      # A/B: the synchronising copies of round 5
+
+
+def to_device_async(t, device, dtype=None):
+    """`t.to(device=device, dtype=dtype)` for the small host tensors of a step (lengths, ids, pointer tables) without synchronising the
+    stream; tensors that already live on the device are converted in place of a copy."""
+    if t is None:
+        return None
+    if t.is_cuda or _H2D_BLOCKING:
+        return t.to(device=device, dtype=dtype or t.dtype)
+    shape = t.shape
+    return _H2D.copy(t, torch.device(device), dtype).reshape(shape)
 
 
 def _err_flag(device):
@@ -378,7 +430,7 @@ class BiLstmFn(torch.autograd.Function):
         dev = x.device
         a = _C.BiLstmArgs()
         a.B, a.L, a.Cin, a.H = B, L, Cin, H
-        lengths32 = lengths.to(device=dev, dtype=torch.int32).contiguous()
+        lengths32 = to_device_async(lengths, dev, torch.int32).contiguous()
         a.x, a.lengths = ptr(x_tm), ptr(lengths32)
         ws = [(w_ih.contiguous(), w_hh.contiguous(), b_ih.contiguous(), b_hh.contiguous()),
               (w_ih_r.contiguous(), w_hh_r.contiguous(), b_ih_r.contiguous(), b_hh_r.contiguous())]

@@ -245,7 +245,7 @@ class Tacotron(Module):
         pre_prediction = prediction.transpose(1, 2)
         post_prediction = post.transpose(1, 2)
 
-        target_mask = lengths_to_mask(target_length.to(stop_token.device), target.size(2))
+        target_mask = lengths_to_mask(K.to_device_async(target_length, stop_token.device), target.size(2))
         stop_token = stop_token.masked_fill(~target_mask, 1000)
         target_mask = target_mask.unsqueeze(1).float()
         pre_prediction = pre_prediction * target_mask

@@ -26,8 +26,9 @@ class TacotronLossFn(torch.autograd.Function):
         nblk = 1024
         partials = torch.empty(nblk * 4, dtype=torch.float32, device=dev)
         out = torch.empty(5, dtype=torch.float32, device=dev)
-        tl = text_len.to(device=dev, dtype=torch.int32).contiguous()
-        fl = target_len.to(device=dev, dtype=torch.int32).contiguous()
+        from .kernels import to_device_async
+        tl = to_device_async(text_len, dev, torch.int32).contiguous()
+        fl = to_device_async(target_len, dev, torch.int32).contiguous()
         a.pre, a.post, a.target, a.stop, a.stop_target, a.align = ptr(pre), ptr(post), ptr(target), ptr(stop), ptr(stop_target), ptr(align)
         a.post_target = ptr(post_target)
         a.text_len, a.target_len = ptr(tl), ptr(fl)
@@ -57,8 +58,9 @@ class MaskedCrossEntropyFn(torch.autograd.Function):
         pred = pred.contiguous()
         B, L, S = pred.shape
         dev = pred.device
-        spk = speakers.to(device=dev, dtype=torch.int64).contiguous()
-        lens = lengths.to(device=dev, dtype=torch.int32).contiguous()
+        from .kernels import to_device_async
+        spk = to_device_async(speakers, dev, torch.int64).contiguous()
+        lens = to_device_async(lengths, dev, torch.int32).contiguous()
         row_loss = torch.empty(B * L, 1, dtype=torch.float32, device=dev)
         dpred = torch.empty_like(pred)
         check(lib().mtts_masked_cross_entropy(ptr(pred), ptr(spk), ptr(lens), ptr(row_loss), ptr(dpred), B, L, S, ctypes.c_float(scale),
@@ -156,22 +158,29 @@ class FusedAdam(torch.optim.Adam):
         self._tables = {}               # the moment buffers were replaced: the cached device tables point at freed memory
 
     def _table(self, name, plist):
-        # the device table bakes in parameter, gradient AND moment pointers: all of them are part of the cache key
+        """Device tables of one launch: per-tensor pointers (parameter, gradient, both moments) and the chunk map.  The chunk map depends
+        on the sizes only and is built once.  The POINTERS change whenever the gradients are re-allocated (`zero_grad(set_to_none=True)`
+        does that every step): they are uploaded again - asynchronously, through the pinned ring of kernels.to_device_async; round 5
+        rebuilt all four tables with `torch.tensor(..., device=)` in that case, i.e. four stream synchronisations per optimizer step."""
+        from .kernels import to_device_async
         key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]['exp_avg'].data_ptr(), self.state[p]['exp_avg_sq'].data_ptr())
                     for p in plist)
+        sizes = tuple(p.numel() for p in plist)
         t = self._tables.get(name)
         if t is not None and t['key'] == key:
             return t
         dev = plist[0].device
-        ptrs, ct, co, cl = [], [], [], []
-        for i, p in enumerate(plist):
-            ptrs += list(key[i])
-            n = p.numel()
+        ptrs = torch.tensor([x for k in key for x in k], dtype=torch.int64)
+        if t is not None and t['sizes'] == sizes and t['ptrs'].device == dev:
+            t['ptrs'].copy_(to_device_async(ptrs, dev))      # stream-ordered behind the previous step's kernels, ahead of this step's
+            t['key'] = key
+            return t
+        ct, co, cl = [], [], []
+        for i, n in enumerate(sizes):
             for off in range(0, n, self.CHUNK):
                 ct.append(i); co.append(off); cl.append(min(self.CHUNK, n - off))
-        t = dict(key=key, n=len(ct),
-                 ptrs=torch.tensor(ptrs, dtype=torch.int64, device=dev), ct=torch.tensor(ct, dtype=torch.int32, device=dev),
-                 co=torch.tensor(co, dtype=torch.int64, device=dev), cl=torch.tensor(cl, dtype=torch.int32, device=dev),
+        up = lambda values, dtype: to_device_async(torch.tensor(values, dtype=dtype), dev) if len(values) * 8 <= (1 << 16) else torch.tensor(values, dtype=dtype, device=dev)
+        t = dict(key=key, sizes=sizes, n=len(ct), ptrs=to_device_async(ptrs, dev), ct=up(ct, torch.int32), co=up(co, torch.int64), cl=up(cl, torch.int32),
                  partials=torch.empty(len(ct), dtype=torch.float32, device=dev))
         self._tables[name] = t
         return t
