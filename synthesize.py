@@ -86,6 +86,8 @@ if __name__ == '__main__':
     args = ap.parse_args()
     from multilingual_text_to_speech_amd.utils import build_model
     model = build_model(args.checkpoint).eval()
+    from multilingual_text_to_speech_amd.utils import settle_host_heap
+    settle_host_heap()      # the garbage collector's full pass over the model's objects now, not in the middle of some utterance's decode loop
     if args.batch > 1:
         lines = [l for l in sys.stdin if l.strip()]
         for i in range(0, len(lines), args.batch):
