@@ -126,7 +126,8 @@ class _PinnedRing:
     SLOTS, BYTES = 32, 1 << 16
 
     def __init__(self):
-        self.slots, self.next = [], 0
+        import threading
+        self.slots, self.next, self.lock = [], 0, threading.Lock()
 
     def copy(self, src, device, dtype=None):
         dtype = dtype or src.dtype
@@ -134,6 +135,10 @@ class _PinnedRing:
         nbytes = src.numel() * src.element_size()
         if nbytes > self.BYTES or nbytes == 0:
             return src.to(device)
+        with self.lock:                                  # host threads driving different streams share the ring
+            return self._copy_locked(src, device, dtype, nbytes)
+
+    def _copy_locked(self, src, device, dtype, nbytes):
         if len(self.slots) < self.SLOTS:
             self.slots.append(dict(buf=torch.empty(self.BYTES, dtype=torch.uint8).pin_memory(), event=None))
             slot = self.slots[-1]
