@@ -955,3 +955,59 @@ def test_fused_adam_counts_every_skipped_step_when_the_host_runs_ahead():
             opt.poll_skipped()
         assert opt.poll_skipped(wait=True) == 2
     assert opt.poll_skipped() == 2                  # a poll without a new step only accounts
+
+
+def test_to_device_async_copies_values_without_synchronising():
+    """kernels.to_device_async: small host tensors through the pinned ring - values, dtype conversion, shapes (0-d, empty, 2-d), more copies
+    than the ring has slots, a tensor too large for a slot (falls back to the ordinary copy), device tensors passed through - and no
+    synchronising call while doing so (torch's sync-debug mode raises on one)."""
+    from multilingual_text_to_speech_amd import kernels as K
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(0)
+    cases = [torch.randint(0, 1000, (64,), generator=g), torch.randint(0, 1000, (7, 3), generator=g), torch.tensor(5), torch.randn(33, generator=g),
+             torch.zeros(0, dtype=torch.int64), torch.randint(0, 2, (100,), generator=g).bool()]
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode('error')
+    try:
+        outs = [K.to_device_async(t, dev) for t in cases if t.numel()]
+        many = [K.to_device_async(torch.full((5,), i), dev, torch.int32) for i in range(3 * K._PinnedRing.SLOTS)]
+        conv = K.to_device_async(cases[0], dev, torch.int32)
+        same = K.to_device_async(outs[0], dev)
+    finally:
+        torch.cuda.set_sync_debug_mode('default')
+    for t, o in zip([t for t in cases if t.numel()], outs):
+        assert o.device.type == 'cuda' and o.shape == t.shape and o.dtype == t.dtype and torch.equal(o.cpu(), t)
+    assert all(int(m[0]) == i and m.dtype == torch.int32 for i, m in enumerate(many))
+    assert conv.dtype == torch.int32 and torch.equal(conv.cpu().long(), cases[0]) and same.data_ptr() == outs[0].data_ptr()
+    assert K.to_device_async(cases[4], dev).numel() == 0 and K.to_device_async(None, dev) is None
+    big = torch.arange(1 << 15, dtype=torch.int64)                   # 256 KB: larger than a slot
+    assert torch.equal(K.to_device_async(big, dev).cpu(), big)
+
+
+def test_train_step_makes_no_synchronising_call():
+    """A whole train step (forward, loss, backward, fused clip + Adam, the two non-blocking polls) without ONE host-side stream
+    synchronisation: round 5 made nine per step (sequence lengths moved with cpu_tensor.to(device), the optimizer's tables rebuilt whenever
+    zero_grad(set_to_none=True) had re-allocated the gradients) and each one cost the host its run-ahead - 67.6 -> 66.2 ms per step
+    (profiles/r06_host_sync_ab.txt).  torch's sync-debug mode raises on any synchronising torch call."""
+    import bench
+    from multilingual_text_to_speech_amd.params import presets, Params as hp
+    from multilingual_text_to_speech_amd.modules.tacotron2 import Tacotron, TacotronLoss
+    from multilingual_text_to_speech_amd.optim import FusedAdam
+    for preset, B in (('shared_training', 8), ('generated_switching', 10)):
+        presets.apply(preset, speaker_number=7)
+        torch.manual_seed(0)
+        dev = torch.device('cuda')
+        model = Tacotron().to(dev).train()
+        crit = TacotronLoss(hp.guided_attention_steps, hp.guided_attention_toleration, hp.guided_attention_gain)
+        opt = FusedAdam(model.parameters(), lr=hp.learning_rate, weight_decay=hp.weight_decay)
+        batch = bench.synthetic_batch(hp, B, 30, 40, dev)
+        for _ in range(2):                                            # first-touch allocations, table builds
+            bench.train_step(model, crit, opt, None, batch, hp)
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode('error')
+        try:
+            for _ in range(2):
+                bench.train_step(model, crit, opt, None, batch, hp)
+        finally:
+            torch.cuda.set_sync_debug_mode('default')
+        torch.cuda.synchronize()
