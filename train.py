@@ -166,7 +166,9 @@ def make_loader(hp, ds, train, rank, world, workers):
         sampler = DT.GlobalBatchSampler(ds, hp.batch_size, shuffle=train and not balanced, balanced=train and balanced,
                                         drop_last=train, rank=rank, world=world)
         collate = DT.Collate(True)
-    return DataLoader(ds, batch_sampler=sampler, collate_fn=collate, num_workers=workers), sampler
+    # pinned batches: `batch_to_device` copies them with non_blocking=True, which only IS asynchronous from pinned memory (from pageable memory
+    # every copy is hipMemcpyAsync + hipStreamSynchronize: the host would lose its run-ahead - and the GPU some milliseconds - once per step)
+    return DataLoader(ds, batch_sampler=sampler, collate_fn=collate, num_workers=workers, pin_memory=torch.cuda.is_available()), sampler
 
 
 EVAL_TERMS = ('mel_pre', 'mel_pos', 'stop_token', 'guided_att', 'lang_class')      # the loss dictionary of TacotronLoss.forward
